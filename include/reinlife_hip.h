@@ -1,0 +1,171 @@
+/* reinlife_hip.h -- C ABI of libreinlife_hip.so: the MI355X (gfx950) implementation of ReinLife's hot path.
+ *
+ * The reference (MaartenGr/ReinLife v1.0.1) is pure Python and has no FFI; this ABI is what a binding for its
+ * per-tick path would call.  Each entry point names the reference code it replaces (paths under ReinLife/):
+ *
+ *   rl_step            Environment.step()                         World/environment.py:160-186
+ *   rl_update          Environment.update_env() minus the Tracker World/environment.py:188-215
+ *   rl_tick            step() + update_env() of one trainer-loop iteration, fused (Helpers/trainer.py:92,99)
+ *   rl_observe         Environment._get_observations()            World/environment.py:313-375
+ *   rl_reset_synthetic Environment.reset()-style world generator  World/environment.py:133-158, 741-761
+ *   rl_policy_act      Agent.get_action() over all agents         World/entities.py:215-222 ->
+ *                      DQN.py:126-139, D3QN.py:161-173, PERD3QN.py:198-210, PPO.py:101-106,164-169
+ *   rl_policy_forward  the bare network forward of one brain on a dense batch of observation rows
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types.  `stream` is a hipStream_t passed as void*.
+ *   - The CALLER owns every device buffer (e.g. torch tensors) and the stream; the library allocates no device
+ *     memory, starts no threads and never synchronises the device.  A handle is not thread-safe; distinct handles
+ *     are independent.
+ *   - Every function returns 0 on success or a negative rl_status; rl_last_error() gives the message (thread-local).
+ *   - World state is struct-of-arrays over `n_worlds` independent worlds.  A world's agent list is ALWAYS its
+ *     on-grid agents in row-major cell order (= Grid.get_entities order, World/grid.py:60-67), so index k is index
+ *     k of the reference's env.agents.
+ *   - Randomness: either a recorded tape of the reference's draws (parity mode) or Philox4x32-10 keyed
+ *     (seed, epoch, world, tick, site, index) generated in-kernel (performance mode).  See DESIGN.md.
+ */
+#ifndef REINLIFE_HIP_H
+#define REINLIFE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RL_OBS_DIM 153   /* Environment.observation_space, environment.py:119 */
+#define RL_N_ACTIONS 8   /* Environment.action_space, environment.py:118; World/utils.py:4-17 */
+#define RL_N_BEST 10     /* len(best_agents), environment.py:149 */
+#define RL_FOOD_TRIES 7  /* 3 Food + 3 Poison + 1 SuperFood set_random calls, environment.py:763-776 */
+#define RL_MAX_CELLS 4096
+#define RL_MAX_BRAINS 64
+
+typedef enum {
+    RL_OK = 0, RL_E_INVALID = -1, RL_E_UNBOUND = -2, RL_E_LAUNCH = -3, RL_E_UNSUPPORTED = -4
+} rl_status;
+
+/* cell codes: World/utils.py:20-33 (kin = 4 is never placed on the grid) */
+enum { RL_EMPTY = 0, RL_FOOD = 1, RL_POISON = 2, RL_AGENT = 3, RL_KIN = 4, RL_SUPER_FOOD = 5 };
+/* a_flags bits (Agent booleans, World/entities.py:150-159) */
+enum { RL_F_DEAD = 1, RL_F_REPRODUCED = 2, RL_F_KILLED = 4, RL_F_ATE_SUPER = 8, RL_F_INTER_KILLED = 16,
+       RL_F_INTRA_KILLED = 32 };
+/* brain kinds (BasicBrain.method, Models/utils.py:1-14) */
+enum { RL_DQN = 0, RL_D3QN = 1, RL_PERD3QN = 2, RL_PPO = 3 };
+/* Philox draw sites */
+enum { RL_SITE_FOOD = 1, RL_SITE_REPRO = 2, RL_SITE_BIRTH = 3, RL_SITE_PRODUCE = 4, RL_SITE_ACT = 5,
+       RL_SITE_RESET_AGENT = 6, RL_SITE_RESET_FOOD = 7, RL_SITE_RESET_POISON = 8, RL_SITE_RESET_SUPER = 9 };
+
+/* keyword arguments of Environment(...) that matter on the path (environment.py:74-89) */
+typedef struct {
+    int32_t width, height;
+    int32_t max_agents;
+    int32_t n_brains;            /* len(brains) */
+    int32_t slot_cap;            /* capacity of the per-world agent arrays; multiple of 64, >= 2*max_agents+2 */
+    int32_t n_worlds;
+    int32_t static_families, limit_reproduction, incentivize_killing;
+    int32_t reserved;
+    uint64_t seed;               /* Philox key */
+} rl_config;
+
+/* Device pointers, all caller-owned.  Shapes: R = n_worlds, C = width*height, cap = slot_cap. */
+typedef struct {
+    uint8_t* cell_type;   /* [R][C]   Grid.get_numpy() */
+    int32_t* n_agents;    /* [R]      len(env.agents) */
+    uint8_t* a_i;         /* [R][cap] Agent.i */
+    uint8_t* a_j;         /* [R][cap] Agent.j */
+    int32_t* a_health;    /* [R][cap] */
+    int32_t* a_age;
+    int32_t* a_max_age;
+    int32_t* a_gene;
+    int32_t* a_brain;     /* index into the brains list the agent's brain descends from */
+    int32_t* a_uid;       /* creation-order id within the world (object identity in the reference) */
+    uint8_t* a_flags;
+    int8_t* a_action;     /* last action taken, -1 for newborns (entities.py:153) */
+    double* a_fitness;    /* Agent.fitness (float64 sum of rewards, entities.py:189) */
+    int32_t* max_gene;    /* [R] Environment.max_gene */
+    int32_t* next_uid;    /* [R] */
+    int32_t* tick;        /* [R] ticks since the last reset (Philox counter) */
+    int32_t* epoch;       /* [R] resets so far (Philox key) */
+    int32_t* best_uid;    /* [R][10] Environment.best_agents (non-static families) */
+    double* best_fit;     /* [R][10] */
+    int32_t* best_brain;  /* [R][10] */
+} rl_state;
+
+/* One tick of recorded reference draws (device pointers).  food_k == NULL => Philox. */
+typedef struct {
+    const int32_t* food_k;         /* [R][7]     np.random.randint results of _add_food's set_random calls */
+    const double* food_u;          /* [R][7]     their np.random.random coins */
+    const double* repro_u;         /* [R][cap]   random.random() gate of the k-th eligible agent (env.py:501) */
+    const int32_t* birth_k;        /* [R][cap+1] np.random.randint result of the b-th birth placement */
+    const double* produce_u;       /* [R]        random.random() gate of _produce (env.py:528) */
+    const int32_t* produce_choice; /* [R]        static: chosen gene (env.py:536/538); else best_agents index (:544) */
+} rl_tape;
+
+/* Outputs of a step, indexed in the POST-step env.agents order.  Any pointer may be NULL. */
+typedef struct {
+    int32_t* n_acted;   /* [R]       agents that acted = agent-steps of this tick */
+    float* reward;      /* [R][cap]  Agent.reward */
+    uint8_t* done;      /* [R][cap]  Agent.done */
+    int16_t* src;       /* [R][cap]  index of the agent in the PRE-step list (its state/action live there) */
+    float* obs;         /* [R][cap][153] Agent.state_prime */
+} rl_step_out;
+
+/* Outputs of an update, indexed in the POST-update env.agents order. */
+typedef struct {
+    int16_t* src;       /* [R][cap]  index in the post-step list, -1 for newborns */
+    float* obs;         /* [R][cap][153] Agent.state (what the policy reads next tick) */
+} rl_update_out;
+
+/* One brain of the brains list. */
+typedef struct {
+    int32_t kind;            /* RL_DQN .. RL_PPO */
+    float epsilon;           /* exploration rate (0 = greedy, training=False); ignored for PPO (always samples) */
+    const float* packed;     /* device: weights in the layout produced by rl_policy_pack_weights */
+} rl_brain;
+
+typedef struct rl_world rl_world;
+
+const char* rl_last_error(void);
+const char* rl_version(void);
+
+int rl_create(const rl_config* cfg, rl_world** out);
+void rl_destroy(rl_world* h);
+int rl_bind_state(rl_world* h, const rl_state* device_ptrs);
+/* optional device int32[4] that kernels set on inconsistencies: [0] code, [1] world, [2..3] detail */
+int rl_bind_error_flag(rl_world* h, int32_t* device_flag);
+
+int rl_reset_synthetic(rl_world* h, int n_agents, float* obs, void* stream);
+/* worlds with n_agents < threshold are re-generated (epoch+1); refill_count: optional device int32 accumulator */
+int rl_refill(rl_world* h, int threshold, int n_agents, float* obs, int32_t* refill_count, void* stream);
+int rl_observe(rl_world* h, float* obs, void* stream);
+int rl_step(rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_step_out* out, void* stream);
+int rl_update(rl_world* h, const rl_tape* tape, const rl_update_out* out, void* stream);
+int rl_tick(rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_step_out* sout,
+            const rl_update_out* uout, void* stream);
+
+/* ---- policy ------------------------------------------------------------------------------------------------- */
+/* number of floats in a brain's state dict (flat, registration order) / in its packed MFMA layout */
+int64_t rl_policy_n_params(int kind);
+int64_t rl_policy_packed_floats(int kind);
+/* host -> host: state-dict order  (DQN: fc1.w fc1.b fc2.w fc2.b fc3.w fc3.b;  D3QN/PERD3QN: fc.w fc.b adv_fc1.w
+ * adv_fc1.b adv_fc2.w adv_fc2.b value_fc1.w value_fc1.b value_fc2.w value_fc2.b;  PPO: fc1.w fc1.b fc2.w fc2.b
+ * fc_pi.w fc_pi.b fc_v.w fc_v.b)  ->  MFMA-fragment-major layout read by the kernels */
+int rl_policy_pack_weights(int kind, const float* state_dict_flat, float* packed);
+/* dense batch: obs [n_rows][153] (device) -> out [n_rows][8]: Q values (per-row dueling mean) or PPO probabilities */
+int rl_policy_forward(int kind, const float* packed, const float* obs, int64_t n_rows, float* out, void* stream);
+/* all agents of all worlds: row (w,k) uses brains[a_brain[w][k]].
+ *   obs     [R][cap][153]   actions [R][cap] (written for k < n_agents[w])   out_q [R][cap][8] or NULL
+ *   work    device scratch of rl_policy_work_bytes(h) bytes
+ *   tape_actions: optional [R][cap] recorded actions (parity mode) that override the selected ones */
+size_t rl_policy_work_bytes(const rl_world* h);
+int rl_policy_act(rl_world* h, const rl_brain* brains, int n_brains, const float* obs, int8_t* actions, float* out_q,
+                  void* work, void* stream);
+
+/* Philox4x32-10 exactly as the kernels use it (host helper for tests / tools) */
+void rl_philox(uint64_t seed, uint32_t epoch, uint32_t world, uint32_t tick, uint32_t site, uint32_t index,
+               uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,46 @@
+"""Builds libreinlife_hip.so (hipcc, gfx950 only) in-tree: reinlife_amd/lib/libreinlife_hip.so."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libreinlife_hip.so")
+SOURCES = ["rl_world.hip", "rl_policy.hip", "rl_capi.hip"]
+HEADERS = ["rl_common.h", os.path.join("..", "..", "include", "reinlife_hip.h")]
+# -ffp-contract=off: the world kernels' float64 reward / fitness arithmetic must round exactly like the CPU path
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [sp] + hdrs):
+            cmd = [hipcc] + FLAGS + ["-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    if force or _stale(LIB_PATH, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

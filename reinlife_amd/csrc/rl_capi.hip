@@ -1,0 +1,190 @@
+// rl_capi.hip -- extern "C" surface of libreinlife_hip.so (see include/reinlife_hip.h for the contract).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "rl_common.h"
+
+// implemented in rl_world.hip / rl_policy.hip
+size_t rl_world_smem_bytes(int cpad, int cap, int hash);
+int rl_world_block();
+int rl_world_prepare();
+int rl_world_launch_step(const rl_world*, const int8_t*, const rl_tape*, const rl_step_out*, hipStream_t);
+int rl_world_launch_update(const rl_world*, const rl_tape*, const rl_update_out*, hipStream_t);
+int rl_world_launch_tick(const rl_world*, const int8_t*, const rl_tape*, const rl_step_out*, const rl_update_out*, hipStream_t);
+int rl_world_launch_observe(const rl_world*, float*, hipStream_t);
+int rl_world_launch_reset(const rl_world*, int, int, float*, int32_t*, hipStream_t);
+int64_t rl_policy_n_params_impl(int);
+int64_t rl_policy_packed_floats_impl(int);
+int rl_policy_pack_impl(int, const float*, float*);
+int rl_policy_forward_impl(int, const float*, const float*, int64_t, float*, hipStream_t);
+size_t rl_policy_work_bytes_impl(const rl_world*);
+int rl_policy_act_impl(rl_world*, const rl_brain*, int, const float*, int8_t*, float*, void*, hipStream_t);
+
+static thread_local char g_err[512] = "";
+
+void rl_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+const char* rl_last_error(void) { return g_err; }
+const char* rl_version(void) { return "reinlife_hip 0.1 (gfx950)"; }
+
+int rl_create(const rl_config* cfg, rl_world** out)
+{
+    if (!cfg || !out) { rl_set_error("rl_create: null argument"); return RL_E_INVALID; }
+    *out = nullptr;
+    if (cfg->width < 3 || cfg->height < 3 || cfg->width > 255 || cfg->height > 255) {  // Grid asserts >= 3 (grid.py:23-24)
+        rl_set_error("rl_create: width/height must be in [3,255] (got %dx%d)", cfg->width, cfg->height);
+        return RL_E_INVALID;
+    }
+    const int cells = cfg->width * cfg->height;
+    if (cells > RL_MAX_CELLS) { rl_set_error("rl_create: %d cells > %d supported", cells, RL_MAX_CELLS); return RL_E_UNSUPPORTED; }
+    if (cfg->n_brains < 1 || cfg->n_brains > RL_MAX_BRAINS) { rl_set_error("rl_create: n_brains must be in [1,%d]", RL_MAX_BRAINS); return RL_E_INVALID; }
+    if (cfg->n_worlds < 1) { rl_set_error("rl_create: n_worlds must be >= 1"); return RL_E_INVALID; }
+    if (cfg->max_agents < 1) { rl_set_error("rl_create: max_agents must be >= 1"); return RL_E_INVALID; }
+    if (cfg->slot_cap < 64 || (cfg->slot_cap & 63) || cfg->slot_cap > 4096 || cfg->slot_cap < 2 * cfg->max_agents + 2) {
+        rl_set_error("rl_create: slot_cap must be a multiple of 64 in [max(64, 2*max_agents+2), 4096] (got %d)", cfg->slot_cap);
+        return RL_E_INVALID;
+    }
+    rl_world* h = new (std::nothrow) rl_world();
+    if (!h) { rl_set_error("rl_create: out of memory"); return RL_E_INVALID; }
+    h->cfg = *cfg;
+    h->cells = cells;
+    h->cpad = (cells + 63) & ~63;
+    int hs = 64;
+    while (hs < 2 * cfg->slot_cap) hs <<= 1;
+    h->hash_size = hs;
+    h->smem_bytes = rl_world_smem_bytes(h->cpad, cfg->slot_cap, hs);
+    h->block = rl_world_block();
+    if (h->smem_bytes > 160 * 1024) {
+        rl_set_error("rl_create: world needs %zu bytes of LDS (> 160 KB)", h->smem_bytes);
+        delete h;
+        return RL_E_UNSUPPORTED;
+    }
+    *out = h;  // no device call here: handles can be created (and configs validated) without a GPU
+    return RL_OK;
+}
+
+void rl_destroy(rl_world* h) { delete h; }
+
+int rl_bind_state(rl_world* h, const rl_state* s)
+{
+    if (!h || !s) { rl_set_error("rl_bind_state: null argument"); return RL_E_INVALID; }
+    const void* const* p = (const void* const*)s;
+    for (size_t i = 0; i < sizeof(rl_state) / sizeof(void*); ++i)
+        if (!p[i]) { rl_set_error("rl_bind_state: state pointer #%zu is null", i); return RL_E_INVALID; }
+    h->st = *s;
+    h->bound = 1;
+    return RL_OK;
+}
+
+int rl_bind_error_flag(rl_world* h, int32_t* flag)
+{
+    if (!h) { rl_set_error("rl_bind_error_flag: null handle"); return RL_E_INVALID; }
+    h->err_flag = flag;
+    return RL_OK;
+}
+
+#define RL_CHECK_BOUND(fn)                                                              \
+    if (!h) { rl_set_error(fn ": null handle"); return RL_E_INVALID; }                 \
+    if (!h->bound) { rl_set_error(fn ": rl_bind_state was not called"); return RL_E_UNBOUND; }
+
+int rl_reset_synthetic(rl_world* h, int n_agents, float* obs, void* stream)
+{
+    RL_CHECK_BOUND("rl_reset_synthetic")
+    if (n_agents < 0 || n_agents > h->cfg.slot_cap || n_agents > h->cells) { rl_set_error("rl_reset_synthetic: bad n_agents %d", n_agents); return RL_E_INVALID; }
+    return rl_world_launch_reset(h, n_agents, -1, obs, nullptr, (hipStream_t)stream);
+}
+
+int rl_refill(rl_world* h, int threshold, int n_agents, float* obs, int32_t* refill_count, void* stream)
+{
+    RL_CHECK_BOUND("rl_refill")
+    if (threshold < 0 || n_agents < 0 || n_agents > h->cfg.slot_cap || n_agents > h->cells) { rl_set_error("rl_refill: bad arguments"); return RL_E_INVALID; }
+    return rl_world_launch_reset(h, n_agents, threshold, obs, refill_count, (hipStream_t)stream);
+}
+
+int rl_observe(rl_world* h, float* obs, void* stream)
+{
+    RL_CHECK_BOUND("rl_observe")
+    if (!obs) { rl_set_error("rl_observe: null obs"); return RL_E_INVALID; }
+    return rl_world_launch_observe(h, obs, (hipStream_t)stream);
+}
+
+static int check_tape(const rl_tape* t, const char* fn)
+{
+    if (!t || !t->food_k) return RL_OK;
+    if (!t->food_u || !t->repro_u || !t->birth_k || !t->produce_u || !t->produce_choice) {
+        rl_set_error("%s: a tape must provide all six arrays", fn);
+        return RL_E_INVALID;
+    }
+    return RL_OK;
+}
+
+int rl_step(rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_step_out* out, void* stream)
+{
+    RL_CHECK_BOUND("rl_step")
+    if (!actions) { rl_set_error("rl_step: null actions"); return RL_E_INVALID; }
+    if (int rc = check_tape(tape, "rl_step")) return rc;
+    return rl_world_launch_step(h, actions, tape, out, (hipStream_t)stream);
+}
+
+int rl_update(rl_world* h, const rl_tape* tape, const rl_update_out* out, void* stream)
+{
+    RL_CHECK_BOUND("rl_update")
+    if (int rc = check_tape(tape, "rl_update")) return rc;
+    return rl_world_launch_update(h, tape, out, (hipStream_t)stream);
+}
+
+int rl_tick(rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_step_out* sout, const rl_update_out* uout, void* stream)
+{
+    RL_CHECK_BOUND("rl_tick")
+    if (!actions) { rl_set_error("rl_tick: null actions"); return RL_E_INVALID; }
+    if (int rc = check_tape(tape, "rl_tick")) return rc;
+    return rl_world_launch_tick(h, actions, tape, sout, uout, (hipStream_t)stream);
+}
+
+int64_t rl_policy_n_params(int kind) { return rl_policy_n_params_impl(kind); }
+int64_t rl_policy_packed_floats(int kind) { return rl_policy_packed_floats_impl(kind); }
+
+int rl_policy_pack_weights(int kind, const float* sd, float* packed)
+{
+    if (!sd || !packed) { rl_set_error("rl_policy_pack_weights: null argument"); return RL_E_INVALID; }
+    return rl_policy_pack_impl(kind, sd, packed);
+}
+
+int rl_policy_forward(int kind, const float* packed, const float* obs, int64_t n_rows, float* out, void* stream)
+{
+    if (!packed || !obs || !out || n_rows < 0) { rl_set_error("rl_policy_forward: bad argument"); return RL_E_INVALID; }
+    if (kind < RL_DQN || kind > RL_PPO) { rl_set_error("rl_policy_forward: unknown brain kind %d", kind); return RL_E_INVALID; }
+    if (n_rows == 0) return RL_OK;
+    return rl_policy_forward_impl(kind, packed, obs, n_rows, out, (hipStream_t)stream);
+}
+
+size_t rl_policy_work_bytes(const rl_world* h) { return h ? rl_policy_work_bytes_impl(h) : 0; }
+
+int rl_policy_act(rl_world* h, const rl_brain* brains, int n_brains, const float* obs, int8_t* actions, float* out_q, void* work, void* stream)
+{
+    RL_CHECK_BOUND("rl_policy_act")
+    if (!brains || !obs || !actions || !work) { rl_set_error("rl_policy_act: null argument"); return RL_E_INVALID; }
+    if (n_brains != h->cfg.n_brains) { rl_set_error("rl_policy_act: n_brains %d != config %d", n_brains, h->cfg.n_brains); return RL_E_INVALID; }
+    for (int b = 0; b < n_brains; ++b)
+        if (brains[b].kind < RL_DQN || brains[b].kind > RL_PPO || !brains[b].packed) { rl_set_error("rl_policy_act: brain %d invalid", b); return RL_E_INVALID; }
+    return rl_policy_act_impl(h, brains, n_brains, obs, actions, out_q, work, (hipStream_t)stream);
+}
+
+void rl_philox(uint64_t seed, uint32_t epoch, uint32_t world, uint32_t tick, uint32_t site, uint32_t index, uint32_t out[4])
+{
+    const rl_u4 r = rl_philox4x32(seed, epoch, world, tick, site, index);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+}  // extern "C"

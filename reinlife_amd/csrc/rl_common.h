@@ -1,0 +1,53 @@
+// Shared host/device helpers of libreinlife_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/reinlife_hip.h"
+
+struct rl_world {
+    rl_config cfg;
+    rl_state st;
+    int bound;
+    int32_t* err_flag;   // device, optional
+    int cells;           // width*height
+    int cpad;            // cells rounded up to 64
+    int hash_size;       // power of two >= 2*slot_cap
+    size_t smem_bytes;   // dynamic LDS of the world kernels
+    int block;           // threads per world workgroup
+};
+
+void rl_set_error(const char* fmt, ...);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11).  counter = (index, site, tick, world), key = (seed_lo, seed_hi ^ epoch*phi)
+// ---------------------------------------------------------------------------------------------------------------
+struct rl_u4 { uint32_t x, y, z, w; };
+
+__host__ __device__ inline uint32_t rl_mulhi(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+__host__ __device__ inline rl_u4 rl_philox4x32(uint64_t seed, uint32_t epoch, uint32_t world, uint32_t tick,
+                                               uint32_t site, uint32_t index)
+{
+    uint32_t c0 = index, c1 = site, c2 = tick, c3 = world;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (epoch * 0x9E3779B9u);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = rl_mulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = rl_mulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return rl_u4{c0, c1, c2, c3};
+}
+
+// 24-bit uniform in [0,1), exactly representable in float and double
+__host__ __device__ inline double rl_u24(uint32_t x) { return (double)(x >> 8) * (1.0 / 16777216.0); }

@@ -1,0 +1,452 @@
+// rl_policy.hip -- batched policy inference for ReinLife's brains on MI355X (gfx950), hand-written HIP + MFMA.
+//
+// Reference (paths under /root/reference/ReinLife/Models):
+//   DQN      Qnet.forward            DQN.py:126-130      153 -> 128 -> 64 -> 8
+//   D3QN     dueling_ddqn.forward    D3QN.py:161-165     153 -> 128 -> (128 -> 8 || 128 -> 1), q = adv + val - mean(adv)
+//   PERD3QN  DuelingDDQN.forward     PERD3QN.py:198-202  (same network)
+//   PPO      PPO.pi                  PPO.py:101-106      153 -> 256 -> 256 -> 8 -> softmax
+//   action selection                 DQN.py:132-139, D3QN.py:167-173, PERD3QN.py:204-210, PPO.py:164-169
+// The reference runs one batch-1 forward per agent; here one wave owns 32 agents (observation rows) and runs the
+// whole MLP for them without leaving registers:
+//
+//   * fp32 everywhere (v_mfma_f32_32x32x2_f32: exact f32 fma chains, the 157 TFLOP/s matrix rate of gfx950).
+//   * transposed formulation  H_out[feature][row] = W[feature][k] . H_in[k][row]: the WEIGHTS are the MFMA A operand
+//     and the ACTIVATIONS the B operand.  The 32x32 f32 accumulator layout (lane = row, register r of half h =
+//     feature (r&3) + 8(r>>2) + 4h) is then exactly a B operand of the next layer if K-step (t, r) pairs feature
+//     32t + (r&3) + 8(r>>2) (lanes 0-31) with the same + 4 (lanes 32-63): activations never move, ReLU and bias are
+//     per-register VALU ops / one extra K-step, and the weights are pre-packed so every A fragment is one coalesced
+//     16-byte-per-lane load (rl_policy_pack_weights).
+//   * the narrow heads (8 / 1 outputs) run on the VALU (an MFMA tile would be 75-97 % padding), followed by the
+//     dueling combine / softmax and the epsilon-greedy / categorical draw (Philox) in the same kernel.
+#include "rl_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int kInQuads = 20;     // input layer: K padded to 160 = 2 halves x 20 quads x 4
+constexpr int kHalfK = 80;
+constexpr int kBiasK = 153;      // x[153] := 1, W[:,153] := bias
+
+// packed sizes (floats)
+__host__ __device__ constexpr int64_t in_layer_floats(int tiles) { return (int64_t)tiles * kInQuads * 64 * 4; }
+__host__ __device__ constexpr int64_t hid_layer_floats(int tin, int tout) { return (int64_t)tout * tin * 4 * 64 * 4 + (int64_t)tout * 64; }
+__host__ __device__ constexpr int64_t head_floats(int tin, int nout) { return (int64_t)tin * 16 * 2 * nout + nout; }
+
+struct Layout {  // offsets (floats) into a brain's packed buffer
+    int64_t l1, l2a, l2b, ha, hb, total;
+};
+__host__ __device__ inline Layout layout_of(int kind)
+{
+    Layout L{};
+    int64_t o = 0;
+    if (kind == RL_DQN) {
+        L.l1 = o; o += in_layer_floats(4);
+        L.l2a = o; o += hid_layer_floats(4, 2);
+        L.ha = o; o += head_floats(2, 8);
+    } else if (kind == RL_D3QN || kind == RL_PERD3QN) {
+        L.l1 = o; o += in_layer_floats(4);
+        L.l2a = o; o += hid_layer_floats(4, 4);
+        L.ha = o; o += head_floats(4, 8);
+        L.l2b = o; o += hid_layer_floats(4, 4);
+        L.hb = o; o += head_floats(4, 1);
+    } else {
+        L.l1 = o; o += in_layer_floats(8);
+        L.l2a = o; o += hid_layer_floats(8, 8);
+        L.ha = o; o += head_floats(8, 8);
+    }
+    L.total = o;
+    return L;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// device building blocks (everything fully unrolled: accumulators must stay in registers)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ inline f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// x quad q of this lane: row j = lane&31, half h = lane>>5 covers k = 80h + 4q + e; k == 153 is the bias input.
+// q is a constant after unrolling, so the two ragged quads cost nothing elsewhere.
+__device__ inline f32x4 load_xq(const float* __restrict__ row, int h, int q)
+{
+    if (q < 18) return *(const f32x4u*)(row + h * kHalfK + 4 * q);
+    if (q == 18) {  // half 0 -> k 72..75; half 1 -> k 152, bias, 0, 0 (reads k 149..152 to stay inside the row)
+        const f32x4 v = *(const f32x4u*)(row + (h ? 149 : 72));
+        return h ? f32x4{v.w, 1.0f, 0.0f, 0.0f} : v;
+    }
+    const f32x4 w = *(const f32x4u*)(row + 76);  // q == 19: half 0 -> k 76..79; half 1 -> padding
+    return h ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : w;
+}
+
+// The packed weights are STEP-major: [K-quad step][output tile][lane][4 floats], so the TOUT fragments of one step
+// are 1 KiB apart (immediate offsets of one running pointer).  The pointer is made opaque at every step so that the
+// compiler neither precomputes nor hoists hundreds of 64-bit addresses (that spilled the accumulators), and a
+// sched_barrier per step bounds the prefetch distance to exactly one step (2 x TOUT fragment registers).
+template <int TOUT>
+__device__ inline void layer_in(const float* __restrict__ pw, int lane, const float* __restrict__ row, f32x16 (&acc)[TOUT])
+{
+    const f32x4* p = (const f32x4*)pw + lane;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < TOUT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    f32x4 a[2][TOUT], x[2];
+#pragma unroll
+    for (int t = 0; t < TOUT; ++t) a[0][t] = p[t * 64];
+    x[0] = load_xq(row, h, 0);
+#pragma unroll
+    for (int q = 0; q < kInQuads; ++q) {
+        const int cur = q & 1, nxt = cur ^ 1;
+        if (q + 1 < kInQuads) {  // prefetch the next step's operands ahead of this step's MFMAs
+            p += TOUT * 64;
+            asm volatile("" : "+v"(p));
+#pragma unroll
+            for (int t = 0; t < TOUT; ++t) a[nxt][t] = p[t * 64];
+            x[nxt] = load_xq(row, h, q + 1);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < TOUT; ++t) acc[t] = mfma(a[cur][t][e], x[cur][e], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int TIN>
+__device__ inline void relu_inplace(f32x16 (&h)[TIN])
+{
+#pragma unroll
+    for (int t = 0; t < TIN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[t][r] = fmaxf(h[t][r], 0.0f);
+}
+
+template <int TIN, int TOUT>
+__device__ inline void layer_hidden(const float* __restrict__ pw, int lane, const f32x16 (&hin)[TIN], f32x16 (&acc)[TOUT])
+{
+    constexpr int NS = TIN * 4;  // step s = t*4 + q covers input features 32t + 8q + 4h + e
+    const f32x4* p = (const f32x4*)pw + lane;
+    const float* bias = pw + (int64_t)NS * TOUT * 64 * 4;
+    const float one = lane < 32 ? 1.0f : 0.0f;
+    f32x4 a[2][TOUT];
+#pragma unroll
+    for (int t2 = 0; t2 < TOUT; ++t2) a[0][t2] = p[t2 * 64];
+#pragma unroll
+    for (int t2 = 0; t2 < TOUT; ++t2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t2][r] = 0.0f;
+        acc[t2] = mfma(bias[t2 * 64 + lane], one, acc[t2]);  // bias as one extra K-step against a constant-1 input
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 1 < NS) {
+            p += TOUT * 64;
+            asm volatile("" : "+v"(p));
+#pragma unroll
+            for (int t2 = 0; t2 < TOUT; ++t2) a[nxt][t2] = p[t2 * 64];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t2 = 0; t2 < TOUT; ++t2) acc[t2] = mfma(a[cur][t2][e], hin[s / 4][4 * (s % 4) + e], acc[t2]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// narrow head on the VALU: out[i] = b[i] + sum_f W[i][f] h[f]; every lane ends with the full sums of its row
+template <int TIN, int NOUT>
+__device__ inline void head(const float* __restrict__ hw, int h, const f32x16 (&hin)[TIN], float (&out)[NOUT])
+{
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) out[i] = 0.0f;
+    const float* wp = hw + h * NOUT;  // [t][r][h][NOUT]
+#pragma unroll
+    for (int t = 0; t < TIN; ++t)
+#pragma unroll
+        for (int rg = 0; rg < 16; rg += 4) {
+#pragma unroll
+            for (int r = rg; r < rg + 4; ++r) {
+                const float* w = wp + (r - rg) * 2 * NOUT;
+                if (NOUT == 8) {
+                    const f32x4 w0 = *(const f32x4*)w, w1 = *(const f32x4*)(w + 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { out[i] = fmaf(hin[t][r], w0[i], out[i]); out[4 + i] = fmaf(hin[t][r], w1[i], out[4 + i]); }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NOUT; ++i) out[i] = fmaf(hin[t][r], w[i], out[i]);
+                }
+            }
+            wp += 4 * 2 * NOUT;
+            asm volatile("" : "+v"(wp));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    const float* b = hw + TIN * 16 * 2 * NOUT;
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) out[i] = out[i] + __shfl_xor(out[i], 32) + b[i];
+}
+
+struct PolicyArgs {
+    const float* packed;
+    const float* obs;         // rows of 153 floats
+    const int* rowlist;       // optional: row ids (world*cap + k); nullptr = dense rows 0..n_rows-1
+    const int* count_ptr;     // device count of rowlist entries (nullptr = n_rows)
+    int64_t n_rows;
+    float* out;               // [row][8] or nullptr
+    int8_t* actions;          // [row] or nullptr
+    float eps;
+    uint64_t seed;
+    int cap;
+    const int32_t* tick;      // per world
+    const int32_t* epoch;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_policy(const PolicyArgs A)
+{
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+    const int64_t n = A.count_ptr ? (int64_t)*A.count_ptr : A.n_rows;
+    const int64_t ntiles = (n + 31) / 32;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const Layout L = layout_of(KIND);
+    for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+        const int64_t li = tile * 32 + j;
+        const bool valid = li < n;
+        const int64_t row = valid ? (A.rowlist ? (int64_t)A.rowlist[li] : li) : (A.rowlist ? (int64_t)A.rowlist[tile * 32] : tile * 32);
+        const float* xrow = A.obs + row * RL_OBS_DIM;
+        float q[8];
+        if (KIND == RL_DQN) {
+            f32x16 h1[4], h2[2];
+            layer_in<4>(A.packed + L.l1, lane, xrow, h1);
+            relu_inplace<4>(h1);
+            layer_hidden<4, 2>(A.packed + L.l2a, lane, h1, h2);
+            relu_inplace<2>(h2);
+            head<2, 8>(A.packed + L.ha, h, h2, q);
+        } else if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
+            f32x16 h1[4], h2[4];
+            float adv[8], val[1];
+            layer_in<4>(A.packed + L.l1, lane, xrow, h1);
+            relu_inplace<4>(h1);  // relu(feature) feeds both branches (PERD3QN.py:200-201)
+            layer_hidden<4, 4>(A.packed + L.l2a, lane, h1, h2);
+            relu_inplace<4>(h2);
+            head<4, 8>(A.packed + L.ha, h, h2, adv);
+            layer_hidden<4, 4>(A.packed + L.l2b, lane, h1, h2);
+            relu_inplace<4>(h2);
+            head<4, 1>(A.packed + L.hb, h, h2, val);
+            float mean = 0.0f;  // advantage.mean() of the [1,8] tensor == per-row mean when batched
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mean += adv[i];
+            mean *= 0.125f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[i] = adv[i] + val[0] - mean;
+        } else {
+            f32x16 h1[8], h2[8];
+            layer_in<8>(A.packed + L.l1, lane, xrow, h1);
+            relu_inplace<8>(h1);
+            layer_hidden<8, 8>(A.packed + L.l2a, lane, h1, h2);
+            relu_inplace<8>(h2);
+            head<8, 8>(A.packed + L.ha, h, h2, q);
+            float m = q[0], s = 0.0f;  // softmax over the 8 logits (PPO.py:105)
+#pragma unroll
+            for (int i = 1; i < 8; ++i) m = fmaxf(m, q[i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { q[i] = expf(q[i] - m); s += q[i]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[i] = q[i] / s;
+        }
+        if (valid && h == 0) {
+            if (A.out) {
+                f32x4* o = (f32x4*)(A.out + row * 8);
+                o[0] = f32x4{q[0], q[1], q[2], q[3]};
+                o[1] = f32x4{q[4], q[5], q[6], q[7]};
+            }
+            if (A.actions) {
+                const int w = (int)(row / A.cap), k = (int)(row - (int64_t)w * A.cap);
+                const rl_u4 r = rl_philox4x32(A.seed, (uint32_t)A.epoch[w], (uint32_t)w, (uint32_t)A.tick[w], RL_SITE_ACT, (uint32_t)k);
+                const float u = (float)rl_u24(r.x);
+                int a = 0;
+                if (KIND == RL_PPO) {  // Categorical(prob).sample() as inverse CDF
+                    float cum = 0.0f; a = 7; bool found = false;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { cum += q[i]; if (!found && u < cum) { a = i; found = true; } }
+                } else if (u < A.eps) a = (int)(r.y >> 29);
+                else {
+#pragma unroll
+                    for (int i = 1; i < 8; ++i) if (q[i] > q[a]) a = i;  // first maximum
+                }
+                A.actions[row] = (int8_t)a;
+            }
+        }
+    }
+}
+
+// per-brain row lists: one wave per world, ballot compaction + one atomic per (world, brain)
+__global__ __launch_bounds__(256) void k_bucket(const int32_t* __restrict__ n_agents, const int32_t* __restrict__ a_brain,
+                                                int n_worlds, int cap, int n_brains, int* __restrict__ counts,
+                                                int* __restrict__ lists, int64_t list_stride)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= n_worlds) return;
+    const int n = n_agents[w];
+    for (int base = 0; base < n; base += 64) {
+        const int k = base + lane;
+        const int b = k < n ? a_brain[(size_t)w * cap + k] : -1;
+        for (int bb = 0; bb < n_brains; ++bb) {
+            const unsigned long long m = __ballot(b == bb);
+            if (!m) continue;
+            int pos = 0;
+            if (lane == 0) pos = atomicAdd(&counts[bb], __popcll(m));
+            pos = __shfl(pos, 0);
+            if (b == bb) lists[bb * list_stride + pos + __popcll(m & ((1ull << lane) - 1ull))] = w * cap + k;
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+int64_t rl_policy_n_params_impl(int kind)
+{
+    if (kind == RL_DQN) return 153 * 128 + 128 + 128 * 64 + 64 + 64 * 8 + 8;
+    if (kind == RL_D3QN || kind == RL_PERD3QN) return 153 * 128 + 128 + 2 * (128 * 128 + 128) + 128 * 8 + 8 + 128 + 1;
+    if (kind == RL_PPO) return 153 * 256 + 256 + 256 * 256 + 256 + 256 * 8 + 8 + 256 + 1;
+    return -1;
+}
+int64_t rl_policy_packed_floats_impl(int kind)
+{
+    if (kind < RL_DQN || kind > RL_PPO) return -1;
+    return layout_of(kind).total;
+}
+
+static void pack_in_layer(const float* W, const float* b, int n_out, float* dst)
+{
+    // dst[q][t][lane][e] = Wext[32t + (lane&31)][80*(lane>>5) + 4q + e],  Wext[:,153] = bias, Wext[:,154..159] = 0
+    const int tout = n_out / 32;
+    for (int q = 0; q < kInQuads; ++q)
+        for (int t = 0; t < tout; ++t)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int o = 32 * t + (lane & 31), k = kHalfK * (lane >> 5) + 4 * q + e;
+                    float v = 0.0f;
+                    if (k < 153) v = W[(size_t)o * 153 + k];
+                    else if (k == kBiasK) v = b[o];
+                    dst[(((size_t)q * tout + t) * 64 + lane) * 4 + e] = v;
+                }
+}
+static void pack_hidden_layer(const float* W, const float* b, int n_in, int n_out, float* dst)
+{
+    // dst[s = t*4+q][t2][lane][e] = W[32 t2 + (lane&31)][32 t + 8 q + 4 (lane>>5) + e];  then bias[t2][lane]
+    const int tin = n_in / 32, tout = n_out / 32;
+    for (int t = 0; t < tin; ++t)
+        for (int q = 0; q < 4; ++q)
+            for (int t2 = 0; t2 < tout; ++t2)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int o = 32 * t2 + (lane & 31), k = 32 * t + 8 * q + 4 * (lane >> 5) + e;
+                        dst[((((size_t)t * 4 + q) * tout + t2) * 64 + lane) * 4 + e] = W[(size_t)o * n_in + k];
+                    }
+    float* bias = dst + (size_t)tout * tin * 4 * 64 * 4;
+    for (int t2 = 0; t2 < tout; ++t2)
+        for (int lane = 0; lane < 64; ++lane) bias[t2 * 64 + lane] = lane < 32 ? b[32 * t2 + lane] : 0.0f;
+}
+static void pack_head(const float* W, const float* b, int n_in, int n_out, float* dst)
+{
+    // dst[t][r][h][i] = W[i][32 t + (r&3) + 8 (r>>2) + 4 h];  then bias[i]
+    const int tin = n_in / 32;
+    for (int t = 0; t < tin; ++t)
+        for (int r = 0; r < 16; ++r)
+            for (int h = 0; h < 2; ++h)
+                for (int i = 0; i < n_out; ++i)
+                    dst[(((size_t)t * 16 + r) * 2 + h) * n_out + i] = W[(size_t)i * n_in + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+    for (int i = 0; i < n_out; ++i) dst[(size_t)tin * 16 * 2 * n_out + i] = b[i];
+}
+
+int rl_policy_pack_impl(int kind, const float* sd, float* packed)
+{
+    if (kind < RL_DQN || kind > RL_PPO) { rl_set_error("unknown brain kind %d", kind); return RL_E_INVALID; }
+    const Layout L = layout_of(kind);
+    const float* p = sd;
+    if (kind == RL_DQN) {
+        pack_in_layer(p, p + 153 * 128, 128, packed + L.l1); p += 153 * 128 + 128;
+        pack_hidden_layer(p, p + 128 * 64, 128, 64, packed + L.l2a); p += 128 * 64 + 64;
+        pack_head(p, p + 64 * 8, 64, 8, packed + L.ha);
+    } else if (kind == RL_D3QN || kind == RL_PERD3QN) {
+        pack_in_layer(p, p + 153 * 128, 128, packed + L.l1); p += 153 * 128 + 128;
+        pack_hidden_layer(p, p + 128 * 128, 128, 128, packed + L.l2a); p += 128 * 128 + 128;
+        pack_head(p, p + 128 * 8, 128, 8, packed + L.ha); p += 128 * 8 + 8;
+        pack_hidden_layer(p, p + 128 * 128, 128, 128, packed + L.l2b); p += 128 * 128 + 128;
+        pack_head(p, p + 128, 128, 1, packed + L.hb);
+    } else {
+        pack_in_layer(p, p + 153 * 256, 256, packed + L.l1); p += 153 * 256 + 256;
+        pack_hidden_layer(p, p + 256 * 256, 256, 256, packed + L.l2a); p += 256 * 256 + 256;
+        pack_head(p, p + 256 * 8, 256, 8, packed + L.ha);  // fc_v is not evaluated when acting (PPO.py:164-169)
+    }
+    return RL_OK;
+}
+
+static int policy_grid(int64_t max_rows)
+{
+    const int64_t tiles = (max_rows + 31) / 32;
+    int64_t blocks = (tiles + 3) / 4;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    return (int)blocks;
+}
+
+static int launch_policy(int kind, const PolicyArgs& a, int64_t max_rows, hipStream_t st)
+{
+    const dim3 grid(policy_grid(max_rows)), block(256);
+    switch (kind) {
+        case RL_DQN: hipLaunchKernelGGL((k_policy<RL_DQN>), grid, block, 0, st, a); break;
+        case RL_D3QN: hipLaunchKernelGGL((k_policy<RL_D3QN>), grid, block, 0, st, a); break;
+        case RL_PERD3QN: hipLaunchKernelGGL((k_policy<RL_PERD3QN>), grid, block, 0, st, a); break;
+        case RL_PPO: hipLaunchKernelGGL((k_policy<RL_PPO>), grid, block, 0, st, a); break;
+        default: rl_set_error("unknown brain kind %d", kind); return RL_E_INVALID;
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rl_set_error("policy kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
+    return RL_OK;
+}
+
+int rl_policy_forward_impl(int kind, const float* packed, const float* obs, int64_t n_rows, float* out, hipStream_t st)
+{
+    PolicyArgs a{};
+    a.packed = packed; a.obs = obs; a.n_rows = n_rows; a.out = out; a.cap = 1;
+    return launch_policy(kind, a, n_rows, st);
+}
+
+size_t rl_policy_work_bytes_impl(const rl_world* h)
+{
+    return 64 * sizeof(int) + (size_t)h->cfg.n_brains * h->cfg.n_worlds * h->cfg.slot_cap * sizeof(int);
+}
+
+int rl_policy_act_impl(rl_world* h, const rl_brain* brains, int n_brains, const float* obs, int8_t* actions, float* out_q,
+                       void* work, hipStream_t st)
+{
+    const int R = h->cfg.n_worlds, cap = h->cfg.slot_cap;
+    int* counts = (int*)work;
+    int* lists = counts + 64;
+    const int64_t stride = (int64_t)R * cap;
+    hipError_t e = hipMemsetAsync(counts, 0, 64 * sizeof(int), st);
+    if (e != hipSuccess) { rl_set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
+    hipLaunchKernelGGL(k_bucket, dim3((R + 3) / 4), dim3(256), 0, st, h->st.n_agents, h->st.a_brain, R, cap, n_brains, counts, lists, stride);
+    e = hipGetLastError();
+    if (e != hipSuccess) { rl_set_error("bucket kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
+    for (int b = 0; b < n_brains; ++b) {
+        PolicyArgs a{};
+        a.packed = brains[b].packed; a.obs = obs; a.rowlist = lists + b * stride; a.count_ptr = counts + b;
+        a.n_rows = 0; a.out = out_q; a.actions = actions; a.eps = brains[b].epsilon; a.seed = h->cfg.seed; a.cap = cap;
+        a.tick = h->st.tick; a.epoch = h->st.epoch;
+        // upper bound of rows for this brain: every live agent (max_agents-bounded populations in practice)
+        const int64_t bound = (int64_t)R * (int64_t)(2 * h->cfg.max_agents + 2 < cap ? 2 * h->cfg.max_agents + 2 : cap);
+        const int rc = launch_policy(brains[b].kind, a, bound, st);
+        if (rc) return rc;
+    }
+    return RL_OK;
+}

@@ -1,0 +1,972 @@
+// rl_world.hip -- the ReinLife world tick on MI355X (gfx950), hand-written HIP.
+//
+// One workgroup per world.  The world (H*W type grid + row-major agent list, ~6 KB) is staged into LDS once, the
+// whole tick runs out of LDS, and the new row-major list + both observation passes are streamed back to HBM.
+//
+// Reference semantics (paths under /root/reference/ReinLife; the sequential restatement is oracle/rl_oracle.c):
+//   step()        World/environment.py:160-186   _act :258-275, _attack :652-699, _prepare_movement :591-625,
+//                 _execute_movement :627-650, _eat :701-715, _update_agent_position :778-782,
+//                 _update_death_status :789-793, _get_rewards :277-311, _add_food :763-776
+//   update_env()  World/environment.py:188-215   _update_best_agents :728-739, _reproduce :488-519, _produce :521-547,
+//                 _remove_dead_agents :795-799
+//   observation   World/environment.py:313-456 + Grid.fov World/grid.py:90-117
+//
+// The reference resolves everything sequentially in agent (row-major cell) order.  Here each phase is a closed form
+// evaluated by one lane per agent, ordered only by comparing cell indices:
+//   attack    final health from the set of successful attackers among the 4 neighbours and own success
+//   movement  Jacobi fixed point on an LDS target-count grid (one __syncthreads_or per iteration)
+//   vanish    a mover entering the cell of a later-ordered mover is erased (sequential grid overwrite)
+//   ordering  Grid.get_entities == rank of the agent's cell in a 64-bit-per-wave ballot bitmap (popcount prefix)
+//   set_random  k-th empty cell == select on the ballot bitmap of occupied cells, held in wave 0's registers
+#include "rl_common.h"
+
+int rl_world_prepare();
+
+namespace {
+
+constexpr int kSuper = RL_SUPER_FOOD;
+constexpr uint8_t kPadCell = 0xFF;  // grid padding up to a multiple of 64 cells: neither empty nor anything else
+
+// scalar slots in LDS
+enum { S_ALIVE = 0, S_NFOOD, S_NPOISON, S_NSUPER, S_NSLOTS, S_N1, S_N2, S_NPARENTS, S_NELIG, S_BESTK, S_ERR, S_COUNT = 16 };
+
+struct KParams {
+    int W, H, C, Cp, nW;
+    int cap, max_agents, n_brains, hash_size, hash_mask;
+    int static_families, limit_reproduction, incentivize_killing;
+    uint64_t seed;
+    rl_state st;
+    const int8_t* actions;
+    rl_tape tape;
+    rl_step_out so;
+    rl_update_out uo;
+    float* obs_only;
+    int32_t* err;
+    int reset_n_agents, refill_threshold;
+    int32_t* refill_count;
+};
+
+struct Smem {
+    unsigned long long* occbits;  // [64] non-empty cells
+    unsigned long long* agbits;   // [64] agent cells
+    int* wordbase;                // [64] exclusive prefix of popc(agbits)
+    int* scal;                    // [S_COUNT]
+    int* best_uid;                // [16]
+    int* best_brain;              // [16]
+    double* best_fit;             // [16]
+    double* wred_f;               // [16] per-wave argmax
+    int* wred_k;                  // [16]
+    int* present;                 // [RL_MAX_BRAINS]
+    int* hkey;                    // [hash]
+    unsigned* hcnt;               // [hash] low 16: alive, high 16: on grid
+    float* foodv;                 // [Cp]  (aliased: unsigned target counts during movement)
+    float* healthv;               // [Cp]
+    int* genev;                   // [Cp]
+    short* occ;                   // [Cp]
+    uint8_t* type;                // [Cp]
+    int *health, *age, *max_age, *gene, *brain, *uid;  // [cap]
+    double *fitness, *reward;                          // [cap]
+    unsigned short *pos, *tgt, *hslot;                 // [cap]
+    short *newidx, *order, *src, *plist;               // [cap]
+    uint8_t *flags, *aux;                              // [cap]
+    signed char* action;                               // [cap]
+};
+
+enum { AUX_VANISH = 1, AUX_PARENT = 2 };
+
+__host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+__host__ __device__ inline size_t carve(Smem& s, char* base, int Cp, int cap, int hash)
+{
+    size_t o = 0;
+#define CARVE(field, type, count) s.field = (type*)(base + o); o = align16(o + sizeof(type) * (size_t)(count));
+    CARVE(occbits, unsigned long long, 64)
+    CARVE(agbits, unsigned long long, 64)
+    CARVE(best_fit, double, 16)
+    CARVE(wred_f, double, 16)
+    CARVE(fitness, double, cap)
+    CARVE(reward, double, cap)
+    CARVE(wordbase, int, 64)
+    CARVE(scal, int, S_COUNT)
+    CARVE(best_uid, int, 16)
+    CARVE(best_brain, int, 16)
+    CARVE(wred_k, int, 16)
+    CARVE(present, int, RL_MAX_BRAINS)
+    CARVE(hkey, int, hash)
+    CARVE(hcnt, unsigned, hash)
+    CARVE(foodv, float, Cp)
+    CARVE(healthv, float, Cp)
+    CARVE(genev, int, Cp)
+    CARVE(health, int, cap)
+    CARVE(age, int, cap)
+    CARVE(max_age, int, cap)
+    CARVE(gene, int, cap)
+    CARVE(brain, int, cap)
+    CARVE(uid, int, cap)
+    CARVE(occ, short, Cp)
+    CARVE(pos, unsigned short, cap)
+    CARVE(tgt, unsigned short, cap)
+    CARVE(hslot, unsigned short, cap)
+    CARVE(newidx, short, cap)
+    CARVE(order, short, cap)
+    CARVE(src, short, cap)
+    CARVE(plist, short, cap)
+    CARVE(type, uint8_t, Cp)
+    CARVE(flags, uint8_t, cap)
+    CARVE(aux, uint8_t, cap)
+    CARVE(action, signed char, cap)
+#undef CARVE
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------------------------
+__device__ inline int lane_id() { return threadIdx.x & 63; }
+__device__ inline unsigned long long shfl_u64(unsigned long long v, int src)
+{
+    unsigned lo = __shfl((unsigned)v, src), hi = __shfl((unsigned)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ inline double shfl_f64(double v, int src) { return __longlong_as_double((long long)shfl_u64((unsigned long long)__double_as_longlong(v), src)); }
+__device__ inline double shfl_xor_f64(double v, int m)
+{
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    unsigned lo = __shfl_xor((unsigned)u, m), hi = __shfl_xor((unsigned)(u >> 32), m);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ inline int wave_incl_scan(int v)
+{
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(v, d); if (l >= d) v += t; }
+    return v;
+}
+__device__ inline unsigned long long lowmask(int b) { return b ? (~0ull >> (64 - b)) : 0ull; }
+
+// toroidal neighbour of cell (i,j): up 0 (i-1), right 1 (j+1), down 2 (i+1), left 3 (j-1)   World/utils.py:4-17
+__device__ inline int neighbour_cell(int i, int j, int d, int W, int H)
+{
+    int ni = i, nj = j;
+    if (d == 0) ni = (i == 0) ? H - 1 : i - 1;
+    else if (d == 1) nj = (j == W - 1) ? 0 : j + 1;
+    else if (d == 2) ni = (i == H - 1) ? 0 : i + 1;
+    else nj = (j == 0) ? W - 1 : j - 1;
+    return ni * W + nj;
+}
+
+// k-th empty cell of Grid.set_random (World/grid.py:69-83) as a select on wave 0's occupancy bitmap.
+struct Placer {
+    unsigned long long word;  // lane l: cells 64l..64l+63, bit set = not empty
+    int n_empty;
+};
+__device__ inline int placer_take(Placer& P, int k)
+{
+    const int l = lane_id();
+    const int zeros = __popcll(~P.word);
+    const int incl = wave_incl_scan(zeros);
+    const unsigned long long m = __ballot(k < incl);
+    const int L = __ffsll((long long)m) - 1;
+    const int excl = __shfl(incl - zeros, L);
+    const unsigned long long z = ~shfl_u64(P.word, L);
+    const int kk = k - excl;
+    const bool set = (z >> l) & 1ull;
+    const int rank = __popcll(z & lowmask(l));
+    const unsigned long long hit = __ballot(set && rank == kk);
+    const int bit = __ffsll((long long)hit) - 1;
+    if (l == L) P.word |= 1ull << bit;
+    P.n_empty -= 1;
+    return L * 64 + bit;
+}
+
+__device__ inline void flag_error(const KParams& p, Smem& s, int code, int w, int d0, int d1)
+{
+    if (p.err && atomicCAS(p.err, 0, code) == 0) { p.err[1] = w; p.err[2] = d0; p.err[3] = d1; }
+    s.scal[S_ERR] = code;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// phases
+// ---------------------------------------------------------------------------------------------------------------
+template <int T>
+__device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
+{
+    const int tid = threadIdx.x;
+    n0 = p.st.n_agents[w];
+    const uint8_t* gt = p.st.cell_type + (size_t)w * p.C;
+    for (int c = tid; c < p.Cp; c += T) {
+        s.type[c] = c < p.C ? gt[c] : kPadCell;
+        s.occ[c] = -1;
+        ((unsigned*)s.foodv)[c] = 0u;
+    }
+    for (int i = tid; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
+    if (tid < S_COUNT) s.scal[tid] = 0;
+    if (tid < RL_MAX_BRAINS) s.present[tid] = 0;
+    if (tid < RL_N_BEST) {
+        s.best_uid[tid] = p.st.best_uid[(size_t)w * RL_N_BEST + tid];
+        s.best_fit[tid] = p.st.best_fit[(size_t)w * RL_N_BEST + tid];
+        s.best_brain[tid] = p.st.best_brain[(size_t)w * RL_N_BEST + tid];
+    }
+    const size_t b = (size_t)w * p.cap;
+    for (int a = tid; a < n0; a += T) {
+        s.pos[a] = (unsigned short)(p.st.a_i[b + a] | (p.st.a_j[b + a] << 8));
+        s.health[a] = p.st.a_health[b + a];
+        s.age[a] = p.st.a_age[b + a];
+        s.max_age[a] = p.st.a_max_age[b + a];
+        s.gene[a] = p.st.a_gene[b + a];
+        s.brain[a] = p.st.a_brain[b + a];
+        s.uid[a] = p.st.a_uid[b + a];
+        s.flags[a] = p.st.a_flags[b + a];
+        s.action[a] = p.st.a_action[b + a];
+        s.fitness[a] = p.st.a_fitness[b + a];
+        s.aux[a] = 0;
+        s.src[a] = (short)a;
+        s.order[a] = (short)a;
+        s.newidx[a] = (short)a;
+    }
+    __syncthreads();
+    for (int a = tid; a < n0; a += T) s.occ[(s.pos[a] & 255) * p.W + (s.pos[a] >> 8)] = (short)a;
+    if (tid == 0) s.scal[S_NSLOTS] = n0;
+    __syncthreads();
+}
+
+// gene -> (alive count, on-grid count) open-addressing table; every agent remembers its slot
+__device__ inline void hash_insert(Smem& s, int mask, int a, int gene, unsigned add)
+{
+    unsigned h = ((unsigned)gene * 2654435761u) & (unsigned)mask;
+    for (;;) {
+        const int old = atomicCAS(&s.hkey[h], -1, gene);
+        if (old == -1 || old == gene) break;
+        h = (h + 1) & (unsigned)mask;
+    }
+    if (add) atomicAdd(&s.hcnt[h], add);
+    s.hslot[a] = (unsigned short)h;
+}
+
+// Grid.get_entities order of the current grid: newidx[a] / order[k] for all slots, returns count via scal[slot]
+template <int T>
+__device__ void build_order(const KParams& p, Smem& s, int nslots, int out_slot)
+{
+    const int tid = threadIdx.x;
+    for (int c = tid; c < p.Cp; c += T) {
+        const unsigned long long m = __ballot(s.type[c] == RL_AGENT);
+        if (lane_id() == 0) s.agbits[c >> 6] = m;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int cntw = tid < p.nW ? __popcll(s.agbits[tid]) : 0;
+        const int incl = wave_incl_scan(cntw);
+        s.wordbase[tid] = incl - cntw;
+        if (tid == 63) s.scal[out_slot] = incl;
+    }
+    __syncthreads();
+    for (int a = tid; a < nslots; a += T) {
+        const int cell = (s.pos[a] & 255) * p.W + (s.pos[a] >> 8);
+        short ni = -1;
+        if (s.occ[cell] == a) {
+            ni = (short)(s.wordbase[cell >> 6] + __popcll(s.agbits[cell >> 6] & lowmask(cell & 63)));
+            s.order[ni] = (short)a;
+        }
+        s.newidx[a] = ni;
+    }
+    __syncthreads();
+}
+
+// _prepare_observations (environment.py:377-404) into LDS planes
+template <int T>
+__device__ void build_planes(const KParams& p, Smem& s)
+{
+    const bool float_mode = s.type[0] == RL_AGENT;  // np.vectorize dtype inference from cell (0,0)
+    for (int c = threadIdx.x; c < p.C; c += T) {
+        const int t = s.type[c];
+        float f = 0.f, h = -1.f;
+        int g = -2;
+        if (t == RL_FOOD) f = 0.5f;
+        else if (t == kSuper) f = 1.f;
+        else if (t == RL_POISON) f = -1.f;
+        else if (t == RL_AGENT) {
+            const int a = s.occ[c];
+            const int hp = s.health[a];
+            if (hp < 0) f = 1.f;                                   // _get_food, environment.py:440-444
+            const double v = (double)hp / 200.0;
+            h = float_mode ? (float)v : (float)(double)(long long)v;  // astype(int64) truncates toward zero
+            if (s.flags[a] & RL_F_DEAD) g = s.gene[a];             // _get_genes, environment.py:448-456
+        }
+        s.foodv[c] = f; s.healthv[c] = h; s.genev[c] = g;
+    }
+}
+
+// _get_observations (environment.py:349-375): n agents in order[] -> obs rows (coalesced 49-float runs)
+template <int T>
+__device__ void write_observations(const KParams& p, Smem& s, int w, int n, float* obs)
+{
+    if (!obs) return;
+    float* base = obs + (size_t)w * p.cap * RL_OBS_DIM;
+    const int total = n * 49;
+    for (int q = threadIdx.x; q < total; q += T) {
+        const int k = q / 49, idx = q - k * 49;
+        const int a = s.order[k];
+        const int i = s.pos[a] & 255, j = s.pos[a] >> 8;
+        const int r = idx / 7, cc = idx - r * 7;
+        int ci = i + r - 3, cj = j + cc - 3;
+        ci += ci < 0 ? p.H : 0; ci -= ci >= p.H ? p.H : 0;
+        cj += cj < 0 ? p.W : 0; cj -= cj >= p.W ? p.W : 0;
+        const int c = ci * p.W + cj;
+        const int g = s.genev[c];
+        float* o = base + (size_t)k * RL_OBS_DIM + idx;
+        o[0] = s.foodv[c];
+        o[49] = s.healthv[c];
+        o[98] = g == -2 ? 0.f : (g == s.gene[a] ? 1.f : -1.f);  // _extract_gene_observation, environment.py:424-428
+    }
+    for (int k = threadIdx.x; k < n; k += T) {
+        const int a = s.order[k];
+        const int same = (int)(s.hcnt[s.hslot[a]] >> 16);
+        float* o = base + (size_t)k * RL_OBS_DIM + 147;
+        o[0] = (float)((double)s.health[a] / 200.0);
+        o[1] = (s.flags[a] & RL_F_REPRODUCED) ? 1.f : 0.f;
+        o[2] = (float)((double)same / (double)n);
+        o[3] = (float)((double)n / (double)p.max_agents);
+        o[4] = (s.flags[a] & RL_F_KILLED) ? 1.f : 0.f;
+        o[5] = (s.flags[a] & RL_F_ATE_SUPER) ? 1.f : -1.f;
+    }
+}
+
+// Environment.step up to (not including) the observation pass
+template <int T>
+__device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
+{
+    const int tid = threadIdx.x;
+    const int W = p.W, H = p.H;
+    unsigned* cnt = (unsigned*)s.foodv;
+    // ---- _act prologue + _attack (closed form) + _prepare_movement ------------------------------------------------
+    const int8_t* acts = p.actions + (size_t)w * p.cap;
+    for (int a = tid; a < n0; a += T) s.action[a] = acts[a];
+    __syncthreads();
+    for (int a = tid; a < n0; a += T) {
+        const int i = s.pos[a] & 255, j = s.pos[a] >> 8, cx = i * W + j;
+        const int act = s.action[a];
+        const int fl = s.flags[a] & ~(RL_F_KILLED | RL_F_INTER_KILLED | RL_F_INTRA_KILLED);
+        const bool dead = fl & RL_F_DEAD;
+        const int h0 = min(200, s.health[a] - 10);
+        s.age[a] = min(s.max_age[a], s.age[a] + 1);
+        // own attack: succeeds iff the adjacent cell holds an agent (environment.py:692)
+        bool own = false;
+        int nfl = fl;
+        if (!dead && act >= 4 && act <= 7) {
+            const int t = s.occ[neighbour_cell(i, j, act - 4, W, H)];
+            if (t >= 0) {
+                own = true;
+                nfl |= RL_F_KILLED | (s.gene[t] == s.gene[a] ? RL_F_INTER_KILLED : RL_F_INTRA_KILLED);
+            }
+        }
+        // successful attackers of this agent: the neighbour in direction d attacking in direction d^2
+        int zmax = -1;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int nc = neighbour_cell(i, j, d, W, H);
+            const int y = s.occ[nc];
+            if (y >= 0 && !(s.flags[y] & RL_F_DEAD) && s.action[y] == 4 + (d ^ 2)) zmax = max(zmax, nc);
+        }
+        int h;
+        if (own) h = zmax > cx ? 0 : (zmax >= 0 ? 100 : min(200, h0 + 100));
+        else h = zmax >= 0 ? 0 : h0;
+        s.health[a] = h;
+        s.flags[a] = (uint8_t)nfl;
+        const int tg = (!dead && act >= 0 && act <= 3) ? neighbour_cell(i, j, act, W, H) : cx;
+        s.tgt[a] = (unsigned short)tg;
+        atomicAdd(&cnt[tg], 1u);
+    }
+    __syncthreads();
+    // ---- _execute_movement: Jacobi fixed point (environment.py:637-644) --------------------------------------------
+    for (;;) {
+        int conflict = 0;
+        for (int a = tid; a < n0; a += T) {
+            const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
+            const bool c = s.tgt[a] != cx && cnt[s.tgt[a]] > 1u;
+            s.aux[a] = c ? 0x80 : 0;
+            conflict |= c;
+        }
+        if (!__syncthreads_or(conflict)) break;
+        for (int a = tid; a < n0; a += T)
+            if (s.aux[a] & 0x80) {
+                const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
+                atomicSub(&cnt[s.tgt[a]], 1u);
+                atomicAdd(&cnt[cx], 1u);
+                s.tgt[a] = (unsigned short)cx;
+            }
+        __syncthreads();
+    }
+    // ---- _eat + vanish rule (reads the pre-move grid) ----------------------------------------------------------------
+    for (int a = tid; a < n0; a += T) {
+        const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
+        const int tg = s.tgt[a], act = s.action[a];
+        uint8_t ax = 0;
+        if (act >= 0 && act <= 3) {
+            const int tt = s.type[tg];
+            if (tt == RL_FOOD) s.health[a] = min(200, s.health[a] + 40);
+            else if (tt == RL_POISON) s.health[a] = min(200, s.health[a] - 40);
+            else if (tt == kSuper) {
+                s.health[a] = min(200, s.health[a] + 40);
+                s.max_age[a] = (int)((double)s.max_age[a] * 1.2);
+                s.flags[a] |= RL_F_ATE_SUPER;
+            }
+            // entering the cell of a later-ordered agent that is itself leaving: erased by its grid[old]=Empty
+            if (tg != cx && s.occ[tg] >= 0 && tg > cx) ax = AUX_VANISH;
+        }
+        s.aux[a] = ax;
+    }
+    __syncthreads();
+    for (int a = tid; a < n0; a += T) {
+        const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
+        if (s.tgt[a] != cx) { s.type[cx] = RL_EMPTY; s.occ[cx] = -1; }
+    }
+    __syncthreads();
+    int alive_local = 0;
+    for (int a = tid; a < n0; a += T) {
+        const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
+        const int tg = s.tgt[a];
+        if (tg != cx) {
+            if (!(s.aux[a] & AUX_VANISH)) { s.type[tg] = RL_AGENT; s.occ[tg] = (short)a; }
+            const int ti = tg / W;
+            s.pos[a] = (unsigned short)(ti | ((tg - ti * W) << 8));
+        }
+        // _update_death_status (environment.py:789-793)
+        int fl = s.flags[a];
+        if (s.health[a] <= 0 || s.age[a] == s.max_age[a]) fl |= RL_F_DEAD;
+        s.flags[a] = (uint8_t)fl;
+        const unsigned alive = (fl & RL_F_DEAD) ? 0u : 1u;
+        const unsigned ongrid = (s.aux[a] & AUX_VANISH) ? 0u : 1u;
+        alive_local += (int)alive;
+        hash_insert(s, p.hash_mask, a, s.gene[a], alive | (ongrid << 16));
+    }
+    if (alive_local) atomicAdd(&s.scal[S_ALIVE], alive_local);
+    __syncthreads();
+    // ---- _get_rewards over the _act list incl. vanished agents (environment.py:291-311) ------------------------------
+    const int alive = s.scal[S_ALIVE];
+    for (int a = tid; a < n0; a += T) {
+        const int kin = max(0, (int)(s.hcnt[s.hslot[a]] & 0xFFFFu) - 1);
+        double r;
+        if (s.flags[a] & RL_F_DEAD) r = (double)(kin - alive);
+        else if (alive == 1) r = 0.0;
+        else r = (double)kin / (double)alive;
+        if ((s.flags[a] & RL_F_KILLED) && p.incentivize_killing) r += 0.2;
+        s.reward[a] = r;
+        s.fitness[a] += r;
+        if (!p.static_families && s.uid[a] >= 0)  // best_agents are references: their fitness tracks the live agent
+            for (int b = 0; b < RL_N_BEST; ++b)
+                if (s.best_uid[b] == s.uid[a]) s.best_fit[b] = s.fitness[a];
+    }
+    // ---- _add_food (environment.py:763-776) ---------------------------------------------------------------------------
+    int nf = 0, np_ = 0, ns = 0;
+    for (int c = tid; c < p.Cp; c += T) {
+        const int t = s.type[c];
+        nf += t == RL_FOOD; np_ += t == RL_POISON; ns += t == kSuper;
+        const unsigned long long m = __ballot(t != RL_EMPTY);
+        if (lane_id() == 0) s.occbits[c >> 6] = m;
+    }
+    if (nf) atomicAdd(&s.scal[S_NFOOD], nf);
+    if (np_) atomicAdd(&s.scal[S_NPOISON], np_);
+    if (ns) atomicAdd(&s.scal[S_NSUPER], ns);
+    __syncthreads();
+    if (tid < 64) {
+        Placer P;
+        P.word = tid < p.nW ? s.occbits[tid] : ~0ull;
+        int ne = __popcll(~P.word);
+#pragma unroll
+        for (int m = 32; m; m >>= 1) ne += __shfl_xor(ne, m);
+        P.n_empty = ne;
+        const bool tape = p.tape.food_k != nullptr;
+        unsigned xk = 0; double u = 2.0;
+        if (tid < RL_FOOD_TRIES) {
+            if (tape) { xk = (unsigned)p.tape.food_k[(size_t)w * RL_FOOD_TRIES + tid]; u = p.tape.food_u[(size_t)w * RL_FOOD_TRIES + tid]; }
+            else {
+                const rl_u4 r = rl_philox4x32(p.seed, (uint32_t)p.st.epoch[w], (uint32_t)w, (uint32_t)p.st.tick[w], RL_SITE_FOOD, (uint32_t)tid);
+                xk = r.x; u = rl_u24(r.y);
+            }
+        }
+        const bool en_food = (double)s.scal[S_NFOOD] <= (double)p.C / 10.0;
+        const bool en_poison = (double)s.scal[S_NPOISON] <= (double)p.C / 20.0;
+        const bool en_super = s.scal[S_NSUPER] == 0;
+        for (int t = 0; t < RL_FOOD_TRIES; ++t) {
+            const bool en = t < 3 ? en_food : (t < 6 ? en_poison : en_super);
+            if (!en || P.n_empty <= 0) continue;  // empty grid: randint raises, nothing is drawn (grid.py:82-83)
+            const unsigned x = __shfl(xk, t);
+            const double ut = shfl_f64(u, t);
+            const int k = tape ? (int)x : (int)rl_mulhi(x, (unsigned)P.n_empty);
+            if (k < 0 || k >= P.n_empty) { if (tid == 0) flag_error(p, s, 1, w, t, k); continue; }
+            if (!(ut < (t < 6 ? 0.2 : 1.0))) continue;
+            const int cell = placer_take(P, k);
+            if (tid == 0) s.type[cell] = (uint8_t)(t < 3 ? RL_FOOD : (t < 6 ? RL_POISON : kSuper));
+        }
+        if (tid < p.nW) s.occbits[tid] = P.word;
+    }
+    __syncthreads();
+}
+
+__device__ inline void init_newborn(Smem& s, int idx, int cell, int W, int gene, int brain, int uid)
+{
+    const int i = cell / W;
+    s.pos[idx] = (unsigned short)(i | ((cell - i * W) << 8));
+    s.health[idx] = 200; s.age[idx] = 0; s.max_age[idx] = 50;  // entities.py:145-159
+    s.gene[idx] = gene; s.brain[idx] = brain; s.uid[idx] = uid;
+    s.flags[idx] = 0; s.action[idx] = -1; s.fitness[idx] = 0.0; s.reward[idx] = 0.0;
+    s.aux[idx] = 0; s.src[idx] = -1; s.tgt[idx] = (unsigned short)cell;
+    s.occ[cell] = (short)idx; s.type[cell] = RL_AGENT;
+}
+
+// Environment.update_env up to (not including) the observation pass.  order[0..n1) is the grid list.
+template <int T>
+__device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslots)
+{
+    const int tid = threadIdx.x;
+    // ---- _update_best_agents (environment.py:728-739) ----------------------------------------------------------------
+    if (!p.static_families) {
+        double bf = -1.0e300; int bk = 0x7fffffff;
+        for (int k = tid; k < n1; k += T) {
+            const double f = s.fitness[s.order[k]];
+            if (f > bf || (f == bf && k < bk)) { bf = f; bk = k; }
+        }
+#pragma unroll
+        for (int m = 32; m; m >>= 1) {
+            const double of = shfl_xor_f64(bf, m); const int ok = __shfl_xor(bk, m);
+            if (of > bf || (of == bf && ok < bk)) { bf = of; bk = ok; }
+        }
+        if (lane_id() == 0) { s.wred_f[tid >> 6] = bf; s.wred_k[tid >> 6] = bk; }
+        __syncthreads();
+        if (tid == 0 && n1 > 0) {
+            for (int v = 1; v < T / 64; ++v)
+                if (s.wred_f[v] > bf || (s.wred_f[v] == bf && s.wred_k[v] < bk)) { bf = s.wred_f[v]; bk = s.wred_k[v]; }
+            int mi = 0;
+            for (int b = 1; b < RL_N_BEST; ++b) if (s.best_fit[b] < s.best_fit[mi]) mi = b;
+            const int a = s.order[bk];
+            bool present = false;
+            for (int b = 0; b < RL_N_BEST; ++b) present |= s.best_uid[b] == s.uid[a];
+            if (!present && bf > s.best_fit[mi]) { s.best_uid[mi] = s.uid[a]; s.best_fit[mi] = bf; s.best_brain[mi] = s.brain[a]; }
+        }
+        __syncthreads();
+    }
+    // ---- _reproduce gates (environment.py:500-501): eligible agents in list order, one draw each ---------------------
+    const bool room = n1 <= p.max_agents;
+    const bool tape = p.tape.food_k != nullptr;
+    const uint32_t epoch = (uint32_t)p.st.epoch[w], tick = (uint32_t)p.st.tick[w];
+    // pass A: eligibility bitmap over list index (reuses agbits/wordbase; rebuilt by build_order afterwards)
+    const int n1p = (n1 + 63) & ~63;
+    for (int k = tid; k < n1p; k += T) {
+        bool e = false;
+        if (k < n1) {
+            const int a = s.order[k];
+            e = room && !(s.flags[a] & (RL_F_DEAD | RL_F_REPRODUCED)) && s.age[a] > 5;  // can_reproduce, entities.py:244
+            if (p.static_families && s.gene[a] >= 0 && s.gene[a] < RL_MAX_BRAINS) s.present[s.gene[a]] = 1;
+        }
+        const unsigned long long m = __ballot(e);
+        if (lane_id() == 0) s.agbits[k >> 6] = m;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int nw = n1p >> 6;
+        const int cntw = tid < nw ? __popcll(s.agbits[tid]) : 0;
+        const int incl = wave_incl_scan(cntw);
+        s.wordbase[tid] = incl - cntw;
+        if (tid == 63) s.scal[S_NELIG] = incl;
+    }
+    __syncthreads();
+    // pass B: gate draw by eligible rank; parents bitmap
+    for (int k = tid; k < n1p; k += T) {
+        bool par = false;
+        if (k < n1 && ((s.agbits[k >> 6] >> (k & 63)) & 1ull)) {
+            const int rank = s.wordbase[k >> 6] + __popcll(s.agbits[k >> 6] & lowmask(k & 63));
+            double u;
+            if (tape) u = p.tape.repro_u[(size_t)w * p.cap + rank];
+            else u = rl_u24(rl_philox4x32(p.seed, epoch, (uint32_t)w, tick, RL_SITE_REPRO, (uint32_t)rank).x);
+            par = u > 0.95;
+            if (par && p.limit_reproduction) s.flags[s.order[k]] |= RL_F_REPRODUCED;
+        }
+        const unsigned long long m = __ballot(par);
+        if (lane_id() == 0) s.occbits[k >> 6] = m;  // parents bitmap; occbits is rebuilt below before its next use
+    }
+    __syncthreads();
+    // compact parents in list order
+    if (tid < 64) {
+        const int nw = n1p >> 6;
+        const int cntw = tid < nw ? __popcll(s.occbits[tid]) : 0;
+        const int incl = wave_incl_scan(cntw);
+        s.wordbase[tid] = incl - cntw;
+        if (tid == 63) s.scal[S_NPARENTS] = incl;
+    }
+    __syncthreads();
+    for (int k = tid; k < n1; k += T)
+        if ((s.occbits[k >> 6] >> (k & 63)) & 1ull)
+            s.plist[s.wordbase[k >> 6] + __popcll(s.occbits[k >> 6] & lowmask(k & 63))] = s.order[k];
+    __syncthreads();
+    // occupancy bitmap for placements (dead agents still occupy their cells here)
+    for (int c = tid; c < p.Cp; c += T) {
+        const unsigned long long m = __ballot(s.type[c] != RL_EMPTY);
+        if (lane_id() == 0) s.occbits[c >> 6] = m;
+    }
+    __syncthreads();
+    // ---- births: _reproduce placements then _produce (environment.py:502-547), sequential on wave 0 ------------------
+    if (tid < 64) {
+        Placer P;
+        P.word = tid < p.nW ? s.occbits[tid] : ~0ull;
+        int ne = __popcll(~P.word);
+#pragma unroll
+        for (int m = 32; m; m >>= 1) ne += __shfl_xor(ne, m);
+        P.n_empty = ne;
+        const int npar = s.scal[S_NPARENTS];
+        int next_uid = p.st.next_uid[w];
+        int max_gene = p.st.max_gene[w];
+        int n_birth = 0, slots = nslots;
+        for (int b = 0; b < npar; ++b) {
+            if (P.n_empty <= 0) continue;  // full grid: randint raises, no draw, no offspring (grid.py:82-83)
+            unsigned x;  // draw indices advance only when a draw happens
+            if (tape) x = (unsigned)p.tape.birth_k[(size_t)w * (p.cap + 1) + n_birth];
+            else x = rl_philox4x32(p.seed, epoch, (uint32_t)w, tick, RL_SITE_BIRTH, (uint32_t)n_birth).x;
+            const int k = tape ? (int)x : (int)rl_mulhi(x, (unsigned)P.n_empty);
+            ++n_birth;
+            if (k < 0 || k >= P.n_empty) { if (tid == 0) flag_error(p, s, 2, w, b, k); continue; }
+            const int cell = placer_take(P, k);
+            if (slots >= p.cap) { if (tid == 0) flag_error(p, s, 3, w, slots, 0); continue; }
+            const int par = s.plist[b];
+            if (tid == 0) init_newborn(s, slots, cell, p.W, s.gene[par], p.static_families ? s.gene[par] : s.brain[par], next_uid);
+            ++slots; ++next_uid;
+        }
+        // _produce
+        if (room) {
+            double u; unsigned x1 = 0;
+            if (tape) u = p.tape.produce_u[w];
+            else { const rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)w, tick, RL_SITE_PRODUCE, 0u); u = rl_u24(r.x); x1 = r.y; }
+            if (u > 0.95) {
+                int gene = -1, brain = 0;
+                if (p.static_families) {
+                    if (tape) gene = p.tape.produce_choice[w];
+                    else {
+                        const bool absent = tid < p.n_brains && !s.present[tid];
+                        const unsigned long long m = __ballot(absent);
+                        const int cntabs = __popcll(m);
+                        if (cntabs > 0) {
+                            const int want = (int)rl_mulhi(x1, (unsigned)cntabs);
+                            const unsigned long long hit = __ballot(absent && __popcll(m & lowmask(tid)) == want);
+                            gene = __ffsll((long long)hit) - 1;
+                        } else gene = (int)rl_mulhi(x1, (unsigned)p.n_brains);
+                    }
+                    brain = gene;
+                } else {
+                    max_gene += 1;  // incremented even if the placement fails (environment.py:543)
+                    const int c = tape ? p.tape.produce_choice[w] : (int)rl_mulhi(x1, RL_N_BEST);
+                    gene = max_gene;
+                    brain = (c >= 0 && c < RL_N_BEST) ? s.best_brain[c] : 0;
+                    if (c < 0 || c >= RL_N_BEST) { if (tid == 0) flag_error(p, s, 4, w, c, 0); }
+                }
+                if (P.n_empty > 0 && gene >= 0) {
+                    unsigned x;
+                    if (tape) x = (unsigned)p.tape.birth_k[(size_t)w * (p.cap + 1) + n_birth];
+                    else x = rl_philox4x32(p.seed, epoch, (uint32_t)w, tick, RL_SITE_BIRTH, (uint32_t)n_birth).x;
+                    const int k = tape ? (int)x : (int)rl_mulhi(x, (unsigned)P.n_empty);
+                    if (k < 0 || k >= P.n_empty) { if (tid == 0) flag_error(p, s, 2, w, -1, k); }
+                    else {
+                        const int cell = placer_take(P, k);
+                        if (slots >= p.cap) { if (tid == 0) flag_error(p, s, 3, w, slots, 0); }
+                        else { if (tid == 0) init_newborn(s, slots, cell, p.W, gene, brain, next_uid); ++slots; ++next_uid; }
+                    }
+                }
+            }
+        }
+        if (tid == 0) { s.scal[S_NSLOTS] = slots; p.st.next_uid[w] = next_uid; p.st.max_gene[w] = max_gene; }
+    }
+    __syncthreads();
+    nslots = s.scal[S_NSLOTS];
+    // ---- _remove_dead_agents (environment.py:795-799): corpses become Food ---------------------------------------------
+    for (int k = tid; k < n1; k += T) {
+        const int a = s.order[k];
+        if (s.flags[a] & RL_F_DEAD) {
+            const int cell = (s.pos[a] & 255) * p.W + (s.pos[a] >> 8);
+            s.type[cell] = RL_FOOD; s.occ[cell] = -1;
+        }
+    }
+    __syncthreads();
+}
+
+// on-grid gene counts for the observation's percent_genes (environment.py:357)
+template <int T>
+__device__ void rebuild_gene_counts(const KParams& p, Smem& s, int n)
+{
+    for (int i = threadIdx.x; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += T) { const int a = s.order[k]; hash_insert(s, p.hash_mask, a, s.gene[a], 1u << 16); }
+    __syncthreads();
+}
+
+template <int T>
+__device__ void store_world(const KParams& p, Smem& s, int w, int n)
+{
+    const int tid = threadIdx.x;
+    uint8_t* gt = p.st.cell_type + (size_t)w * p.C;
+    for (int c = tid; c < p.C; c += T) gt[c] = s.type[c];
+    const size_t b = (size_t)w * p.cap;
+    for (int k = tid; k < n; k += T) {
+        const int a = s.order[k];
+        p.st.a_i[b + k] = (uint8_t)(s.pos[a] & 255);
+        p.st.a_j[b + k] = (uint8_t)(s.pos[a] >> 8);
+        p.st.a_health[b + k] = s.health[a];
+        p.st.a_age[b + k] = s.age[a];
+        p.st.a_max_age[b + k] = s.max_age[a];
+        p.st.a_gene[b + k] = s.gene[a];
+        p.st.a_brain[b + k] = s.brain[a];
+        p.st.a_uid[b + k] = s.uid[a];
+        p.st.a_flags[b + k] = s.flags[a];
+        p.st.a_action[b + k] = s.action[a];
+        p.st.a_fitness[b + k] = s.fitness[a];
+    }
+    if (tid == 0) p.st.n_agents[w] = n;
+    if (tid < RL_N_BEST && !p.static_families) {
+        p.st.best_uid[(size_t)w * RL_N_BEST + tid] = s.best_uid[tid];
+        p.st.best_fit[(size_t)w * RL_N_BEST + tid] = s.best_fit[tid];
+        p.st.best_brain[(size_t)w * RL_N_BEST + tid] = s.best_brain[tid];
+    }
+}
+
+enum { MODE_STEP = 0, MODE_UPDATE = 1, MODE_TICK = 2, MODE_OBSERVE = 3 };
+
+template <int T, int MODE>
+__global__ __launch_bounds__(T) void k_world(const KParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Smem s;
+    carve(s, smem_raw, p.Cp, p.cap, p.hash_size);
+    const int w = blockIdx.x;
+    const int tid = threadIdx.x;
+    int n0;
+    load_world<T>(p, s, w, n0);
+    int nslots = n0;
+    int n_cur = n0;  // length of order[]
+
+    if (MODE == MODE_OBSERVE) {
+        rebuild_gene_counts<T>(p, s, n0);
+        build_planes<T>(p, s);
+        __syncthreads();
+        write_observations<T>(p, s, w, n0, p.obs_only);
+        return;
+    }
+    if (MODE == MODE_STEP || MODE == MODE_TICK) {
+        phase_step<T>(p, s, w, n0);
+        build_order<T>(p, s, nslots, S_N1);
+        const int n1 = s.scal[S_N1];
+        build_planes<T>(p, s);
+        __syncthreads();
+        write_observations<T>(p, s, w, n1, p.so.obs);
+        const size_t b = (size_t)w * p.cap;
+        for (int k = tid; k < n1; k += T) {
+            const int a = s.order[k];
+            if (p.so.reward) p.so.reward[b + k] = (float)s.reward[a];
+            if (p.so.done) p.so.done[b + k] = (s.flags[a] & RL_F_DEAD) ? 1 : 0;
+            if (p.so.src) p.so.src[b + k] = (short)a;
+        }
+        if (tid == 0 && p.so.n_acted) p.so.n_acted[w] = n0;
+        n_cur = n1;
+        if (MODE == MODE_STEP) { store_world<T>(p, s, w, n1); return; }
+        __syncthreads();
+        // fused tick: agents keep their LDS slot; remember their post-step list index for uo.src
+        for (int a = tid; a < nslots; a += T) s.src[a] = s.newidx[a];
+        if (tid < RL_MAX_BRAINS) s.present[tid] = 0;
+        __syncthreads();
+    }
+    if (MODE == MODE_UPDATE || MODE == MODE_TICK) {
+        const int n1 = n_cur;
+        phase_update<T>(p, s, w, n1, nslots);
+        build_order<T>(p, s, nslots, S_N2);
+        const int n2 = s.scal[S_N2];
+        rebuild_gene_counts<T>(p, s, n2);
+        build_planes<T>(p, s);
+        __syncthreads();
+        write_observations<T>(p, s, w, n2, p.uo.obs);
+        if (p.uo.src) {
+            const size_t b = (size_t)w * p.cap;
+            for (int k = tid; k < n2; k += T) p.uo.src[b + k] = s.src[s.order[k]];
+        }
+        store_world<T>(p, s, w, n2);
+        if (tid == 0) p.st.tick[w] += 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// synthetic world generator (same rule as oracle/rl_oracle.c reset_world) + refill
+// ---------------------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(T) void k_reset(const KParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Smem s;
+    carve(s, smem_raw, p.Cp, p.cap, p.hash_size);
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (p.refill_threshold >= 0) {
+        if (p.st.n_agents[w] >= p.refill_threshold) return;  // uniform per workgroup
+    }
+    __syncthreads();
+    uint32_t epoch = (uint32_t)p.st.epoch[w];
+    if (p.refill_threshold >= 0) epoch += 1;
+    for (int c = tid; c < p.Cp; c += T) { s.type[c] = c < p.C ? (uint8_t)RL_EMPTY : kPadCell; s.occ[c] = -1; }
+    if (tid < S_COUNT) s.scal[tid] = 0;
+    __syncthreads();
+    const int n_agents = p.reset_n_agents;
+    if (tid < 64) {
+        Placer P;
+        P.word = 0ull;
+        if (tid >= p.nW) P.word = ~0ull;
+        else if (tid == p.nW - 1 && (p.C & 63)) P.word = ~lowmask(p.C & 63);
+        P.n_empty = p.C;
+        int placed = 0;
+        for (int a = 0; a < n_agents && P.n_empty > 0; ++a) {
+            const rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)w, 0u, RL_SITE_RESET_AGENT, (uint32_t)a);
+            const int cell = placer_take(P, (int)rl_mulhi(r.x, (unsigned)P.n_empty));
+            const int gene = (int)rl_mulhi(r.y, (unsigned)p.n_brains);
+            if (tid == 0) init_newborn(s, a, cell, p.W, gene, gene, a);
+            ++placed;
+        }
+        for (int pass = 0; pass < 2; ++pass) {
+            const uint32_t site = pass == 0 ? RL_SITE_RESET_FOOD : RL_SITE_RESET_POISON;
+            const double prob = pass == 0 ? 0.1 : 0.05;
+            for (int i0 = 0; i0 < p.C; i0 += 64) {
+                // 64 iterations' draws at once, one per lane; placements stay sequential
+                const int i = i0 + tid;
+                rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)w, 0u, site, (uint32_t)i);
+                const bool want = i < p.C && rl_u24(r.y) < prob;
+                unsigned long long m = __ballot(want);
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    if (P.n_empty <= 0) continue;
+                    const unsigned x = __shfl(r.x, l);
+                    const int cell = placer_take(P, (int)rl_mulhi(x, (unsigned)P.n_empty));
+                    if (tid == 0) s.type[cell] = (uint8_t)(pass == 0 ? RL_FOOD : RL_POISON);
+                }
+            }
+        }
+        if (P.n_empty > 0) {
+            const rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)w, 0u, RL_SITE_RESET_SUPER, 0u);
+            const int cell = placer_take(P, (int)rl_mulhi(r.x, (unsigned)P.n_empty));
+            if (tid == 0) s.type[cell] = (uint8_t)kSuper;
+        }
+        if (tid == 0) {
+            s.scal[S_NSLOTS] = placed;
+            p.st.next_uid[w] = placed; p.st.max_gene[w] = p.n_brains; p.st.tick[w] = 0; p.st.epoch[w] = (int)epoch;
+            if (p.refill_count) atomicAdd(p.refill_count, 1);
+        }
+        if (tid < RL_N_BEST) {
+            s.best_uid[tid] = -1; s.best_fit[tid] = 0.0; s.best_brain[tid] = 0;
+            p.st.best_uid[(size_t)w * RL_N_BEST + tid] = -1;
+            p.st.best_fit[(size_t)w * RL_N_BEST + tid] = 0.0;
+            p.st.best_brain[(size_t)w * RL_N_BEST + tid] = 0;
+        }
+    }
+    __syncthreads();
+    const int nslots = s.scal[S_NSLOTS];
+    build_order<T>(p, s, nslots, S_N2);
+    const int n = s.scal[S_N2];
+    rebuild_gene_counts<T>(p, s, n);
+    build_planes<T>(p, s);
+    __syncthreads();
+    write_observations<T>(p, s, w, n, p.obs_only);
+    KParams q = p;  // store_world writes best_* only for non-static; done above for both
+    store_world<T>(q, s, w, n);
+}
+
+constexpr int kBlock = 256;
+
+KParams make_params(const rl_world* h)
+{
+    KParams p{};
+    p.W = h->cfg.width; p.H = h->cfg.height; p.C = h->cells; p.Cp = h->cpad; p.nW = h->cpad / 64;
+    p.cap = h->cfg.slot_cap; p.max_agents = h->cfg.max_agents; p.n_brains = h->cfg.n_brains;
+    p.hash_size = h->hash_size; p.hash_mask = h->hash_size - 1;
+    p.static_families = h->cfg.static_families; p.limit_reproduction = h->cfg.limit_reproduction;
+    p.incentivize_killing = h->cfg.incentivize_killing;
+    p.seed = h->cfg.seed;
+    p.st = h->st;
+    p.err = h->err_flag;
+    p.refill_threshold = -1;
+    return p;
+}
+
+int prepare_once()
+{
+    static int state = 1;  // 1 = not yet, 0 = ok, <0 = failed
+    if (state == 1) state = rl_world_prepare();
+    return state;
+}
+
+template <int MODE>
+int launch_world(const rl_world* h, const KParams& p, hipStream_t stream)
+{
+    if (int rc = prepare_once()) return rc;
+    hipLaunchKernelGGL((k_world<kBlock, MODE>), dim3(h->cfg.n_worlds), dim3(kBlock), h->smem_bytes, stream, p);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rl_set_error("world kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
+    return RL_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// host entry points used by rl_capi.hip
+// ---------------------------------------------------------------------------------------------------------------
+size_t rl_world_smem_bytes(int cpad, int cap, int hash)
+{
+    Smem s;
+    return carve(s, nullptr, cpad, cap, hash);
+}
+int rl_world_block() { return kBlock; }
+
+int rl_world_prepare()
+{
+    // worlds larger than the 64 KB default dynamic-LDS window need the opt-in attribute (160 KB per CU on gfx950)
+    const int max_lds = 160 * 1024;
+    hipError_t e = hipSuccess;
+#define RL_ATTR(K) e = e != hipSuccess ? e : hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    RL_ATTR((k_world<kBlock, MODE_STEP>)) RL_ATTR((k_world<kBlock, MODE_UPDATE>)) RL_ATTR((k_world<kBlock, MODE_TICK>))
+    RL_ATTR((k_world<kBlock, MODE_OBSERVE>)) RL_ATTR((k_reset<kBlock>))
+#undef RL_ATTR
+    if (e != hipSuccess) { rl_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
+    return RL_OK;
+}
+
+int rl_world_launch_step(const rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_step_out* out, hipStream_t st)
+{
+    KParams p = make_params(h);
+    p.actions = actions;
+    if (tape) p.tape = *tape;
+    if (out) p.so = *out;
+    return launch_world<MODE_STEP>(h, p, st);
+}
+int rl_world_launch_update(const rl_world* h, const rl_tape* tape, const rl_update_out* out, hipStream_t st)
+{
+    KParams p = make_params(h);
+    if (tape) p.tape = *tape;
+    if (out) p.uo = *out;
+    return launch_world<MODE_UPDATE>(h, p, st);
+}
+int rl_world_launch_tick(const rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_step_out* so,
+                         const rl_update_out* uo, hipStream_t st)
+{
+    KParams p = make_params(h);
+    p.actions = actions;
+    if (tape) p.tape = *tape;
+    if (so) p.so = *so;
+    if (uo) p.uo = *uo;
+    return launch_world<MODE_TICK>(h, p, st);
+}
+int rl_world_launch_observe(const rl_world* h, float* obs, hipStream_t st)
+{
+    KParams p = make_params(h);
+    p.obs_only = obs;
+    return launch_world<MODE_OBSERVE>(h, p, st);
+}
+int rl_world_launch_reset(const rl_world* h, int n_agents, int threshold, float* obs, int32_t* refill_count, hipStream_t st)
+{
+    KParams p = make_params(h);
+    p.reset_n_agents = n_agents; p.refill_threshold = threshold; p.obs_only = obs; p.refill_count = refill_count;
+    if (int rc = prepare_once()) return rc;
+    hipLaunchKernelGGL((k_reset<kBlock>), dim3(h->cfg.n_worlds), dim3(kBlock), h->smem_bytes, st, p);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rl_set_error("reset kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
+    return RL_OK;
+}

@@ -1,0 +1,221 @@
+"""DeviceWorlds: R independent ReinLife worlds resident in HBM, driven through the C ABI (include/reinlife_hip.h).
+
+PyTorch is plumbing only: it owns the device buffers and the stream; all compute is libreinlife_hip.so.
+Layout = `rl_state` (struct-of-arrays over worlds; a world's agent list is its on-grid agents in row-major cell
+order, i.e. the reference's env.agents order -- World/grid.py:60-67).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_STATE_SPEC = [  # name, torch dtype, shape suffix
+    ("cell_type", torch.uint8, "C"), ("n_agents", torch.int32, ""), ("a_i", torch.uint8, "cap"),
+    ("a_j", torch.uint8, "cap"), ("a_health", torch.int32, "cap"), ("a_age", torch.int32, "cap"),
+    ("a_max_age", torch.int32, "cap"), ("a_gene", torch.int32, "cap"), ("a_brain", torch.int32, "cap"),
+    ("a_uid", torch.int32, "cap"), ("a_flags", torch.uint8, "cap"), ("a_action", torch.int8, "cap"),
+    ("a_fitness", torch.float64, "cap"), ("max_gene", torch.int32, ""), ("next_uid", torch.int32, ""),
+    ("tick", torch.int32, ""), ("epoch", torch.int32, ""), ("best_uid", torch.int32, "best"),
+    ("best_fit", torch.float64, "best"), ("best_brain", torch.int32, "best")]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class DeviceWorlds:
+    def __init__(self, n_worlds=1, width=30, height=30, max_agents=100, n_brains=2, static_families=True,
+                 limit_reproduction=False, incentivize_killing=True, seed=0, slot_cap=None, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise _lib.ReinLifeHipError("DeviceWorlds needs an MI355X: torch.cuda.is_available() is False "
+                                        "(there is no CPU fallback)")
+        self.lib = _lib.lib()
+        self.device = torch.device(device)
+        self.R, self.W, self.H, self.C = n_worlds, width, height, width * height
+        self.cap = slot_cap or _lib.slot_cap_for(max_agents)
+        self.max_agents, self.n_brains = max_agents, n_brains
+        self.cfg = _lib.Config(width, height, max_agents, n_brains, self.cap, n_worlds, int(static_families),
+                               int(limit_reproduction), int(incentivize_killing), 0, seed)
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.rl_create(C.byref(self.cfg), C.byref(self.handle)), "rl_create")
+        dims = {"C": (self.C,), "cap": (self.cap,), "best": (_lib.N_BEST,), "": ()}
+        with torch.cuda.device(self.device):
+            self.s = {n: torch.zeros((self.R,) + dims[suf], dtype=dt, device=self.device) for n, dt, suf in _STATE_SPEC}
+            self.s["best_uid"].fill_(-1)
+            self.s["max_gene"].fill_(n_brains)
+            R, cap = self.R, self.cap
+            self.actions = torch.zeros((R, cap), dtype=torch.int8, device=self.device)
+            self.n_acted = torch.zeros(R, dtype=torch.int32, device=self.device)
+            self.reward = torch.zeros((R, cap), dtype=torch.float32, device=self.device)
+            self.done = torch.zeros((R, cap), dtype=torch.uint8, device=self.device)
+            self.src1 = torch.full((R, cap), -1, dtype=torch.int16, device=self.device)
+            # +1 row of padding keeps 16-byte row reads of the policy kernel inside the allocation
+            self.obs1 = torch.zeros((R * cap + 1, _lib.OBS_DIM), dtype=torch.float32, device=self.device)
+            self.src2 = torch.full((R, cap), -1, dtype=torch.int16, device=self.device)
+            self.obs2 = torch.zeros((R * cap + 1, _lib.OBS_DIM), dtype=torch.float32, device=self.device)
+            self.out_q = torch.zeros((R, cap, 8), dtype=torch.float32, device=self.device)
+            self.err = torch.zeros(4, dtype=torch.int32, device=self.device)
+            self.refill_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._state = _lib.State(*[_ptr(self.s[n]) for n in _lib.STATE_FIELDS])
+        _lib.check(self.lib.rl_bind_state(self.handle, C.byref(self._state)), "rl_bind_state")
+        _lib.check(self.lib.rl_bind_error_flag(self.handle, _ptr(self.err)), "rl_bind_error_flag")
+        self._step_out = _lib.StepOut(_ptr(self.n_acted), _ptr(self.reward), _ptr(self.done), _ptr(self.src1),
+                                      _ptr(self.obs1))
+        self._upd_out = _lib.UpdateOut(_ptr(self.src2), _ptr(self.obs2))
+        self._work = None
+        self._brains = None
+        self._tape_keep = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and self.handle.value:
+                self.lib.rl_destroy(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # -- helpers ------------------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def obs_state(self):
+        """[R, cap, 153] view of Agent.state (post-update observation)."""
+        return self.obs2[: self.R * self.cap].view(self.R, self.cap, _lib.OBS_DIM)
+
+    def obs_state_prime(self):
+        """[R, cap, 153] view of Agent.state_prime (post-step observation)."""
+        return self.obs1[: self.R * self.cap].view(self.R, self.cap, _lib.OBS_DIM)
+
+    def check_error_flag(self):
+        e = self.err.cpu().numpy()
+        if e[0] != 0:
+            raise _lib.ReinLifeHipError("device error flag: code %d world %d detail (%d, %d)" % tuple(int(x) for x in e))
+
+    # -- host <-> device state (parity I/O) ----------------------------------------------------------------------
+    def load_world(self, w, snap):
+        n = len(snap["i"])
+        assert n <= self.cap
+        dev = self.device
+        self.s["cell_type"][w] = torch.as_tensor(np.asarray(snap["cell_type"], np.uint8), device=dev)
+        self.s["n_agents"][w] = n
+        for key in ("i", "j", "health", "age", "max_age", "gene", "brain", "uid", "flags", "action", "fitness"):
+            t = self.s["a_" + key]
+            t[w, :n] = torch.as_tensor(np.ascontiguousarray(snap[key]), device=dev).to(t.dtype)
+        self.s["max_gene"][w] = int(snap.get("max_gene", self.n_brains))
+        self.s["next_uid"][w] = int(snap.get("next_uid", (int(np.max(snap["uid"])) + 1) if n else 0))
+        for key in ("best_uid", "best_fit", "best_brain"):
+            if key in snap:
+                self.s[key][w] = torch.as_tensor(np.asarray(snap[key]), device=dev).to(self.s[key].dtype)
+
+    def world(self, w):
+        n = int(self.s["n_agents"][w].item())
+        d = {k[2:]: self.s[k][w, :n].cpu().numpy() for k in self.s if k.startswith("a_")}
+        d["cell_type"] = self.s["cell_type"][w].cpu().numpy()
+        for key in ("max_gene", "next_uid", "tick", "epoch"):
+            d[key] = int(self.s[key][w].item())
+        for key in ("best_uid", "best_fit", "best_brain"):
+            d[key] = self.s[key][w].cpu().numpy()
+        return d
+
+    def make_tape(self, tapes):
+        """tapes: one dict per world (food_k, food_u, repro_u, birth_k, produce_u, produce_choice) -> device Tape."""
+        R, cap = self.R, self.cap
+        host = {"food_k": np.zeros((R, _lib.FOOD_TRIES), np.int32), "food_u": np.zeros((R, _lib.FOOD_TRIES), np.float64),
+                "repro_u": np.zeros((R, cap), np.float64), "birth_k": np.zeros((R, cap + 1), np.int32),
+                "produce_u": np.zeros(R, np.float64), "produce_choice": np.zeros(R, np.int32)}
+        for w, t in enumerate(tapes):
+            host["food_k"][w] = t["food_k"]
+            host["food_u"][w] = t["food_u"]
+            m = min(cap, len(t["repro_u"]))
+            host["repro_u"][w, :m] = t["repro_u"][:m]
+            m = min(cap + 1, len(t["birth_k"]))
+            host["birth_k"][w, :m] = t["birth_k"][:m]
+            host["produce_u"][w] = t["produce_u"]
+            host["produce_choice"][w] = t["produce_choice"]
+        self._tape_keep = {k: torch.as_tensor(v, device=self.device) for k, v in host.items()}
+        return _lib.Tape(*[_ptr(self._tape_keep[n]) for n in _lib.TAPE_FIELDS])
+
+    # -- the path -----------------------------------------------------------------------------------------------
+    def set_actions(self, actions):
+        a = torch.as_tensor(np.ascontiguousarray(actions, dtype=np.int8) if not torch.is_tensor(actions) else actions,
+                            device=self.device).to(torch.int8)
+        assert tuple(a.shape) == (self.R, self.cap)
+        self.actions.copy_(a)
+
+    def step(self, actions=None, tape=None):
+        if actions is not None:
+            self.set_actions(actions)
+        _lib.check(self.lib.rl_step(self.handle, _ptr(self.actions), C.byref(tape) if tape is not None else None,
+                                    C.byref(self._step_out), self._stream()), "rl_step")
+
+    def update(self, tape=None):
+        _lib.check(self.lib.rl_update(self.handle, C.byref(tape) if tape is not None else None,
+                                      C.byref(self._upd_out), self._stream()), "rl_update")
+
+    def tick(self, actions=None, tape=None):
+        """step() + update_env() of one trainer-loop iteration in ONE kernel launch."""
+        if actions is not None:
+            self.set_actions(actions)
+        _lib.check(self.lib.rl_tick(self.handle, _ptr(self.actions), C.byref(tape) if tape is not None else None,
+                                    C.byref(self._step_out), C.byref(self._upd_out), self._stream()), "rl_tick")
+
+    def observe(self):
+        _lib.check(self.lib.rl_observe(self.handle, _ptr(self.obs2), self._stream()), "rl_observe")
+        return self.obs_state()
+
+    def reset_synthetic(self, n_agents):
+        _lib.check(self.lib.rl_reset_synthetic(self.handle, n_agents, _ptr(self.obs2), self._stream()),
+                   "rl_reset_synthetic")
+
+    def refill(self, threshold, n_agents):
+        _lib.check(self.lib.rl_refill(self.handle, threshold, n_agents, _ptr(self.obs2), _ptr(self.refill_count),
+                                      self._stream()), "rl_refill")
+
+    # -- policy -------------------------------------------------------------------------------------------------
+    def set_brains(self, brains):
+        """brains: list of (kind:int, epsilon:float, packed: device float32 tensor)."""
+        assert len(brains) == self.n_brains
+        self._brain_keep = [b[2] for b in brains]
+        arr = (_lib.Brain * len(brains))()
+        for k, (kind, eps, packed) in enumerate(brains):
+            assert packed.is_cuda and packed.dtype == torch.float32 and packed.is_contiguous()
+            assert packed.numel() == self.lib.rl_policy_packed_floats(kind)
+            arr[k] = _lib.Brain(kind, float(eps), packed.data_ptr())
+        self._brains = arr
+        if self._work is None:
+            nbytes = self.lib.rl_policy_work_bytes(self.handle)
+            self._work = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=self.device)
+
+    def act(self, want_q=False):
+        """Agent.get_action for every agent of every world: obs_state -> self.actions (and self.out_q)."""
+        if self._brains is None:
+            raise _lib.ReinLifeHipError("set_brains() was not called")
+        _lib.check(self.lib.rl_policy_act(self.handle, self._brains, self.n_brains, _ptr(self.obs2), _ptr(self.actions),
+                                          _ptr(self.out_q) if want_q else None, _ptr(self._work), self._stream()),
+                   "rl_policy_act")
+
+
+def pack_brain_weights(kind, state_dict_flat, device="cuda:0"):
+    """state-dict-order float32 vector (host) -> packed MFMA layout on the device."""
+    lib = _lib.lib()
+    flat = np.ascontiguousarray(state_dict_flat, dtype=np.float32)
+    if flat.size != lib.rl_policy_n_params(kind):
+        raise ValueError("brain kind %d expects %d parameters, got %d" % (kind, lib.rl_policy_n_params(kind), flat.size))
+    packed = np.zeros(lib.rl_policy_packed_floats(kind), np.float32)
+    _lib.check(lib.rl_policy_pack_weights(kind, flat.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)),
+               "rl_policy_pack_weights")
+    return torch.as_tensor(packed, device=device)
+
+
+def policy_forward(kind, packed, obs, out=None):
+    """Dense batch: obs [n,153] device float32 (allocation must extend >= 12 bytes past the last row, or n rows of a
+    larger buffer) -> [n,8]."""
+    lib = _lib.lib()
+    n = obs.shape[0]
+    if out is None:
+        out = torch.empty((n, 8), dtype=torch.float32, device=obs.device)
+    stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
+    _lib.check(lib.rl_policy_forward(kind, _ptr(packed), _ptr(obs), n, _ptr(out), stream), "rl_policy_forward")
+    return out

@@ -1,0 +1,170 @@
+"""GPU: the HIP path (through the C ABI) against the reference's golden vectors and against the CPU oracle."""
+import numpy as np
+import pytest
+
+import golden_io
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip(**kw):
+    from hip_backend import HipBackend
+    return lambda n_worlds, **cfg: HipBackend(n_worlds, **kw, **cfg)
+
+
+@pytest.mark.parametrize("path", golden_io.trace_files("micro_"), ids=lambda p: p.split("/")[-1])
+def test_hip_replays_quirk_microworlds(path):
+    golden_io.replay_trace(_hip(), path, n_worlds=2)
+
+
+@pytest.mark.parametrize("path", golden_io.trace_files("trace_"), ids=lambda p: p.split("/")[-1])
+def test_hip_replays_reference_traces(path):
+    golden_io.replay_trace(_hip(), path, n_worlds=3)
+
+
+def _compare_states(hb, ow, tag):
+    for name in ("cell_type", "n_agents", "max_gene", "next_uid", "tick", "epoch"):
+        got = hb.dw.s[name].cpu().numpy()
+        assert np.array_equal(got, ow.s[name]), "%s: %s differs" % (tag, name)
+    n = ow.s["n_agents"]
+    for name in ("a_i", "a_j", "a_health", "a_age", "a_max_age", "a_gene", "a_brain", "a_uid", "a_flags", "a_action",
+                 "a_fitness"):
+        got = hb.dw.s[name].cpu().numpy()
+        for w in range(ow.R):
+            assert np.array_equal(got[w, : n[w]], ow.s[name][w, : n[w]]), "%s: %s differs in world %d" % (tag, name, w)
+    for name in ("best_uid", "best_fit", "best_brain"):
+        assert np.array_equal(hb.dw.s[name].cpu().numpy(), ow.s[name]), "%s: %s differs" % (tag, name)
+
+
+def _compare_rows(got, want, n, tag):
+    got = np.asarray(got)
+    for w in range(len(n)):
+        assert np.array_equal(got[w, : n[w]], want[w, : n[w]]), "%s differs in world %d" % (tag, w)
+
+
+@pytest.mark.parametrize("static,limit,fused", [(True, False, False), (False, False, False), (True, True, True),
+                                                (False, False, True)])
+def test_hip_matches_oracle_free_running_philox(static, limit, fused):
+    """Synthetic worlds, in-kernel Philox draws, random actions: GPU and oracle must stay bit-identical for many ticks
+    (integer state exact; rewards / observations float32-identical), split and fused launches alike."""
+    from hip_backend import HipBackend
+    from oracle import oracle as orc
+    R, ticks = 48, 60
+    cfg = dict(width=30, height=30, max_agents=100, n_brains=3, static_families=static, limit_reproduction=limit,
+               incentivize_killing=True)
+    hb = HipBackend(R, seed=1234, **cfg)
+    ow = orc.OracleWorlds(n_worlds=R, seed=1234, **cfg)
+    hb.dw.reset_synthetic(100)
+    ow.reset_synthetic(100)
+    _compare_states(hb, ow, "reset")
+    _compare_rows(hb.obs2, ow.obs2, ow.s["n_agents"], "reset obs")
+    rng = np.random.RandomState(5)
+    for t in range(ticks):
+        acts = rng.randint(0, 8, size=(R, hb.cap)).astype(np.int8)
+        n0 = ow.s["n_agents"].copy()
+        ow.step(acts)
+        if fused:
+            ow_n1 = ow.s["n_agents"].copy()
+            ow.update()
+            hb.tick(acts)
+        else:
+            hb.step(acts)
+            _compare_states(hb, ow, "tick %d step" % t)
+            ow_n1 = ow.s["n_agents"].copy()
+        assert np.array_equal(hb.n_acted, n0)
+        _compare_rows(hb.reward, ow.reward, ow_n1, "tick %d reward" % t)
+        _compare_rows(hb.done, ow.done, ow_n1, "tick %d done" % t)
+        _compare_rows(hb.src1, ow.src1, ow_n1, "tick %d src1" % t)
+        _compare_rows(hb.obs1, ow.obs1, ow_n1, "tick %d obs1" % t)
+        if not fused:
+            ow.update()
+            hb.update()
+        _compare_states(hb, ow, "tick %d update" % t)
+        _compare_rows(hb.src2, ow.src2, ow.s["n_agents"], "tick %d src2" % t)
+        _compare_rows(hb.obs2, ow.obs2, ow.s["n_agents"], "tick %d obs2" % t)
+        if t % 20 == 19:
+            ow.refill(70, 100)
+            hb.dw.refill(70, 100)
+            _compare_states(hb, ow, "tick %d refill" % t)
+
+
+def test_hip_small_and_rect_grids_match_oracle():
+    from hip_backend import HipBackend
+    from oracle import oracle as orc
+    for (w, h, ma, n) in ((7, 5, 12, 10), (30, 20, 80, 60), (64, 64, 100, 100), (3, 3, 4, 3)):
+        cfg = dict(width=w, height=h, max_agents=ma, n_brains=2, static_families=True, limit_reproduction=False,
+                   incentivize_killing=False)
+        hb = HipBackend(5, seed=77, **cfg)
+        ow = orc.OracleWorlds(n_worlds=5, seed=77, **cfg)
+        hb.dw.reset_synthetic(n)
+        ow.reset_synthetic(n)
+        rng = np.random.RandomState(w * 100 + h)
+        for t in range(40):
+            acts = rng.randint(0, 8, size=(5, hb.cap)).astype(np.int8)
+            ow.step(acts); ow.update()
+            hb.step(acts); hb.update()
+            _compare_states(hb, ow, "%dx%d tick %d" % (w, h, t))
+            _compare_rows(hb.obs2, ow.obs2, ow.s["n_agents"], "%dx%d tick %d obs2" % (w, h, t))
+
+
+def test_hip_policy_forward_matches_reference_and_oracle():
+    """fp32 MFMA MLPs vs the reference's torch networks (golden) and the C oracle: 1e-5 (north_star tolerance)."""
+    import torch
+    from oracle import oracle as orc
+    from reinlife_amd import _lib
+    from reinlife_amd.worlds import pack_brain_weights, policy_forward
+    m = np.load(golden_io.GOLDEN_DIR + "/models.npz")
+    obs = torch.as_tensor(m["obs"], device="cuda:0")
+    for name in ("DQN", "D3QN", "PERD3QN", "PPO"):
+        kind = _lib.KIND_BY_METHOD[name]
+        packed = pack_brain_weights(kind, m[name + "_weights"])
+        for n in (1, 31, 32, 33, obs.shape[0]):
+            out = policy_forward(kind, packed, obs[:n].contiguous()).cpu().numpy()
+            np.testing.assert_allclose(out, m[name + "_out"][:n], rtol=0, atol=1e-5, err_msg="%s n=%d vs reference" % (name, n))
+            ora = orc.policy_forward(orc.KIND_BY_NAME[name], m[name + "_weights"], m["obs"][:n])
+            np.testing.assert_allclose(out, ora, rtol=0, atol=1e-5, err_msg="%s n=%d vs oracle" % (name, n))
+
+
+def test_hip_policy_act_over_worlds_matches_oracle():
+    """rl_policy_act: per-agent brain dispatch (bucketed by brain), greedy / eps-greedy / categorical Philox draws."""
+    import torch
+    from hip_backend import HipBackend
+    from oracle import oracle as orc
+    from reinlife_amd import _lib
+    from reinlife_amd.worlds import pack_brain_weights
+    m = np.load(golden_io.GOLDEN_DIR + "/models.npz")
+    names = ["PERD3QN", "PPO", "DQN", "D3QN"]
+    R = 24
+    cfg = dict(width=30, height=30, max_agents=100, n_brains=4, static_families=True, limit_reproduction=False,
+               incentivize_killing=True)
+    hb = HipBackend(R, seed=99, **cfg)
+    ow = orc.OracleWorlds(n_worlds=R, seed=99, **cfg)
+    hb.dw.reset_synthetic(100)
+    ow.reset_synthetic(100)
+    eps = [0.0, 0.0, 0.3, 0.0]
+    hb.dw.set_brains([(_lib.KIND_BY_METHOD[n], e, pack_brain_weights(_lib.KIND_BY_METHOD[n], m[n + "_weights"]))
+                      for n, e in zip(names, eps)])
+    for t in range(3):
+        hb.dw.act(want_q=True)
+        torch.cuda.synchronize()
+        acts = hb.dw.actions.cpu().numpy()
+        q = hb.dw.out_q.cpu().numpy()
+        n = ow.s["n_agents"]
+        mismatches = 0
+        total = 0
+        for b, name in enumerate(names):
+            rows = [(w, k) for w in range(R) for k in range(n[w]) if ow.s["a_brain"][w, k] == b]
+            assert rows
+            ws = np.array([r[0] for r in rows]); ks = np.array([r[1] for r in rows])
+            want_q = orc.policy_forward(orc.KIND_BY_NAME[name], m[name + "_weights"], ow.obs2[ws, ks])
+            np.testing.assert_allclose(q[ws, ks], want_q, rtol=0, atol=1e-5, err_msg=name)
+            # action selection on the GPU's own outputs must equal the oracle's rule bit for bit
+            want_a = orc.select_actions(ow.cfg, orc.KIND_BY_NAME[name], q[ws, ks], ws, ks, ow.s["tick"], ow.s["epoch"], eps[b])
+            mismatches += int((acts[ws, ks] != want_a).sum()); total += len(rows)
+        assert mismatches == 0, "%d / %d actions differ" % (mismatches, total)
+        full = np.zeros((R, hb.cap), np.int8)
+        for w in range(R):
+            full[w, : n[w]] = acts[w, : n[w]]
+        ow.step(full); ow.update()
+        hb.tick(full)
+        _compare_rows(hb.obs2, ow.obs2, ow.s["n_agents"], "obs after act tick %d" % t)
