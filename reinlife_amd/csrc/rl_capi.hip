@@ -10,7 +10,6 @@
 // implemented in rl_world.hip / rl_policy.hip
 size_t rl_world_smem_bytes(int cpad, int cap, int hash);
 int rl_world_block();
-int rl_world_prepare();
 int rl_world_launch_step(const rl_world*, const int8_t*, const rl_tape*, const rl_step_out*, hipStream_t);
 int rl_world_launch_update(const rl_world*, const rl_tape*, const rl_update_out*, hipStream_t);
 int rl_world_launch_tick(const rl_world*, const int8_t*, const rl_tape*, const rl_step_out*, const rl_update_out*, hipStream_t);

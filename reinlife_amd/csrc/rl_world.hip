@@ -20,7 +20,7 @@
 //   set_random  k-th empty cell == select on the ballot bitmap of occupied cells, held in wave 0's registers
 #include "rl_common.h"
 
-int rl_world_prepare();
+int rl_world_prepare_bytes(size_t bytes);
 
 namespace {
 
@@ -887,17 +887,11 @@ KParams make_params(const rl_world* h)
     return p;
 }
 
-int prepare_once()
-{
-    static int state = 1;  // 1 = not yet, 0 = ok, <0 = failed
-    if (state == 1) state = rl_world_prepare();
-    return state;
-}
 
 template <int MODE>
 int launch_world(const rl_world* h, const KParams& p, hipStream_t stream)
 {
-    if (int rc = prepare_once()) return rc;
+    if (int rc = rl_world_prepare_bytes(h->smem_bytes)) return rc;
     hipLaunchKernelGGL((k_world<kBlock, MODE>), dim3(h->cfg.n_worlds), dim3(kBlock), h->smem_bytes, stream, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rl_set_error("world kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
@@ -916,16 +910,18 @@ size_t rl_world_smem_bytes(int cpad, int cap, int hash)
 }
 int rl_world_block() { return kBlock; }
 
-int rl_world_prepare()
+int rl_world_prepare_bytes(size_t bytes)
 {
-    // worlds larger than the 64 KB default dynamic-LDS window need the opt-in attribute (160 KB per CU on gfx950)
-    const int max_lds = 160 * 1024;
+    // worlds that need more than the default 64 KB dynamic-LDS window opt in (160 KB per CU on gfx950)
+    static size_t granted = 64 * 1024;
+    if (bytes <= granted) return RL_OK;
     hipError_t e = hipSuccess;
-#define RL_ATTR(K) e = e != hipSuccess ? e : hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+#define RL_ATTR(K) e = e != hipSuccess ? e : hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     RL_ATTR((k_world<kBlock, MODE_STEP>)) RL_ATTR((k_world<kBlock, MODE_UPDATE>)) RL_ATTR((k_world<kBlock, MODE_TICK>))
     RL_ATTR((k_world<kBlock, MODE_OBSERVE>)) RL_ATTR((k_reset<kBlock>))
 #undef RL_ATTR
-    if (e != hipSuccess) { rl_set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
+    if (e != hipSuccess) { rl_set_error("hipFuncSetAttribute(%zu bytes of LDS) failed: %s", bytes, hipGetErrorString(e)); return RL_E_LAUNCH; }
+    granted = bytes;
     return RL_OK;
 }
 
@@ -964,7 +960,7 @@ int rl_world_launch_reset(const rl_world* h, int n_agents, int threshold, float*
 {
     KParams p = make_params(h);
     p.reset_n_agents = n_agents; p.refill_threshold = threshold; p.obs_only = obs; p.refill_count = refill_count;
-    if (int rc = prepare_once()) return rc;
+    if (int rc = rl_world_prepare_bytes(h->smem_bytes)) return rc;
     hipLaunchKernelGGL((k_reset<kBlock>), dim3(h->cfg.n_worlds), dim3(kBlock), h->smem_bytes, st, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rl_set_error("reset kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
