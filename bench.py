@@ -1,0 +1,255 @@
+#!/usr/bin/env python
+"""bench.py -- ReinLife hot-path throughput on MI355X: agent-steps/s (policy forward + env.step + update_env).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one trainer-loop tick (Helpers/trainer.py:85-99 minus learn) of EVERY world on the GPU:
+    policy forward + action selection for all agents  ->  rl_tick (step + update_env, fused)  ->  rl_refill
+Workload (BASELINE.json configs[3]): 256 independent 30x30 worlds per GPU x 100 agents, two
+PERD3QN brains (random-init weights of the reference architecture, greedy), static families, synthetic worlds from
+the Philox generator, a world is re-generated when its population drops below 70.  Worlds are sharded over GPUs
+with NO data-path collective (weak scaling); RCCL is used once, for the final counter reduction.
+An agent-step = one live agent receiving an action and being advanced by one step().
+
+Prints ONE JSON line (rank 0).  `value` counts the full tick (update_env included: more work than the metric's
+literal "env.step + policy fwd", never less).
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from reinlife_amd import _lib  # noqa: E402
+from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights  # noqa: E402
+
+# Algorithmic HBM bytes per agent-step (DESIGN.md "Roofline accounting"; SURVEY.md 8d gives 2,082 B for the whole
+# tick of the reference's data flow, of which the policy's 612 B observation read belongs to the policy kernel):
+#   tick kernel : state_prime row 612 + state row 612 + agent record read 36 + write 36 + action 1 + reward 4 + done 1
+#                 + src 2+2 + type grid (900 B read + 900 B write) / 100 agents = 18   -> 1,324 B
+#   policy      : observation row 612 + action 1 + brain id 4                          -> 617 B, 107,008 FLOP (PERD3QN)
+TICK_BYTES_PER_AGENT_STEP = 612 + 612 + 36 + 36 + 1 + 4 + 1 + 4 + 18
+POLICY_BYTES_PER_AGENT = 612 + 1 + 4
+POLICY_FLOP_PER_AGENT = {"DQN": 56576, "D3QN": 107008, "PERD3QN": 107008, "PPO": 213504}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def brain_weights(kind_name, seed):
+    """Random-init weights of the reference architecture, nn.Linear default scale (uniform +-1/sqrt(fan_in))."""
+    shapes = {"DQN": [(128, 153), (64, 128), (8, 64)],
+              "D3QN": [(128, 153), (128, 128), (8, 128), (128, 128), (1, 128)],
+              "PPO": [(256, 153), (256, 256), (8, 256), (1, 256)]}["D3QN" if kind_name == "PERD3QN" else kind_name]
+    rng = np.random.RandomState(seed)
+    parts = []
+    for n_out, n_in in shapes:
+        b = 1.0 / np.sqrt(n_in)
+        parts.append(rng.uniform(-b, b, size=(n_out, n_in)).astype(np.float32).reshape(-1))
+        parts.append(rng.uniform(-b, b, size=(n_out,)).astype(np.float32))
+    return np.concatenate(parts)
+
+
+WORKLOADS = {
+    "c4": dict(brains=["PERD3QN", "PERD3QN"], static_families=True,
+               name="256 worlds/GPU x 30x30 x 100 agents, 2xPERD3QN greedy inference, static families (BASELINE configs[3])"),
+    "c5": dict(brains=["PPO", "PERD3QN"], static_families=False,
+               name="256 worlds/GPU x 30x30 x 100 agents, PPO + PERD3QN mixed brains, static_families=False (BASELINE configs[4])"),
+}
+
+
+def make_worlds(args, rank, device):
+    wl = WORKLOADS[args.workload]
+    dw = DeviceWorlds(n_worlds=args.worlds, width=30, height=30, max_agents=100, n_brains=len(wl["brains"]),
+                      static_families=wl["static_families"], seed=args.seed, device=device,
+                      world_base=rank * args.worlds)
+    dw.set_brains([(_lib.KIND_BY_METHOD[n], 0.0, pack_brain_weights(_lib.KIND_BY_METHOD[n], brain_weights(n, 100 + k), device))
+                   for k, n in enumerate(wl["brains"])])
+    dw.reset_synthetic(100)
+    return dw
+
+
+def one_step(dw, refill=True):
+    dw.act()
+    dw.tick()
+    if refill:
+        dw.refill(70, 100)
+
+
+def cpu_baseline(args, seconds_target=12.0):
+    """The oracle (a CPU port of the reference path: policy forward + step + update_env) on the host cores, one
+    world range per thread, on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    wl = WORKLOADS[args.workload]
+    cores = max(1, min(os.cpu_count() or 1, 32))
+    R = cores
+    ow = orc.OracleWorlds(n_worlds=R, n_brains=len(wl["brains"]), static_families=wl["static_families"], seed=args.seed)
+    ow.reset_synthetic(100)
+    weights = [brain_weights(n, 100 + k) for k, n in enumerate(wl["brains"])]
+    kinds = [orc.KIND_BY_NAME[n] for n in wl["brains"]]
+    acts = np.zeros((R, ow.cap), np.int8)
+    counts = [0] * R
+
+    def work(w, n_ticks):
+        for _ in range(n_ticks):
+            n = int(ow.s["n_agents"][w])
+            if n < 70:
+                ow.refill(70, 100, w, w + 1)
+                n = int(ow.s["n_agents"][w])
+            br = ow.s["a_brain"][w, :n]
+            for b, (kind, wts) in enumerate(zip(kinds, weights)):
+                idx = np.nonzero(br == b)[0]
+                if len(idx):
+                    q = orc.policy_forward(kind, wts, ow.obs2[w, idx])
+                    acts[w, idx] = q.argmax(1)
+            ow.step(acts, None, w, w + 1)
+            ow.update(None, w, w + 1)
+            counts[w] += n
+
+    t0 = time.time()
+    work(0, 3)  # calibrate
+    per_tick = (time.time() - t0) / 3
+    n_ticks = max(5, int(seconds_target / max(per_tick, 1e-6)))
+    counts = [0] * R
+    threads = [threading.Thread(target=work, args=(w, n_ticks)) for w in range(R)]
+    t0 = time.time()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    dt = time.time() - t0
+    return {"value": round(sum(counts) / dt, 1), "unit": "agent-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d worlds (one per host thread) x %d ticks of the same workload through oracle/rl_oracle.c "
+                      "(policy forward + step + update_env), %.1f s" % (R, n_ticks, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--worlds", type=int, default=256, help="worlds per GPU")
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--seed", type=int, default=20260928)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = "cuda:%d" % local_rank
+    torch.cuda.set_device(local_rank)
+
+    dw = make_worlds(args, rank, device)
+    for _ in range(args.warmup):
+        one_step(dw)
+    torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps, inputs resident in HBM ------------------------------------------------------
+    dw.acted_total.zero_()
+    dw.refill_count.zero_()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(dw)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dw.check_error_flag()
+
+    stats = torch.tensor([float(dw.acted_total.item()), float(dw.refill_count.item())], dtype=torch.float64, device=device)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if dist is not None:  # the only collective of the job: RCCL all-reduce of the counters over xGMI
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_agent_steps, refills = stats.tolist()
+    elapsed = float(tmax.item())
+
+    # ---- per-kernel durations with HIP events on the launch stream (untimed extra steps) ------------------------------
+    roofline, extra = None, {}
+    if rank == 0 and not args.no_kernel_timing:
+        n_probe = 40
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_probe)]
+        probe_acted = 0
+        for i in range(n_probe):
+            ev[i][0].record(); dw.act(); ev[i][1].record(); dw.tick(); ev[i][2].record(); dw.refill(70, 100); ev[i][3].record()
+            probe_acted += int(dw.n_acted.sum().item())
+        torch.cuda.synchronize()
+        t_act = np.mean([e[0].elapsed_time(e[1]) for e in ev]) * 1e-3
+        t_tick = np.mean([e[1].elapsed_time(e[2]) for e in ev]) * 1e-3
+        t_refill = np.mean([e[2].elapsed_time(e[3]) for e in ev]) * 1e-3
+        per_launch = probe_acted / n_probe
+        wl = WORKLOADS[args.workload]
+        flop = np.mean([POLICY_FLOP_PER_AGENT[n] for n in wl["brains"]])
+        tick_gbs = per_launch * TICK_BYTES_PER_AGENT_STEP / t_tick / 1e9
+        pol_tflops = per_launch * flop / t_act / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "tick_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        tick_roof = {"kernel": "k_world<256,TICK> (rl_tick)", "bound": "hbm", "achieved": round(tick_gbs, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(tick_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "avg_launch_us": round(t_tick * 1e6, 2), "agent_steps_per_launch": round(per_launch, 1),
+                     "bytes_per_agent_step": TICK_BYTES_PER_AGENT_STEP}
+        pol_roof = {"kernel": "k_bucket + k_policy (rl_policy_act)", "bound": "mfma", "achieved": round(pol_tflops, 3),
+                    "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(pol_tflops / MFMA_F32_PEAK_TFLOPS, 5),
+                    "traffic": None, "avg_launch_us": round(t_act * 1e6, 2), "flop_per_agent": flop}
+        roofline = tick_roof if t_tick >= t_act else pol_roof
+        extra = {"roofline_tick": tick_roof, "roofline_policy": pol_roof, "refill_us": round(t_refill * 1e6, 2)}
+
+    cpu = None
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        wl = WORKLOADS[args.workload]
+        out = {
+            "metric": "agent-steps/sec (env.step + policy fwd), 30x30 grid, 100 agents",
+            "value": round(total_agent_steps / elapsed, 1),
+            "unit": "agent-steps/s",
+            "n_gpus": args.gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 policy (v_mfma_f32_32x32x2_f32) / int32+u8 world state / f64 rewards",
+            "data": "synthetic",
+            "config": {"workload": wl["name"], "worlds_per_gpu": args.worlds, "worlds_total": args.worlds * max(1, world_size),
+                       "grid": "30x30", "max_agents": 100, "brains": wl["brains"], "static_families": wl["static_families"],
+                       "refill_below": 70, "includes_update_env": True,
+                       "mean_agents_per_world": round(total_agent_steps / (args.steps * args.worlds * max(1, world_size)), 2),
+                       "world_refills": int(refills), "parallelism": "replica-sharded x%d, no data-path collective" % max(1, world_size)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        out.update(extra)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -63,7 +63,7 @@ typedef struct {
     int32_t slot_cap;            /* capacity of the per-world agent arrays; multiple of 64, >= 2*max_agents+2 */
     int32_t n_worlds;
     int32_t static_families, limit_reproduction, incentivize_killing;
-    int32_t reserved;
+    int32_t world_base;          /* global id of world 0 (replica sharding across GPUs): Philox uses world_base + w */
     uint64_t seed;               /* Philox key */
 } rl_config;
 
@@ -108,6 +108,7 @@ typedef struct {
     uint8_t* done;      /* [R][cap]  Agent.done */
     int16_t* src;       /* [R][cap]  index of the agent in the PRE-step list (its state/action live there) */
     float* obs;         /* [R][cap][153] Agent.state_prime */
+    unsigned long long* acted_total; /* [1] running sum of n_acted over worlds and calls (metric counter) */
 } rl_step_out;
 
 /* Outputs of an update, indexed in the POST-update env.agents order. */

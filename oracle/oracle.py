@@ -34,7 +34,7 @@ def build(force=False):
 class Config(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_agents", C.c_int32), ("n_brains", C.c_int32),
                 ("slot_cap", C.c_int32), ("n_worlds", C.c_int32), ("static_families", C.c_int32),
-                ("limit_reproduction", C.c_int32), ("incentivize_killing", C.c_int32), ("reserved", C.c_int32),
+                ("limit_reproduction", C.c_int32), ("incentivize_killing", C.c_int32), ("world_base", C.c_int32),
                 ("seed", C.c_uint64)]
 
 
@@ -89,11 +89,11 @@ class OracleWorlds:
     """R independent worlds in the oracle's SoA layout."""
 
     def __init__(self, n_worlds=1, width=30, height=30, max_agents=100, n_brains=2, static_families=True,
-                 limit_reproduction=False, incentivize_killing=True, seed=0, slot_cap=None):
+                 limit_reproduction=False, incentivize_killing=True, seed=0, slot_cap=None, world_base=0):
         self.R, self.W, self.H, self.C = n_worlds, width, height, width * height
         self.cap = slot_cap or slot_cap_for(max_agents, self.C)
         self.cfg = Config(width, height, max_agents, n_brains, self.cap, n_worlds, int(static_families),
-                          int(limit_reproduction), int(incentivize_killing), 0, seed)
+                          int(limit_reproduction), int(incentivize_killing), world_base, seed)
         dims = {"C": (self.C,), "cap": (self.cap,), "best": (N_BEST,), "": ()}
         self.s = {}
         for name, dt, suf in _STATE_FIELDS:

@@ -49,7 +49,7 @@ static inline uint32_t mulhi32(uint32_t x, uint32_t n) { return (uint32_t)(((uin
 
 static void draw(const world_t* wd, uint32_t site, uint32_t index, uint32_t out[4])
 {
-    rlo_philox(wd->cfg->seed, wd->epoch, (uint32_t)wd->w, wd->tick, site, index, out);
+    rlo_philox(wd->cfg->seed, wd->epoch, (uint32_t)(wd->cfg->world_base + wd->w), wd->tick, site, index, out);
 }
 
 /* ------------------------------------------------------------------------------------------------------------ */
@@ -601,7 +601,7 @@ int rlo_select_actions(const rlo_config* cfg, int kind, const float* out, int n_
         const float* y = out + (size_t)r * 8;
         uint32_t rn[4];
         int w = world_of_row[r];
-        rlo_philox(cfg->seed, (uint32_t)epoch_of_world[w], (uint32_t)w, (uint32_t)tick_of_world[w], RLO_SITE_ACT, (uint32_t)index_in_world[r], rn);
+        rlo_philox(cfg->seed, (uint32_t)epoch_of_world[w], (uint32_t)(cfg->world_base + w), (uint32_t)tick_of_world[w], RLO_SITE_ACT, (uint32_t)index_in_world[r], rn);
         float u = (float)u24(rn[0]);
         int a = 0;
         if (kind == RLO_PPO) { /* Categorical(prob).sample(), PPO.py:166-167, as inverse CDF */

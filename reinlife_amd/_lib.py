@@ -19,7 +19,7 @@ KIND_BY_METHOD = {"DQN": DQN, "D3QN": D3QN, "PERD3QN": PERD3QN, "PPO": PPO}
 class Config(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_agents", C.c_int32), ("n_brains", C.c_int32),
                 ("slot_cap", C.c_int32), ("n_worlds", C.c_int32), ("static_families", C.c_int32),
-                ("limit_reproduction", C.c_int32), ("incentivize_killing", C.c_int32), ("reserved", C.c_int32),
+                ("limit_reproduction", C.c_int32), ("incentivize_killing", C.c_int32), ("world_base", C.c_int32),
                 ("seed", C.c_uint64)]
 
 
@@ -27,7 +27,7 @@ STATE_FIELDS = ("cell_type", "n_agents", "a_i", "a_j", "a_health", "a_age", "a_m
                 "a_flags", "a_action", "a_fitness", "max_gene", "next_uid", "tick", "epoch", "best_uid", "best_fit",
                 "best_brain")
 TAPE_FIELDS = ("food_k", "food_u", "repro_u", "birth_k", "produce_u", "produce_choice")
-STEP_OUT_FIELDS = ("n_acted", "reward", "done", "src", "obs")
+STEP_OUT_FIELDS = ("n_acted", "reward", "done", "src", "obs", "acted_total")
 UPDATE_OUT_FIELDS = ("src", "obs")
 
 

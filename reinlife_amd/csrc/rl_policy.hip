@@ -198,7 +198,7 @@ struct PolicyArgs {
     int8_t* actions;          // [row] or nullptr
     float eps;
     uint64_t seed;
-    int cap;
+    int cap, world_base;
     const int32_t* tick;      // per world
     const int32_t* epoch;
 };
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void k_policy(const PolicyArgs A)
             }
             if (A.actions) {
                 const int w = (int)(row / A.cap), k = (int)(row - (int64_t)w * A.cap);
-                const rl_u4 r = rl_philox4x32(A.seed, (uint32_t)A.epoch[w], (uint32_t)w, (uint32_t)A.tick[w], RL_SITE_ACT, (uint32_t)k);
+                const rl_u4 r = rl_philox4x32(A.seed, (uint32_t)A.epoch[w], (uint32_t)(A.world_base + w), (uint32_t)A.tick[w], RL_SITE_ACT, (uint32_t)k);
                 const float u = (float)rl_u24(r.x);
                 int a = 0;
                 if (KIND == RL_PPO) {  // Categorical(prob).sample() as inverse CDF
@@ -441,7 +441,7 @@ int rl_policy_act_impl(rl_world* h, const rl_brain* brains, int n_brains, const 
     for (int b = 0; b < n_brains; ++b) {
         PolicyArgs a{};
         a.packed = brains[b].packed; a.obs = obs; a.rowlist = lists + b * stride; a.count_ptr = counts + b;
-        a.n_rows = 0; a.out = out_q; a.actions = actions; a.eps = brains[b].epsilon; a.seed = h->cfg.seed; a.cap = cap;
+        a.n_rows = 0; a.out = out_q; a.actions = actions; a.eps = brains[b].epsilon; a.seed = h->cfg.seed; a.cap = cap; a.world_base = h->cfg.world_base;
         a.tick = h->st.tick; a.epoch = h->st.epoch;
         // upper bound of rows for this brain: every live agent (max_agents-bounded populations in practice)
         const int64_t bound = (int64_t)R * (int64_t)(2 * h->cfg.max_agents + 2 < cap ? 2 * h->cfg.max_agents + 2 : cap);

@@ -32,7 +32,7 @@ enum { S_ALIVE = 0, S_NFOOD, S_NPOISON, S_NSUPER, S_NSLOTS, S_N1, S_N2, S_NPAREN
 
 struct KParams {
     int W, H, C, Cp, nW;
-    int cap, max_agents, n_brains, hash_size, hash_mask;
+    int cap, max_agents, n_brains, hash_size, hash_mask, world_base;
     int static_families, limit_reproduction, incentivize_killing;
     uint64_t seed;
     rl_state st;
@@ -480,7 +480,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
         if (tid < RL_FOOD_TRIES) {
             if (tape) { xk = (unsigned)p.tape.food_k[(size_t)w * RL_FOOD_TRIES + tid]; u = p.tape.food_u[(size_t)w * RL_FOOD_TRIES + tid]; }
             else {
-                const rl_u4 r = rl_philox4x32(p.seed, (uint32_t)p.st.epoch[w], (uint32_t)w, (uint32_t)p.st.tick[w], RL_SITE_FOOD, (uint32_t)tid);
+                const rl_u4 r = rl_philox4x32(p.seed, (uint32_t)p.st.epoch[w], (uint32_t)(p.world_base + w), (uint32_t)p.st.tick[w], RL_SITE_FOOD, (uint32_t)tid);
                 xk = r.x; u = rl_u24(r.y);
             }
         }
@@ -577,7 +577,7 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
             const int rank = s.wordbase[k >> 6] + __popcll(s.agbits[k >> 6] & lowmask(k & 63));
             double u;
             if (tape) u = p.tape.repro_u[(size_t)w * p.cap + rank];
-            else u = rl_u24(rl_philox4x32(p.seed, epoch, (uint32_t)w, tick, RL_SITE_REPRO, (uint32_t)rank).x);
+            else u = rl_u24(rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_REPRO, (uint32_t)rank).x);
             par = u > 0.95;
             if (par && p.limit_reproduction) s.flags[s.order[k]] |= RL_F_REPRODUCED;
         }
@@ -620,7 +620,7 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
             if (P.n_empty <= 0) continue;  // full grid: randint raises, no draw, no offspring (grid.py:82-83)
             unsigned x;  // draw indices advance only when a draw happens
             if (tape) x = (unsigned)p.tape.birth_k[(size_t)w * (p.cap + 1) + n_birth];
-            else x = rl_philox4x32(p.seed, epoch, (uint32_t)w, tick, RL_SITE_BIRTH, (uint32_t)n_birth).x;
+            else x = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_BIRTH, (uint32_t)n_birth).x;
             const int k = tape ? (int)x : (int)rl_mulhi(x, (unsigned)P.n_empty);
             ++n_birth;
             if (k < 0 || k >= P.n_empty) { if (tid == 0) flag_error(p, s, 2, w, b, k); continue; }
@@ -634,7 +634,7 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
         if (room) {
             double u; unsigned x1 = 0;
             if (tape) u = p.tape.produce_u[w];
-            else { const rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)w, tick, RL_SITE_PRODUCE, 0u); u = rl_u24(r.x); x1 = r.y; }
+            else { const rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_PRODUCE, 0u); u = rl_u24(r.x); x1 = r.y; }
             if (u > 0.95) {
                 int gene = -1, brain = 0;
                 if (p.static_families) {
@@ -660,7 +660,7 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
                 if (P.n_empty > 0 && gene >= 0) {
                     unsigned x;
                     if (tape) x = (unsigned)p.tape.birth_k[(size_t)w * (p.cap + 1) + n_birth];
-                    else x = rl_philox4x32(p.seed, epoch, (uint32_t)w, tick, RL_SITE_BIRTH, (uint32_t)n_birth).x;
+                    else x = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_BIRTH, (uint32_t)n_birth).x;
                     const int k = tape ? (int)x : (int)rl_mulhi(x, (unsigned)P.n_empty);
                     if (k < 0 || k >= P.n_empty) { if (tid == 0) flag_error(p, s, 2, w, -1, k); }
                     else {
@@ -762,6 +762,7 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
             if (p.so.src) p.so.src[b + k] = (short)a;
         }
         if (tid == 0 && p.so.n_acted) p.so.n_acted[w] = n0;
+        if (tid == 0 && p.so.acted_total && n0) atomicAdd(p.so.acted_total, (unsigned long long)n0);
         n_cur = n1;
         if (MODE == MODE_STEP) { store_world<T>(p, s, w, n1); return; }
         __syncthreads();
@@ -816,7 +817,7 @@ __global__ __launch_bounds__(T) void k_reset(const KParams p)
         P.n_empty = p.C;
         int placed = 0;
         for (int a = 0; a < n_agents && P.n_empty > 0; ++a) {
-            const rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)w, 0u, RL_SITE_RESET_AGENT, (uint32_t)a);
+            const rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), 0u, RL_SITE_RESET_AGENT, (uint32_t)a);
             const int cell = placer_take(P, (int)rl_mulhi(r.x, (unsigned)P.n_empty));
             const int gene = (int)rl_mulhi(r.y, (unsigned)p.n_brains);
             if (tid == 0) init_newborn(s, a, cell, p.W, gene, gene, a);
@@ -828,7 +829,7 @@ __global__ __launch_bounds__(T) void k_reset(const KParams p)
             for (int i0 = 0; i0 < p.C; i0 += 64) {
                 // 64 iterations' draws at once, one per lane; placements stay sequential
                 const int i = i0 + tid;
-                rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)w, 0u, site, (uint32_t)i);
+                rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), 0u, site, (uint32_t)i);
                 const bool want = i < p.C && rl_u24(r.y) < prob;
                 unsigned long long m = __ballot(want);
                 while (m) {
@@ -842,7 +843,7 @@ __global__ __launch_bounds__(T) void k_reset(const KParams p)
             }
         }
         if (P.n_empty > 0) {
-            const rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)w, 0u, RL_SITE_RESET_SUPER, 0u);
+            const rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), 0u, RL_SITE_RESET_SUPER, 0u);
             const int cell = placer_take(P, (int)rl_mulhi(r.x, (unsigned)P.n_empty));
             if (tid == 0) s.type[cell] = (uint8_t)kSuper;
         }
@@ -877,7 +878,7 @@ KParams make_params(const rl_world* h)
     KParams p{};
     p.W = h->cfg.width; p.H = h->cfg.height; p.C = h->cells; p.Cp = h->cpad; p.nW = h->cpad / 64;
     p.cap = h->cfg.slot_cap; p.max_agents = h->cfg.max_agents; p.n_brains = h->cfg.n_brains;
-    p.hash_size = h->hash_size; p.hash_mask = h->hash_size - 1;
+    p.hash_size = h->hash_size; p.hash_mask = h->hash_size - 1; p.world_base = h->cfg.world_base;
     p.static_families = h->cfg.static_families; p.limit_reproduction = h->cfg.limit_reproduction;
     p.incentivize_killing = h->cfg.incentivize_killing;
     p.seed = h->cfg.seed;

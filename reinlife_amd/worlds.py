@@ -27,7 +27,8 @@ def _ptr(t):
 
 class DeviceWorlds:
     def __init__(self, n_worlds=1, width=30, height=30, max_agents=100, n_brains=2, static_families=True,
-                 limit_reproduction=False, incentivize_killing=True, seed=0, slot_cap=None, device="cuda:0"):
+                 limit_reproduction=False, incentivize_killing=True, seed=0, slot_cap=None, device="cuda:0",
+                 world_base=0):
         if not torch.cuda.is_available():
             raise _lib.ReinLifeHipError("DeviceWorlds needs an MI355X: torch.cuda.is_available() is False "
                                         "(there is no CPU fallback)")
@@ -37,7 +38,7 @@ class DeviceWorlds:
         self.cap = slot_cap or _lib.slot_cap_for(max_agents)
         self.max_agents, self.n_brains = max_agents, n_brains
         self.cfg = _lib.Config(width, height, max_agents, n_brains, self.cap, n_worlds, int(static_families),
-                               int(limit_reproduction), int(incentivize_killing), 0, seed)
+                               int(limit_reproduction), int(incentivize_killing), world_base, seed)
         self.handle = C.c_void_p()
         _lib.check(self.lib.rl_create(C.byref(self.cfg), C.byref(self.handle)), "rl_create")
         dims = {"C": (self.C,), "cap": (self.cap,), "best": (_lib.N_BEST,), "": ()}
@@ -58,11 +59,12 @@ class DeviceWorlds:
             self.out_q = torch.zeros((R, cap, 8), dtype=torch.float32, device=self.device)
             self.err = torch.zeros(4, dtype=torch.int32, device=self.device)
             self.refill_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.acted_total = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._state = _lib.State(*[_ptr(self.s[n]) for n in _lib.STATE_FIELDS])
         _lib.check(self.lib.rl_bind_state(self.handle, C.byref(self._state)), "rl_bind_state")
         _lib.check(self.lib.rl_bind_error_flag(self.handle, _ptr(self.err)), "rl_bind_error_flag")
         self._step_out = _lib.StepOut(_ptr(self.n_acted), _ptr(self.reward), _ptr(self.done), _ptr(self.src1),
-                                      _ptr(self.obs1))
+                                      _ptr(self.obs1), _ptr(self.acted_total))
         self._upd_out = _lib.UpdateOut(_ptr(self.src2), _ptr(self.obs2))
         self._work = None
         self._brains = None
