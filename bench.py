@@ -76,11 +76,9 @@ def make_worlds(args, rank, device):
     return dw
 
 
-def one_step(dw, refill=True):
-    dw.act()
-    dw.tick()
-    if refill:
-        dw.refill(70, 100)
+def one_step(dw):
+    dw.act()                    # k_bucket + k_policy: Agent.get_action for every agent of every world
+    dw.tick_refill(70, 100)     # k_world<TICK>: step + update_env (+ re-generation of worlds below 70 agents)
 
 
 def cpu_baseline(args, seconds_target=12.0):
@@ -187,15 +185,14 @@ def main():
     roofline, extra = None, {}
     if rank == 0 and not args.no_kernel_timing:
         n_probe = 40
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_probe)]
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_probe)]
         probe_acted = 0
         for i in range(n_probe):
-            ev[i][0].record(); dw.act(); ev[i][1].record(); dw.tick(); ev[i][2].record(); dw.refill(70, 100); ev[i][3].record()
+            ev[i][0].record(); dw.act(); ev[i][1].record(); dw.tick_refill(70, 100); ev[i][2].record()
             probe_acted += int(dw.n_acted.sum().item())
         torch.cuda.synchronize()
         t_act = np.mean([e[0].elapsed_time(e[1]) for e in ev]) * 1e-3
         t_tick = np.mean([e[1].elapsed_time(e[2]) for e in ev]) * 1e-3
-        t_refill = np.mean([e[2].elapsed_time(e[3]) for e in ev]) * 1e-3
         per_launch = probe_acted / n_probe
         wl = WORKLOADS[args.workload]
         flop = np.mean([POLICY_FLOP_PER_AGENT[n] for n in wl["brains"]])
@@ -208,7 +205,7 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:  # noqa: BLE001
                 traffic = None
-        tick_roof = {"kernel": "k_world<256,TICK> (rl_tick)", "bound": "hbm", "achieved": round(tick_gbs, 2), "peak": HBM_PEAK_GBS,
+        tick_roof = {"kernel": "k_world<TICK> (rl_tick_refill)", "bound": "hbm", "achieved": round(tick_gbs, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(tick_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "avg_launch_us": round(t_tick * 1e6, 2), "agent_steps_per_launch": round(per_launch, 1),
                      "bytes_per_agent_step": TICK_BYTES_PER_AGENT_STEP}
@@ -216,7 +213,7 @@ def main():
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(pol_tflops / MFMA_F32_PEAK_TFLOPS, 5),
                     "traffic": None, "avg_launch_us": round(t_act * 1e6, 2), "flop_per_agent": flop}
         roofline = tick_roof if t_tick >= t_act else pol_roof
-        extra = {"roofline_tick": tick_roof, "roofline_policy": pol_roof, "refill_us": round(t_refill * 1e6, 2)}
+        extra = {"roofline_tick": tick_roof, "roofline_policy": pol_roof}
 
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:

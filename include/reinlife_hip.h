@@ -135,6 +135,9 @@ int rl_bind_state(rl_world* h, const rl_state* device_ptrs);
 /* optional device int32[4] that kernels set on inconsistencies: [0] code, [1] world, [2..3] detail */
 int rl_bind_error_flag(rl_world* h, int32_t* device_flag);
 
+/* tuning aid: device int64[32] receiving shader-clock stamps at the phase boundaries of world `world` (NULL = off) */
+int rl_bind_phase_profile(rl_world* h, long long* device_stamps, int world);
+
 int rl_reset_synthetic(rl_world* h, int n_agents, float* obs, void* stream);
 /* worlds with n_agents < threshold are re-generated (epoch+1); refill_count: optional device int32 accumulator */
 int rl_refill(rl_world* h, int threshold, int n_agents, float* obs, int32_t* refill_count, void* stream);
@@ -143,6 +146,9 @@ int rl_step(rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_st
 int rl_update(rl_world* h, const rl_tape* tape, const rl_update_out* out, void* stream);
 int rl_tick(rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_step_out* sout,
             const rl_update_out* uout, void* stream);
+/* rl_tick (Philox draws) followed, in the same launch, by rl_refill(threshold, n_agents) of every world */
+int rl_tick_refill(rl_world* h, const int8_t* actions, const rl_step_out* sout, const rl_update_out* uout,
+                   int threshold, int n_agents, int32_t* refill_count, void* stream);
 
 /* ---- policy ------------------------------------------------------------------------------------------------- */
 /* number of floats in a brain's state dict (flat, registration order) / in its packed MFMA layout */
@@ -156,7 +162,8 @@ int rl_policy_pack_weights(int kind, const float* state_dict_flat, float* packed
 int rl_policy_forward(int kind, const float* packed, const float* obs, int64_t n_rows, float* out, void* stream);
 /* all agents of all worlds: row (w,k) uses brains[a_brain[w][k]].
  *   obs     [R][cap][153]   actions [R][cap] (written for k < n_agents[w])   out_q [R][cap][8] or NULL
- *   work    device scratch of rl_policy_work_bytes(h) bytes
+ *   work    device scratch of rl_policy_work_bytes(h) bytes, zero-initialised ONCE by the caller before the first
+ *           call and owned by this handle afterwards (it carries double-buffered counters between calls)
  *   tape_actions: optional [R][cap] recorded actions (parity mode) that override the selected ones */
 size_t rl_policy_work_bytes(const rl_world* h);
 int rl_policy_act(rl_world* h, const rl_brain* brains, int n_brains, const float* obs, int8_t* actions, float* out_q,

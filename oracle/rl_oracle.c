@@ -465,16 +465,18 @@ int rlo_observe(const rlo_config* cfg, const rlo_state* st, float* obs, int w0, 
 }
 
 /* ------------------------------------------------------------------------------------------------------------ */
-/* Synthetic world generator (the build's own rule, identical on CPU and GPU):
- *   n_agents agents at uniformly random empty cells, gene = brain = uniform over n_brains, health 200, age 0;
- *   then Environment._init_food's rule (environment.py:741-761): for each of H*W iterations Food with p=.1 at a
- *   random empty cell, likewise Poison with p=.05, then one SuperFood.  All draws from Philox sites RESET_*. */
-static int kth_empty(const world_t* wd, int k)
+/* Synthetic world generator (the build's own rule, identical on CPU and GPU, parallel by design):
+ *   every cell c draws r = Philox(seed, epoch, world, tick 0, site RESET_CELL, index c);
+ *   cells are ranked by the unique key (r.x & ~0xFFF) | c  (a uniformly random permutation of the cells);
+ *   n_food = #{c : u24(r.z) < 0.1}, n_poison = #{c : u24(r.w) < 0.05}  (the Binomial(H*W, p) counts that
+ *   Environment._init_food's H*W coin flips produce, environment.py:741-761);
+ *   rank < n_agents -> Agent (gene = brain = mulhi(r.y, n_brains), health 200, age 0), the next n_food ranks Food,
+ *   the next n_poison ranks Poison, the next one SuperFood.  Agents are listed row-major; uid = list index. */
+typedef struct { uint32_t key; int cell; } keyed_t;
+static int cmp_keyed(const void* a, const void* b)
 {
-    int seen = 0;
-    for (int c = 0; c < wd->C; ++c)
-        if (wd->type[c] == RLO_EMPTY) { if (seen == k) return c; ++seen; }
-    return -1;
+    uint32_t x = ((const keyed_t*)a)->key, y = ((const keyed_t*)b)->key;
+    return x < y ? -1 : (x > y ? 1 : 0);
 }
 
 static void reset_world(const rlo_config* cfg, rlo_state* st, int w, int n_agents, float* obs)
@@ -491,30 +493,24 @@ static void reset_world(const rlo_config* cfg, rlo_state* st, int w, int n_agent
         st->best_uid[(size_t)w * RLO_N_BEST + b] = -1; st->best_fit[(size_t)w * RLO_N_BEST + b] = 0.0;
         st->best_brain[(size_t)w * RLO_N_BEST + b] = 0;
     }
-    int n_empty = wd.C;
-    uint32_t r[4];
-    for (int a = 0; a < n_agents && n_empty > 0; ++a) {
-        draw(&wd, RLO_SITE_RESET_AGENT, (uint32_t)a, r);
-        int cell = kth_empty(&wd, (int)mulhi32(r[0], (uint32_t)n_empty));
-        int gene = (int)mulhi32(r[1], (uint32_t)cfg->n_brains);
-        wd.type[cell] = RLO_AGENT; --n_empty;
-        new_agent(&wd, st, a, cell, gene, gene);
+    keyed_t* ks = (keyed_t*)malloc(sizeof(keyed_t) * (size_t)wd.C);
+    uint32_t* gdraw = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)wd.C);
+    int nf = 0, np_ = 0;
+    for (int c = 0; c < wd.C; ++c) {
+        uint32_t r[4]; draw(&wd, RLO_SITE_RESET_AGENT, (uint32_t)c, r);
+        ks[c].key = (r[0] & ~0xFFFu) | (uint32_t)c; ks[c].cell = c; gdraw[c] = r[1];
+        nf += (u24(r[2]) < 0.1); np_ += (u24(r[3]) < 0.05);
     }
-    for (int pass = 0; pass < 2; ++pass) {
-        uint32_t site = pass == 0 ? RLO_SITE_RESET_FOOD : RLO_SITE_RESET_POISON;
-        double p = pass == 0 ? 0.1 : 0.05;
-        for (int i = 0; i < wd.C; ++i) {
-            draw(&wd, site, (uint32_t)i, r);
-            if (u24(r[1]) < p && n_empty > 0) {
-                int cell = kth_empty(&wd, (int)mulhi32(r[0], (uint32_t)n_empty));
-                wd.type[cell] = pass == 0 ? RLO_FOOD : RLO_POISON; --n_empty;
-            }
-        }
+    qsort(ks, (size_t)wd.C, sizeof(keyed_t), cmp_keyed);
+    const int na = n_agents < wd.C ? n_agents : wd.C;
+    for (int p = 0; p < wd.C; ++p) {
+        int c = ks[p].cell;
+        wd.type[c] = p < na ? RLO_AGENT : p < na + nf ? RLO_FOOD : p < na + nf + np_ ? RLO_POISON : p == na + nf + np_ ? RLO_SUPER : RLO_EMPTY;
     }
-    if (n_empty > 0) {
-        draw(&wd, RLO_SITE_RESET_SUPER, 0, r);
-        wd.type[kth_empty(&wd, (int)mulhi32(r[0], (uint32_t)n_empty))] = RLO_SUPER;
-    }
+    int idx = 0;
+    for (int c = 0; c < wd.C; ++c)
+        if (wd.type[c] == RLO_AGENT) { int g = (int)mulhi32(gdraw[c], (uint32_t)cfg->n_brains); new_agent(&wd, st, idx++, c, g, g); }
+    free(ks); free(gdraw);
     int* l = (int*)malloc(sizeof(int) * (size_t)wd.cap);
     int n = grid_agents(&wd, l);
     if (obs) observe(&wd, l, n, obs + (size_t)w * wd.cap * RLO_OBS_DIM);

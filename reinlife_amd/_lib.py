@@ -60,12 +60,14 @@ ABI = [
     ("rl_destroy", None, [_P]),
     ("rl_bind_state", C.c_int, [_P, C.POINTER(State)]),
     ("rl_bind_error_flag", C.c_int, [_P, _P]),
+    ("rl_bind_phase_profile", C.c_int, [_P, _P, C.c_int]),
     ("rl_reset_synthetic", C.c_int, [_P, C.c_int, _P, _P]),
     ("rl_refill", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
     ("rl_observe", C.c_int, [_P, _P, _P]),
     ("rl_step", C.c_int, [_P, _P, C.POINTER(Tape), C.POINTER(StepOut), _P]),
     ("rl_update", C.c_int, [_P, C.POINTER(Tape), C.POINTER(UpdateOut), _P]),
     ("rl_tick", C.c_int, [_P, _P, C.POINTER(Tape), C.POINTER(StepOut), C.POINTER(UpdateOut), _P]),
+    ("rl_tick_refill", C.c_int, [_P, _P, C.POINTER(StepOut), C.POINTER(UpdateOut), C.c_int, C.c_int, _P, _P]),
     ("rl_policy_n_params", C.c_int64, [C.c_int]),
     ("rl_policy_packed_floats", C.c_int64, [C.c_int]),
     ("rl_policy_pack_weights", C.c_int, [C.c_int, _P, _P]),

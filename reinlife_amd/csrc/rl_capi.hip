@@ -12,7 +12,7 @@ size_t rl_world_smem_bytes(int cpad, int cap, int hash);
 int rl_world_block();
 int rl_world_launch_step(const rl_world*, const int8_t*, const rl_tape*, const rl_step_out*, hipStream_t);
 int rl_world_launch_update(const rl_world*, const rl_tape*, const rl_update_out*, hipStream_t);
-int rl_world_launch_tick(const rl_world*, const int8_t*, const rl_tape*, const rl_step_out*, const rl_update_out*, hipStream_t);
+int rl_world_launch_tick(const rl_world*, const int8_t*, const rl_tape*, const rl_step_out*, const rl_update_out*, int, int, int32_t*, hipStream_t);
 int rl_world_launch_observe(const rl_world*, float*, hipStream_t);
 int rl_world_launch_reset(const rl_world*, int, int, float*, int32_t*, hipStream_t);
 int64_t rl_policy_n_params_impl(int);
@@ -93,6 +93,13 @@ int rl_bind_error_flag(rl_world* h, int32_t* flag)
     return RL_OK;
 }
 
+int rl_bind_phase_profile(rl_world* h, long long* device_stamps, int world)
+{
+    if (!h) { rl_set_error("rl_bind_phase_profile: null handle"); return RL_E_INVALID; }
+    h->prof = device_stamps; h->prof_world = world;
+    return RL_OK;
+}
+
 #define RL_CHECK_BOUND(fn)                                                              \
     if (!h) { rl_set_error(fn ": null handle"); return RL_E_INVALID; }                 \
     if (!h->bound) { rl_set_error(fn ": rl_bind_state was not called"); return RL_E_UNBOUND; }
@@ -148,7 +155,16 @@ int rl_tick(rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_st
     RL_CHECK_BOUND("rl_tick")
     if (!actions) { rl_set_error("rl_tick: null actions"); return RL_E_INVALID; }
     if (int rc = check_tape(tape, "rl_tick")) return rc;
-    return rl_world_launch_tick(h, actions, tape, sout, uout, (hipStream_t)stream);
+    return rl_world_launch_tick(h, actions, tape, sout, uout, -1, 0, nullptr, (hipStream_t)stream);
+}
+
+int rl_tick_refill(rl_world* h, const int8_t* actions, const rl_step_out* sout, const rl_update_out* uout, int threshold,
+                   int n_agents, int32_t* refill_count, void* stream)
+{
+    RL_CHECK_BOUND("rl_tick_refill")
+    if (!actions) { rl_set_error("rl_tick_refill: null actions"); return RL_E_INVALID; }
+    if (threshold < 0 || n_agents < 0 || n_agents > h->cfg.slot_cap || n_agents > h->cells) { rl_set_error("rl_tick_refill: bad arguments"); return RL_E_INVALID; }
+    return rl_world_launch_tick(h, actions, nullptr, sout, uout, threshold, n_agents, refill_count, (hipStream_t)stream);
 }
 
 int64_t rl_policy_n_params(int kind) { return rl_policy_n_params_impl(kind); }

@@ -15,6 +15,9 @@ struct rl_world {
     int hash_size;       // power of two >= 2*slot_cap
     size_t smem_bytes;   // dynamic LDS of the world kernels
     int block;           // threads per world workgroup
+    int act_parity;      // which half of the policy work counters the next rl_policy_act uses
+    long long* prof;     // optional device int64[32]: shader-clock stamps of one world's phases
+    int prof_world;
 };
 
 void rl_set_error(const char* fmt, ...);

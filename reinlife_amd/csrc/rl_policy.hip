@@ -6,8 +6,10 @@
 //   PERD3QN  DuelingDDQN.forward     PERD3QN.py:198-202  (same network)
 //   PPO      PPO.pi                  PPO.py:101-106      153 -> 256 -> 256 -> 8 -> softmax
 //   action selection                 DQN.py:132-139, D3QN.py:167-173, PERD3QN.py:204-210, PPO.py:164-169
-// The reference runs one batch-1 forward per agent; here one wave owns 32 agents (observation rows) and runs the
-// whole MLP for them without leaving registers:
+// The reference runs one batch-1 forward per agent; here a 4-wave workgroup owns 32 agents (observation rows):
+// every wave computes a quarter of each layer's output features for those 32 rows ("N-split": 4x shorter dependency
+// chain per tile and 4x more waves than one-wave-per-tile, which is what matters at 256 worlds = ~700 tiles on
+// 1024 SIMDs), activations cross waves through LDS once per layer:
 //
 //   * fp32 everywhere (v_mfma_f32_32x32x2_f32: exact f32 fma chains, the 157 TFLOP/s matrix rate of gfx950).
 //   * transposed formulation  H_out[feature][row] = W[feature][k] . H_in[k][row]: the WEIGHTS are the MFMA A operand
@@ -79,92 +81,120 @@ __device__ inline f32x4 load_xq(const float* __restrict__ row, int h, int q)
     return h ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : w;
 }
 
-// The packed weights are STEP-major: [K-quad step][output tile][lane][4 floats], so the TOUT fragments of one step
-// are 1 KiB apart (immediate offsets of one running pointer).  The pointer is made opaque at every step so that the
-// compiler neither precomputes nor hoists hundreds of 64-bit addresses (that spilled the accumulators), and a
-// sched_barrier per step bounds the prefetch distance to exactly one step (2 x TOUT fragment registers).
-template <int TOUT>
-__device__ inline void layer_in(const float* __restrict__ pw, int lane, const float* __restrict__ row, f32x16 (&acc)[TOUT])
+// The packed weights are STEP-major: [K-quad step][output tile][lane][4 floats], so the fragments of one step are
+// 1 KiB apart (immediate offsets of one running pointer).  The pointer is made opaque at every step so that the
+// compiler neither precomputes nor hoists hundreds of 64-bit addresses, and a sched_barrier per step bounds the
+// prefetch distance to exactly one step.
+//
+// layer_in: this wave computes output tiles {t0, t0 + TSTRIDE, ...} (NT of them) of a layer with TOUT tiles.
+// D = prefetch ring depth in K-quad steps: a step is only 4*NT MFMAs (256*NT cycles), an L2 round trip under load is
+// 2-3x that, so D steps of operands are kept in flight.
+template <int TOUT, int NT, int TSTRIDE, int D>
+__device__ inline void layer_in(const float* __restrict__ pw, int lane, int t0, const float* __restrict__ row, f32x16 (&acc)[NT])
 {
-    const f32x4* p = (const f32x4*)pw + lane;
+    const f32x4* p = (const f32x4*)pw + t0 * 64 + lane;
     const int h = lane >> 5;
 #pragma unroll
-    for (int t = 0; t < TOUT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    f32x4 a[2][TOUT], x[2];
+    f32x4 a[D][NT], x[D];
 #pragma unroll
-    for (int t = 0; t < TOUT; ++t) a[0][t] = p[t * 64];
-    x[0] = load_xq(row, h, 0);
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[d][t] = p[(d * TOUT + t * TSTRIDE) * 64];
+        x[d] = load_xq(row, h, d);
+    }
 #pragma unroll
     for (int q = 0; q < kInQuads; ++q) {
-        const int cur = q & 1, nxt = cur ^ 1;
-        if (q + 1 < kInQuads) {  // prefetch the next step's operands ahead of this step's MFMAs
-            p += TOUT * 64;
-            asm volatile("" : "+v"(p));
+        const int cur = q % D;
+        f32x4 ac[NT], xc = x[cur];
 #pragma unroll
-            for (int t = 0; t < TOUT; ++t) a[nxt][t] = p[t * 64];
-            x[nxt] = load_xq(row, h, q + 1);
+        for (int t = 0; t < NT; ++t) ac[t] = a[cur][t];
+        p += TOUT * 64;
+        asm volatile("" : "+v"(p));
+        if (q + D < kInQuads) {  // refill this ring slot with step q + D
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a[cur][t] = p[((D - 1) * TOUT + t * TSTRIDE) * 64];
+            x[cur] = load_xq(row, h, q + D);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int t = 0; t < TOUT; ++t) acc[t] = mfma(a[cur][t][e], x[cur][e], acc[t]);
+            for (int t = 0; t < NT; ++t) acc[t] = mfma(ac[t][e], xc[e], acc[t]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <int TIN>
-__device__ inline void relu_inplace(f32x16 (&h)[TIN])
+template <int NT>
+__device__ inline void relu_inplace(f32x16 (&h)[NT])
 {
 #pragma unroll
-    for (int t = 0; t < TIN; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[t][r] = fmaxf(h[t][r], 0.0f);
 }
 
-template <int TIN, int TOUT>
-__device__ inline void layer_hidden(const float* __restrict__ pw, int lane, const f32x16 (&hin)[TIN], f32x16 (&acc)[TOUT])
+// Publish this wave's activation tile `t` to the workgroup: lds[(t*4 + q)*64 + lane] = registers 4q..4q+3, i.e.
+// exactly the B-operand quad of K-step (t, q) of the next layer for this lane.
+__device__ inline void publish_tile(f32x4* lds, int t, int lane, const f32x16& h)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lds[(t * 4 + q) * 64 + lane] = f32x4{h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]};
+}
+
+// layer_hidden: input = TIN published tiles in LDS; this wave computes output tiles {t0, t0 + TSTRIDE, ...}.
+template <int TIN, int TOUT, int NT, int TSTRIDE, int D>
+__device__ inline void layer_hidden(const float* __restrict__ pw, int lane, int t0, const f32x4* __restrict__ hin, f32x16 (&acc)[NT])
 {
     constexpr int NS = TIN * 4;  // step s = t*4 + q covers input features 32t + 8q + 4h + e
-    const f32x4* p = (const f32x4*)pw + lane;
-    const float* bias = pw + (int64_t)NS * TOUT * 64 * 4;
+    const f32x4* p = (const f32x4*)pw + t0 * 64 + lane;
+    const float* bias = pw + (int64_t)NS * TOUT * 64 * 4 + t0 * 64 + lane;
     const float one = lane < 32 ? 1.0f : 0.0f;
-    f32x4 a[2][TOUT];
+    f32x4 a[D][NT], b[2];
 #pragma unroll
-    for (int t2 = 0; t2 < TOUT; ++t2) a[0][t2] = p[t2 * 64];
+    for (int d = 0; d < D; ++d)
 #pragma unroll
-    for (int t2 = 0; t2 < TOUT; ++t2) {
+        for (int t = 0; t < NT; ++t) a[d][t] = p[(d * TOUT + t * TSTRIDE) * 64];
+    b[0] = hin[lane];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t2][r] = 0.0f;
-        acc[t2] = mfma(bias[t2 * 64 + lane], one, acc[t2]);  // bias as one extra K-step against a constant-1 input
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        acc[t] = mfma(bias[t * TSTRIDE * 64], one, acc[t]);  // bias as one extra K-step against a constant-1 input
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const int cur = s & 1, nxt = cur ^ 1;
-        if (s + 1 < NS) {
-            p += TOUT * 64;
-            asm volatile("" : "+v"(p));
+        const int cur = s % D;
+        f32x4 ac[NT];
 #pragma unroll
-            for (int t2 = 0; t2 < TOUT; ++t2) a[nxt][t2] = p[t2 * 64];
+        for (int t = 0; t < NT; ++t) ac[t] = a[cur][t];
+        const f32x4 bc = b[s & 1];
+        p += TOUT * 64;
+        asm volatile("" : "+v"(p));
+        if (s + D < NS) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a[cur][t] = p[((D - 1) * TOUT + t * TSTRIDE) * 64];
         }
+        if (s + 1 < NS) b[(s + 1) & 1] = hin[(s + 1) * 64 + lane];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int t2 = 0; t2 < TOUT; ++t2) acc[t2] = mfma(a[cur][t2][e], hin[s / 4][4 * (s % 4) + e], acc[t2]);
+            for (int t = 0; t < NT; ++t) acc[t] = mfma(ac[t][e], bc[e], acc[t]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// narrow head on the VALU: out[i] = b[i] + sum_f W[i][f] h[f]; every lane ends with the full sums of its row
-template <int TIN, int NOUT>
-__device__ inline void head(const float* __restrict__ hw, int h, const f32x16 (&hin)[TIN], float (&out)[NOUT])
+// narrow head on the VALU, partial over this wave's NT tiles {t0, t0+TSTRIDE, ..}: out[i] = sum_f W[i][f] h[f]
+// (both halves of the wave end with the sum over the wave's features; bias and the cross-wave sum come later)
+template <int NT, int TSTRIDE, int NOUT>
+__device__ inline void head_partial(const float* __restrict__ hw, int h, int t0, const f32x16 (&hin)[NT], float (&out)[NOUT])
 {
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) out[i] = 0.0f;
-    const float* wp = hw + h * NOUT;  // [t][r][h][NOUT]
 #pragma unroll
-    for (int t = 0; t < TIN; ++t)
+    for (int t = 0; t < NT; ++t) {
+        const float* wp = hw + ((t0 + t * TSTRIDE) * 16 * 2 + h) * NOUT;  // [tile][r][h][NOUT]
 #pragma unroll
         for (int rg = 0; rg < 16; rg += 4) {
 #pragma unroll
@@ -183,125 +213,201 @@ __device__ inline void head(const float* __restrict__ hw, int h, const f32x16 (&
             asm volatile("" : "+v"(wp));
             __builtin_amdgcn_sched_barrier(0);
         }
-    const float* b = hw + TIN * 16 * 2 * NOUT;
+    }
 #pragma unroll
-    for (int i = 0; i < NOUT; ++i) out[i] = out[i] + __shfl_xor(out[i], 32) + b[i];
+    for (int i = 0; i < NOUT; ++i) out[i] = out[i] + __shfl_xor(out[i], 32);
 }
 
+constexpr int kMaxBrainsPerLaunch = 8;
+
+struct BrainSlot {
+    const float* packed;   // device, rl_policy_pack_weights layout
+    const int* rowlist;    // row ids (world*cap + k) of the agents using this brain; nullptr = dense rows 0..n_rows-1
+    const int* count_ptr;  // device count of rowlist entries (nullptr = n_rows)
+    float eps;
+    int pad;
+};
+
 struct PolicyArgs {
-    const float* packed;
+    BrainSlot b[kMaxBrainsPerLaunch];
+    int nb;
     const float* obs;         // rows of 153 floats
-    const int* rowlist;       // optional: row ids (world*cap + k); nullptr = dense rows 0..n_rows-1
-    const int* count_ptr;     // device count of rowlist entries (nullptr = n_rows)
-    int64_t n_rows;
+    int64_t n_rows;           // dense mode only
     float* out;               // [row][8] or nullptr
     int8_t* actions;          // [row] or nullptr
-    float eps;
     uint64_t seed;
     int cap, world_base;
     const int32_t* tick;      // per world
     const int32_t* epoch;
 };
 
+// One launch serves every brain of one kind: the tile space is the concatenation of the brains' 32-row tiles; one
+// 4-wave workgroup per tile.
 template <int KIND>
 __global__ __launch_bounds__(256) void k_policy(const PolicyArgs A)
 {
-    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
-    const int64_t n = A.count_ptr ? (int64_t)*A.count_ptr : A.n_rows;
-    const int64_t ntiles = (n + 31) / 32;
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    constexpr int HID_TILES = KIND == RL_PPO ? 8 : 4;          // tiles of the first hidden layer
+    __shared__ __attribute__((aligned(16))) f32x4 lds_h[HID_TILES * 4 * 64];  // published activations (16 / 32 KiB)
+    __shared__ float lds_part[4][32][9];                        // per-wave head partials
+
+    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, v = threadIdx.x >> 6;
+    int ntiles = 0;
+    for (int i = 0; i < A.nb; ++i) ntiles += ((A.b[i].count_ptr ? *A.b[i].count_ptr : (int)A.n_rows) + 31) / 32;
     const Layout L = layout_of(KIND);
-    for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
-        const int64_t li = tile * 32 + j;
+    for (int gt = blockIdx.x; gt < ntiles; gt += gridDim.x) {
+        int bi = 0, n = 0, tile = gt;
+        for (int i = 0; i < A.nb; ++i) {  // which brain does global tile gt belong to
+            n = A.b[i].count_ptr ? *A.b[i].count_ptr : (int)A.n_rows;
+            bi = i;
+            const int nt = (n + 31) / 32;
+            if (tile < nt) break;
+            tile -= nt;
+        }
+        const BrainSlot B = A.b[bi];
+        const float* __restrict__ packed = B.packed;
+        const int li = tile * 32 + j;
         const bool valid = li < n;
-        const int64_t row = valid ? (A.rowlist ? (int64_t)A.rowlist[li] : li) : (A.rowlist ? (int64_t)A.rowlist[tile * 32] : tile * 32);
+        const int64_t row = valid ? (B.rowlist ? (int64_t)B.rowlist[li] : (int64_t)li) : (B.rowlist ? (int64_t)B.rowlist[tile * 32] : (int64_t)tile * 32);
         const float* xrow = A.obs + row * RL_OBS_DIM;
-        float q[8];
+        float part[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) part[i] = 0.0f;
         if (KIND == RL_DQN) {
-            f32x16 h1[4], h2[2];
-            layer_in<4>(A.packed + L.l1, lane, xrow, h1);
-            relu_inplace<4>(h1);
-            layer_hidden<4, 2>(A.packed + L.l2a, lane, h1, h2);
-            relu_inplace<2>(h2);
-            head<2, 8>(A.packed + L.ha, h, h2, q);
+            f32x16 h1[1], h2[1];
+            layer_in<4, 1, 1, 4>(packed + L.l1, lane, v, xrow, h1);
+            relu_inplace<1>(h1);
+            publish_tile(lds_h, v, lane, h1[0]);
+            __syncthreads();
+            if (v < 2) {  // the second hidden layer has 2 output tiles: waves 0 and 1
+                float q8[8];
+                layer_hidden<4, 2, 1, 1, 4>(packed + L.l2a, lane, v, lds_h, h2);
+                relu_inplace<1>(h2);
+                head_partial<1, 1, 8>(packed + L.ha, h, v, h2, q8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) part[i] = q8[i];
+            }
         } else if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
-            f32x16 h1[4], h2[4];
+            f32x16 h1[1], h2[1];
             float adv[8], val[1];
-            layer_in<4>(A.packed + L.l1, lane, xrow, h1);
-            relu_inplace<4>(h1);  // relu(feature) feeds both branches (PERD3QN.py:200-201)
-            layer_hidden<4, 4>(A.packed + L.l2a, lane, h1, h2);
-            relu_inplace<4>(h2);
-            head<4, 8>(A.packed + L.ha, h, h2, adv);
-            layer_hidden<4, 4>(A.packed + L.l2b, lane, h1, h2);
-            relu_inplace<4>(h2);
-            head<4, 1>(A.packed + L.hb, h, h2, val);
-            float mean = 0.0f;  // advantage.mean() of the [1,8] tensor == per-row mean when batched
+            layer_in<4, 1, 1, 4>(packed + L.l1, lane, v, xrow, h1);
+            relu_inplace<1>(h1);  // relu(feature) feeds both branches (PERD3QN.py:200-201)
+            publish_tile(lds_h, v, lane, h1[0]);
+            __syncthreads();
+            layer_hidden<4, 4, 1, 1, 4>(packed + L.l2a, lane, v, lds_h, h2);
+            relu_inplace<1>(h2);
+            head_partial<1, 1, 8>(packed + L.ha, h, v, h2, adv);
+            layer_hidden<4, 4, 1, 1, 4>(packed + L.l2b, lane, v, lds_h, h2);
+            relu_inplace<1>(h2);
+            head_partial<1, 1, 1>(packed + L.hb, h, v, h2, val);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) mean += adv[i];
-            mean *= 0.125f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) q[i] = adv[i] + val[0] - mean;
+            for (int i = 0; i < 8; ++i) part[i] = adv[i];
+            part[8] = val[0];
         } else {
-            f32x16 h1[8], h2[8];
-            layer_in<8>(A.packed + L.l1, lane, xrow, h1);
-            relu_inplace<8>(h1);
-            layer_hidden<8, 8>(A.packed + L.l2a, lane, h1, h2);
-            relu_inplace<8>(h2);
-            head<8, 8>(A.packed + L.ha, h, h2, q);
-            float m = q[0], s = 0.0f;  // softmax over the 8 logits (PPO.py:105)
+            f32x16 h1[2], h2[2];
+            float q8[8];
+            layer_in<8, 2, 4, 3>(packed + L.l1, lane, v, xrow, h1);   // tiles v and v+4
+            relu_inplace<2>(h1);
+            publish_tile(lds_h, v, lane, h1[0]);
+            publish_tile(lds_h, v + 4, lane, h1[1]);
+            __syncthreads();
+            layer_hidden<8, 8, 2, 4, 3>(packed + L.l2a, lane, v, lds_h, h2);
+            relu_inplace<2>(h2);
+            head_partial<2, 4, 8>(packed + L.ha, h, v, h2, q8);
 #pragma unroll
-            for (int i = 1; i < 8; ++i) m = fmaxf(m, q[i]);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { q[i] = expf(q[i] - m); s += q[i]; }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) q[i] = q[i] / s;
+            for (int i = 0; i < 8; ++i) part[i] = q8[i];
         }
-        if (valid && h == 0) {
-            if (A.out) {
-                f32x4* o = (f32x4*)(A.out + row * 8);
-                o[0] = f32x4{q[0], q[1], q[2], q[3]};
-                o[1] = f32x4{q[4], q[5], q[6], q[7]};
-            }
-            if (A.actions) {
-                const int w = (int)(row / A.cap), k = (int)(row - (int64_t)w * A.cap);
-                const rl_u4 r = rl_philox4x32(A.seed, (uint32_t)A.epoch[w], (uint32_t)(A.world_base + w), (uint32_t)A.tick[w], RL_SITE_ACT, (uint32_t)k);
-                const float u = (float)rl_u24(r.x);
-                int a = 0;
-                if (KIND == RL_PPO) {  // Categorical(prob).sample() as inverse CDF
-                    float cum = 0.0f; a = 7; bool found = false;
+        if (h == 0) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { cum += q[i]; if (!found && u < cum) { a = i; found = true; } }
-                } else if (u < A.eps) a = (int)(r.y >> 29);
-                else {
+            for (int i = 0; i < 9; ++i) lds_part[v][j][i] = part[i];
+        }
+        __syncthreads();
+        if (v == 0 && h == 0) {
+            float q[8];
+            float sum9[9];
 #pragma unroll
-                    for (int i = 1; i < 8; ++i) if (q[i] > q[a]) a = i;  // first maximum
+            for (int i = 0; i < 9; ++i) sum9[i] = ((lds_part[0][j][i] + lds_part[1][j][i]) + lds_part[2][j][i]) + lds_part[3][j][i];
+            if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
+                const float* ba = packed + L.ha + 4 * 16 * 2 * 8;
+                const float bv = packed[L.hb + 4 * 16 * 2 * 1];
+                float adv[8], mean = 0.0f;  // advantage.mean() of the [1,8] tensor == per-row mean when batched
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { adv[i] = sum9[i] + ba[i]; mean += adv[i]; }
+                mean *= 0.125f;
+                const float val = sum9[8] + bv;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) q[i] = adv[i] + val - mean;
+            } else {
+                const float* bq = packed + L.ha + (KIND == RL_DQN ? 2 : 8) * 16 * 2 * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) q[i] = sum9[i] + bq[i];
+                if (KIND == RL_PPO) {
+                    float m = q[0], sm = 0.0f;  // softmax over the 8 logits (PPO.py:105)
+#pragma unroll
+                    for (int i = 1; i < 8; ++i) m = fmaxf(m, q[i]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { q[i] = expf(q[i] - m); sm += q[i]; }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) q[i] = q[i] / sm;
                 }
-                A.actions[row] = (int8_t)a;
+            }
+            if (valid) {
+                if (A.out) {
+                    f32x4* o = (f32x4*)(A.out + row * 8);
+                    o[0] = f32x4{q[0], q[1], q[2], q[3]};
+                    o[1] = f32x4{q[4], q[5], q[6], q[7]};
+                }
+                if (A.actions) {
+                    const int w = (int)(row / A.cap), k = (int)(row - (int64_t)w * A.cap);
+                    const rl_u4 r = rl_philox4x32(A.seed, (uint32_t)A.epoch[w], (uint32_t)(A.world_base + w), (uint32_t)A.tick[w], RL_SITE_ACT, (uint32_t)k);
+                    const float u = (float)rl_u24(r.x);
+                    int a = 0;
+                    if (KIND == RL_PPO) {  // Categorical(prob).sample() as inverse CDF
+                        float cum = 0.0f; a = 7; bool found = false;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { cum += q[i]; if (!found && u < cum) { a = i; found = true; } }
+                    } else if (u < B.eps) a = (int)(r.y >> 29);
+                    else {
+#pragma unroll
+                        for (int i = 1; i < 8; ++i) if (q[i] > q[a]) a = i;  // first maximum
+                    }
+                    A.actions[row] = (int8_t)a;
+                }
             }
         }
+        __syncthreads();  // lds_h / lds_part are reused by the next tile
     }
 }
 
-// per-brain row lists: one wave per world, ballot compaction + one atomic per (world, brain)
+// Per-brain row lists: one wave per world.  Pass 1 counts the world's agents per brain with ballots (lane b keeps
+// brain b's count), ONE atomic instruction reserves the ranges of all brains, pass 2 scatters the row ids.
+// counts_zero is the other parity's counter block, cleared here for the next call (no memset node needed).
 __global__ __launch_bounds__(256) void k_bucket(const int32_t* __restrict__ n_agents, const int32_t* __restrict__ a_brain,
                                                 int n_worlds, int cap, int n_brains, int* __restrict__ counts,
-                                                int* __restrict__ lists, int64_t list_stride)
+                                                int* __restrict__ counts_zero, int* __restrict__ lists, int64_t list_stride)
 {
     const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x < 64) counts_zero[threadIdx.x] = 0;
     const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (w >= n_worlds) return;
     const int n = n_agents[w];
+    int cnt = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int k = base + lane;
+        const int b = k < n ? a_brain[(size_t)w * cap + k] : -1;
+        for (int bb = 0; bb < n_brains; ++bb) {
+            const int c = __popcll(__ballot(b == bb));
+            if (lane == bb) cnt += c;
+        }
+    }
+    int pos = (lane < n_brains && cnt) ? atomicAdd(&counts[lane], cnt) : 0;
     for (int base = 0; base < n; base += 64) {
         const int k = base + lane;
         const int b = k < n ? a_brain[(size_t)w * cap + k] : -1;
         for (int bb = 0; bb < n_brains; ++bb) {
             const unsigned long long m = __ballot(b == bb);
-            if (!m) continue;
-            int pos = 0;
-            if (lane == 0) pos = atomicAdd(&counts[bb], __popcll(m));
-            pos = __shfl(pos, 0);
-            if (b == bb) lists[bb * list_stride + pos + __popcll(m & ((1ull << lane) - 1ull))] = w * cap + k;
+            const int start = __shfl(pos, bb);
+            if (b == bb) lists[bb * list_stride + start + __popcll(m & ((1ull << lane) - 1ull))] = w * cap + k;
+            if (lane == bb) pos += __popcll(m);
         }
     }
 }
@@ -392,10 +498,9 @@ int rl_policy_pack_impl(int kind, const float* sd, float* packed)
 
 static int policy_grid(int64_t max_rows)
 {
-    const int64_t tiles = (max_rows + 31) / 32;
-    int64_t blocks = (tiles + 3) / 4;
+    int64_t blocks = (max_rows + 31) / 32 + kMaxBrainsPerLaunch;  // one 4-wave workgroup per 32-row tile
     if (blocks < 1) blocks = 1;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 16384) blocks = 16384;
     return (int)blocks;
 }
 
@@ -417,36 +522,47 @@ static int launch_policy(int kind, const PolicyArgs& a, int64_t max_rows, hipStr
 int rl_policy_forward_impl(int kind, const float* packed, const float* obs, int64_t n_rows, float* out, hipStream_t st)
 {
     PolicyArgs a{};
-    a.packed = packed; a.obs = obs; a.n_rows = n_rows; a.out = out; a.cap = 1;
+    a.nb = 1; a.b[0].packed = packed; a.obs = obs; a.n_rows = n_rows; a.out = out; a.cap = 1;
     return launch_policy(kind, a, n_rows, st);
 }
 
+// work layout: int counts[2][64] (parity double buffer, zero-initialised once by the caller), then
+// int lists[n_brains][n_worlds*slot_cap]
 size_t rl_policy_work_bytes_impl(const rl_world* h)
 {
-    return 64 * sizeof(int) + (size_t)h->cfg.n_brains * h->cfg.n_worlds * h->cfg.slot_cap * sizeof(int);
+    return 128 * sizeof(int) + (size_t)h->cfg.n_brains * h->cfg.n_worlds * h->cfg.slot_cap * sizeof(int);
 }
 
 int rl_policy_act_impl(rl_world* h, const rl_brain* brains, int n_brains, const float* obs, int8_t* actions, float* out_q,
                        void* work, hipStream_t st)
 {
     const int R = h->cfg.n_worlds, cap = h->cfg.slot_cap;
-    int* counts = (int*)work;
-    int* lists = counts + 64;
+    const int parity = h->act_parity & 1;
+    h->act_parity ^= 1;
+    int* counts = (int*)work + 64 * parity;
+    int* counts_zero = (int*)work + 64 * (parity ^ 1);
+    int* lists = (int*)work + 128;
     const int64_t stride = (int64_t)R * cap;
-    hipError_t e = hipMemsetAsync(counts, 0, 64 * sizeof(int), st);
-    if (e != hipSuccess) { rl_set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
-    hipLaunchKernelGGL(k_bucket, dim3((R + 3) / 4), dim3(256), 0, st, h->st.n_agents, h->st.a_brain, R, cap, n_brains, counts, lists, stride);
-    e = hipGetLastError();
+    hipLaunchKernelGGL(k_bucket, dim3((R + 3) / 4), dim3(256), 0, st, h->st.n_agents, h->st.a_brain, R, cap, n_brains, counts,
+                       counts_zero, lists, stride);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rl_set_error("bucket kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
-    for (int b = 0; b < n_brains; ++b) {
+    // every live agent: populations are bounded by 2*max_agents+1 (environment.py:501 snapshot rule)
+    const int64_t bound = (int64_t)R * (int64_t)(2 * h->cfg.max_agents + 2 < cap ? 2 * h->cfg.max_agents + 2 : cap);
+    for (int kind = RL_DQN; kind <= RL_PPO; ++kind) {
         PolicyArgs a{};
-        a.packed = brains[b].packed; a.obs = obs; a.rowlist = lists + b * stride; a.count_ptr = counts + b;
-        a.n_rows = 0; a.out = out_q; a.actions = actions; a.eps = brains[b].epsilon; a.seed = h->cfg.seed; a.cap = cap; a.world_base = h->cfg.world_base;
+        a.obs = obs; a.out = out_q; a.actions = actions; a.seed = h->cfg.seed; a.cap = cap; a.world_base = h->cfg.world_base;
         a.tick = h->st.tick; a.epoch = h->st.epoch;
-        // upper bound of rows for this brain: every live agent (max_agents-bounded populations in practice)
-        const int64_t bound = (int64_t)R * (int64_t)(2 * h->cfg.max_agents + 2 < cap ? 2 * h->cfg.max_agents + 2 : cap);
-        const int rc = launch_policy(brains[b].kind, a, bound, st);
-        if (rc) return rc;
+        for (int b = 0; b < n_brains; ++b) {
+            if (brains[b].kind != kind) continue;
+            BrainSlot& s = a.b[a.nb++];
+            s.packed = brains[b].packed; s.rowlist = lists + b * stride; s.count_ptr = counts + b; s.eps = brains[b].epsilon;
+            if (a.nb == kMaxBrainsPerLaunch) {
+                if (int rc = launch_policy(kind, a, bound, st)) return rc;
+                a.nb = 0;
+            }
+        }
+        if (a.nb) if (int rc = launch_policy(kind, a, bound, st)) return rc;
     }
     return RL_OK;
 }

@@ -18,6 +18,8 @@
 //   vanish    a mover entering the cell of a later-ordered mover is erased (sequential grid overwrite)
 //   ordering  Grid.get_entities == rank of the agent's cell in a 64-bit-per-wave ballot bitmap (popcount prefix)
 //   set_random  k-th empty cell == select on the ballot bitmap of occupied cells, held in wave 0's registers
+#include <stdlib.h>
+
 #include "rl_common.h"
 
 int rl_world_prepare_bytes(size_t bytes);
@@ -28,7 +30,8 @@ constexpr int kSuper = RL_SUPER_FOOD;
 constexpr uint8_t kPadCell = 0xFF;  // grid padding up to a multiple of 64 cells: neither empty nor anything else
 
 // scalar slots in LDS
-enum { S_ALIVE = 0, S_NFOOD, S_NPOISON, S_NSUPER, S_NSLOTS, S_N1, S_N2, S_NPARENTS, S_NELIG, S_BESTK, S_ERR, S_COUNT = 16 };
+enum { S_ALIVE = 0, S_NFOOD, S_NPOISON, S_NSUPER, S_NSLOTS, S_N1, S_N2, S_NPARENTS, S_NELIG, S_BESTK, S_ERR, S_TICK, S_EPOCH,
+       S_NEXT_UID, S_MAX_GENE, S_COUNT = 16 };
 
 struct KParams {
     int W, H, C, Cp, nW;
@@ -44,6 +47,9 @@ struct KParams {
     int32_t* err;
     int reset_n_agents, refill_threshold;
     int32_t* refill_count;
+    int hash_agg;     // experiment switch: wave-aggregated gene hash (1) or per-agent LDS atomics (0)
+    long long* prof;  // optional: shader-clock stamps of world prof_world's phases (debug / tuning)
+    int prof_world;
 };
 
 struct Smem {
@@ -73,6 +79,8 @@ struct Smem {
 };
 
 enum { AUX_VANISH = 1, AUX_PARENT = 2 };
+
+#define RL_MARK(i) do { if (p.prof && (int)blockIdx.x == p.prof_world && threadIdx.x == 0) p.prof[i] = (long long)clock64(); } while (0)
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
@@ -193,6 +201,13 @@ __device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
 {
     const int tid = threadIdx.x;
     n0 = p.st.n_agents[w];
+    if (p.prof && (int)blockIdx.x == p.prof_world && threadIdx.x == 0 && n0 >= 0) p.prof[23] = (long long)clock64();
+    // per-world scalars and this tick's actions are fetched now so that no later phase waits on HBM latency
+    int sc_val = 0;
+    if (tid == S_TICK) sc_val = p.st.tick[w];
+    else if (tid == S_EPOCH) sc_val = p.st.epoch[w];
+    else if (tid == S_NEXT_UID) sc_val = p.st.next_uid[w];
+    else if (tid == S_MAX_GENE) sc_val = p.st.max_gene[w];
     const uint8_t* gt = p.st.cell_type + (size_t)w * p.C;
     for (int c = tid; c < p.Cp; c += T) {
         s.type[c] = c < p.C ? gt[c] : kPadCell;
@@ -200,7 +215,7 @@ __device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
         ((unsigned*)s.foodv)[c] = 0u;
     }
     for (int i = tid; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
-    if (tid < S_COUNT) s.scal[tid] = 0;
+    if (tid < S_COUNT) s.scal[tid] = sc_val;
     if (tid < RL_MAX_BRAINS) s.present[tid] = 0;
     if (tid < RL_N_BEST) {
         s.best_uid[tid] = p.st.best_uid[(size_t)w * RL_N_BEST + tid];
@@ -217,7 +232,7 @@ __device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
         s.brain[a] = p.st.a_brain[b + a];
         s.uid[a] = p.st.a_uid[b + a];
         s.flags[a] = p.st.a_flags[b + a];
-        s.action[a] = p.st.a_action[b + a];
+        s.action[a] = p.actions ? p.actions[b + a] : p.st.a_action[b + a];
         s.fitness[a] = p.st.a_fitness[b + a];
         s.aux[a] = 0;
         s.src[a] = (short)a;
@@ -230,17 +245,48 @@ __device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
     __syncthreads();
 }
 
-// gene -> (alive count, on-grid count) open-addressing table; every agent remembers its slot
-__device__ inline void hash_insert(Smem& s, int mask, int a, int gene, unsigned add)
+// gene -> (alive count, on-grid count) open-addressing table; every agent remembers its slot.  Lanes of a wave that
+// share a gene are aggregated first (one CAS + one add per distinct gene per wave instead of per agent): with a
+// handful of families every agent would otherwise hammer the same two LDS words.
+// Must be called by all 64 lanes of the wave; `active` lanes contribute.
+__device__ inline void hash_insert_wave(Smem& s, int mask, bool active, int a, int gene, unsigned add, int agg)
 {
-    unsigned h = ((unsigned)gene * 2654435761u) & (unsigned)mask;
-    for (;;) {
-        const int old = atomicCAS(&s.hkey[h], -1, gene);
-        if (old == -1 || old == gene) break;
-        h = (h + 1) & (unsigned)mask;
+    if (!agg) {
+        if (active) {
+            unsigned h = ((unsigned)gene * 2654435761u) & (unsigned)mask;
+            for (;;) {
+                const int old = atomicCAS(&s.hkey[h], -1, gene);
+                if (old == -1 || old == gene) break;
+                h = (h + 1) & (unsigned)mask;
+            }
+            if (add) atomicAdd(&s.hcnt[h], add);
+            s.hslot[a] = (unsigned short)h;
+        }
+        return;
     }
-    if (add) atomicAdd(&s.hcnt[h], add);
-    s.hslot[a] = (unsigned short)h;
+    unsigned long long pending = __ballot(active);
+    while (pending) {
+        const int leader = __ffsll((long long)pending) - 1;
+        const int g = __shfl(gene, leader);
+        const bool mine = active && gene == g;
+        const unsigned long long m = __ballot(mine);
+        unsigned lo = mine ? (add & 0xFFFFu) : 0u, hi = mine ? (add >> 16) : 0u;
+#pragma unroll
+        for (int d = 32; d; d >>= 1) { lo += __shfl_xor(lo, d); hi += __shfl_xor(hi, d); }
+        unsigned h = 0;
+        if (lane_id() == leader) {
+            h = ((unsigned)g * 2654435761u) & (unsigned)mask;
+            for (;;) {
+                const int old = atomicCAS(&s.hkey[h], -1, g);
+                if (old == -1 || old == g) break;
+                h = (h + 1) & (unsigned)mask;
+            }
+            if (lo | hi) atomicAdd(&s.hcnt[h], lo | (hi << 16));
+        }
+        h = __shfl(h, leader);
+        if (mine) s.hslot[a] = (unsigned short)h;
+        pending &= ~m;
+    }
 }
 
 // Grid.get_entities order of the current grid: newidx[a] / order[k] for all slots, returns count via scal[slot]
@@ -339,9 +385,6 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
     const int W = p.W, H = p.H;
     unsigned* cnt = (unsigned*)s.foodv;
     // ---- _act prologue + _attack (closed form) + _prepare_movement ------------------------------------------------
-    const int8_t* acts = p.actions + (size_t)w * p.cap;
-    for (int a = tid; a < n0; a += T) s.action[a] = acts[a];
-    __syncthreads();
     for (int a = tid; a < n0; a += T) {
         const int i = s.pos[a] & 255, j = s.pos[a] >> 8, cx = i * W + j;
         const int act = s.action[a];
@@ -377,6 +420,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
         atomicAdd(&cnt[tg], 1u);
     }
     __syncthreads();
+    RL_MARK(2);
     // ---- _execute_movement: Jacobi fixed point (environment.py:637-644) --------------------------------------------
     for (;;) {
         int conflict = 0;
@@ -396,6 +440,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
             }
         __syncthreads();
     }
+    RL_MARK(3);
     // ---- _eat + vanish rule (reads the pre-move grid) ----------------------------------------------------------------
     for (int a = tid; a < n0; a += T) {
         const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
@@ -422,7 +467,9 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
     }
     __syncthreads();
     int alive_local = 0;
-    for (int a = tid; a < n0; a += T) {
+    const int n0p = (n0 + 63) & ~63;  // whole waves take part in the gene aggregation
+    for (int a = tid; a < n0p; a += T) {
+        if (a >= n0) { hash_insert_wave(s, p.hash_mask, false, 0, 0, 0u, p.hash_agg); continue; }
         const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
         const int tg = s.tgt[a];
         if (tg != cx) {
@@ -437,10 +484,11 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
         const unsigned alive = (fl & RL_F_DEAD) ? 0u : 1u;
         const unsigned ongrid = (s.aux[a] & AUX_VANISH) ? 0u : 1u;
         alive_local += (int)alive;
-        hash_insert(s, p.hash_mask, a, s.gene[a], alive | (ongrid << 16));
+        hash_insert_wave(s, p.hash_mask, true, a, s.gene[a], alive | (ongrid << 16), p.hash_agg);
     }
     if (alive_local) atomicAdd(&s.scal[S_ALIVE], alive_local);
     __syncthreads();
+    RL_MARK(4);
     // ---- _get_rewards over the _act list incl. vanished agents (environment.py:291-311) ------------------------------
     const int alive = s.scal[S_ALIVE];
     for (int a = tid; a < n0; a += T) {
@@ -456,6 +504,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
             for (int b = 0; b < RL_N_BEST; ++b)
                 if (s.best_uid[b] == s.uid[a]) s.best_fit[b] = s.fitness[a];
     }
+    RL_MARK(5);
     // ---- _add_food (environment.py:763-776) ---------------------------------------------------------------------------
     int nf = 0, np_ = 0, ns = 0;
     for (int c = tid; c < p.Cp; c += T) {
@@ -468,6 +517,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
     if (np_) atomicAdd(&s.scal[S_NPOISON], np_);
     if (ns) atomicAdd(&s.scal[S_NSUPER], ns);
     __syncthreads();
+    RL_MARK(6);
     if (tid < 64) {
         Placer P;
         P.word = tid < p.nW ? s.occbits[tid] : ~0ull;
@@ -480,7 +530,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
         if (tid < RL_FOOD_TRIES) {
             if (tape) { xk = (unsigned)p.tape.food_k[(size_t)w * RL_FOOD_TRIES + tid]; u = p.tape.food_u[(size_t)w * RL_FOOD_TRIES + tid]; }
             else {
-                const rl_u4 r = rl_philox4x32(p.seed, (uint32_t)p.st.epoch[w], (uint32_t)(p.world_base + w), (uint32_t)p.st.tick[w], RL_SITE_FOOD, (uint32_t)tid);
+                const rl_u4 r = rl_philox4x32(p.seed, (uint32_t)s.scal[S_EPOCH], (uint32_t)(p.world_base + w), (uint32_t)s.scal[S_TICK], RL_SITE_FOOD, (uint32_t)tid);
                 xk = r.x; u = rl_u24(r.y);
             }
         }
@@ -545,10 +595,11 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
         }
         __syncthreads();
     }
+    RL_MARK(13);
     // ---- _reproduce gates (environment.py:500-501): eligible agents in list order, one draw each ---------------------
     const bool room = n1 <= p.max_agents;
     const bool tape = p.tape.food_k != nullptr;
-    const uint32_t epoch = (uint32_t)p.st.epoch[w], tick = (uint32_t)p.st.tick[w];
+    const uint32_t epoch = (uint32_t)s.scal[S_EPOCH], tick = (uint32_t)s.scal[S_TICK];
     // pass A: eligibility bitmap over list index (reuses agbits/wordbase; rebuilt by build_order afterwards)
     const int n1p = (n1 + 63) & ~63;
     for (int k = tid; k < n1p; k += T) {
@@ -604,6 +655,7 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
         if (lane_id() == 0) s.occbits[c >> 6] = m;
     }
     __syncthreads();
+    RL_MARK(14);
     // ---- births: _reproduce placements then _produce (environment.py:502-547), sequential on wave 0 ------------------
     if (tid < 64) {
         Placer P;
@@ -613,14 +665,23 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
         for (int m = 32; m; m >>= 1) ne += __shfl_xor(ne, m);
         P.n_empty = ne;
         const int npar = s.scal[S_NPARENTS];
-        int next_uid = p.st.next_uid[w];
-        int max_gene = p.st.max_gene[w];
+        int next_uid = s.scal[S_NEXT_UID];
+        int max_gene = s.scal[S_MAX_GENE];
         int n_birth = 0, slots = nslots;
+        // draw b of this tick's birth placements lives in lane b%64 (fetched / generated 64 at a time, in parallel)
+        unsigned bdraw = 0; int bdraw_base = -64;
+        auto birth_draw = [&](int b) -> unsigned {
+            if (b >= bdraw_base + 64 || b < bdraw_base) {
+                bdraw_base = b & ~63;
+                const int mine = bdraw_base + tid;
+                if (tape) bdraw = mine <= p.cap ? (unsigned)p.tape.birth_k[(size_t)w * (p.cap + 1) + mine] : 0u;
+                else bdraw = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_BIRTH, (uint32_t)mine).x;
+            }
+            return __shfl(bdraw, b & 63);
+        };
         for (int b = 0; b < npar; ++b) {
             if (P.n_empty <= 0) continue;  // full grid: randint raises, no draw, no offspring (grid.py:82-83)
-            unsigned x;  // draw indices advance only when a draw happens
-            if (tape) x = (unsigned)p.tape.birth_k[(size_t)w * (p.cap + 1) + n_birth];
-            else x = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_BIRTH, (uint32_t)n_birth).x;
+            const unsigned x = birth_draw(n_birth);  // draw indices advance only when a draw happens
             const int k = tape ? (int)x : (int)rl_mulhi(x, (unsigned)P.n_empty);
             ++n_birth;
             if (k < 0 || k >= P.n_empty) { if (tid == 0) flag_error(p, s, 2, w, b, k); continue; }
@@ -658,9 +719,7 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
                     if (c < 0 || c >= RL_N_BEST) { if (tid == 0) flag_error(p, s, 4, w, c, 0); }
                 }
                 if (P.n_empty > 0 && gene >= 0) {
-                    unsigned x;
-                    if (tape) x = (unsigned)p.tape.birth_k[(size_t)w * (p.cap + 1) + n_birth];
-                    else x = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_BIRTH, (uint32_t)n_birth).x;
+                    const unsigned x = birth_draw(n_birth);
                     const int k = tape ? (int)x : (int)rl_mulhi(x, (unsigned)P.n_empty);
                     if (k < 0 || k >= P.n_empty) { if (tid == 0) flag_error(p, s, 2, w, -1, k); }
                     else {
@@ -675,6 +734,7 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
     }
     __syncthreads();
     nslots = s.scal[S_NSLOTS];
+    RL_MARK(15);
     // ---- _remove_dead_agents (environment.py:795-799): corpses become Food ---------------------------------------------
     for (int k = tid; k < n1; k += T) {
         const int a = s.order[k];
@@ -692,7 +752,12 @@ __device__ void rebuild_gene_counts(const KParams& p, Smem& s, int n)
 {
     for (int i = threadIdx.x; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
     __syncthreads();
-    for (int k = threadIdx.x; k < n; k += T) { const int a = s.order[k]; hash_insert(s, p.hash_mask, a, s.gene[a], 1u << 16); }
+    const int np2 = (n + 63) & ~63;
+    for (int k = threadIdx.x; k < np2; k += T) {
+        const bool act = k < n;
+        const int a = act ? s.order[k] : 0;
+        hash_insert_wave(s, p.hash_mask, act, a, act ? s.gene[a] : 0, 1u << 16, p.hash_agg);
+    }
     __syncthreads();
 }
 
@@ -725,6 +790,9 @@ __device__ void store_world(const KParams& p, Smem& s, int w, int n)
     }
 }
 
+template <int T>
+__device__ int reset_world_lds(const KParams& p, Smem& s, int w, uint32_t epoch);
+
 enum { MODE_STEP = 0, MODE_UPDATE = 1, MODE_TICK = 2, MODE_OBSERVE = 3 };
 
 template <int T, int MODE>
@@ -736,7 +804,9 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
     const int w = blockIdx.x;
     const int tid = threadIdx.x;
     int n0;
+    RL_MARK(0);
     load_world<T>(p, s, w, n0);
+    RL_MARK(1);
     int nslots = n0;
     int n_cur = n0;  // length of order[]
 
@@ -749,11 +819,15 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
     }
     if (MODE == MODE_STEP || MODE == MODE_TICK) {
         phase_step<T>(p, s, w, n0);
+        RL_MARK(8);
         build_order<T>(p, s, nslots, S_N1);
+        RL_MARK(9);
         const int n1 = s.scal[S_N1];
         build_planes<T>(p, s);
         __syncthreads();
+        RL_MARK(10);
         write_observations<T>(p, s, w, n1, p.so.obs);
+        RL_MARK(11);
         const size_t b = (size_t)w * p.cap;
         for (int k = tid; k < n1; k += T) {
             const int a = s.order[k];
@@ -773,105 +847,163 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
     }
     if (MODE == MODE_UPDATE || MODE == MODE_TICK) {
         const int n1 = n_cur;
+        RL_MARK(12);
         phase_update<T>(p, s, w, n1, nslots);
+        RL_MARK(17);
         build_order<T>(p, s, nslots, S_N2);
-        const int n2 = s.scal[S_N2];
+        RL_MARK(18);
+        int n2 = s.scal[S_N2];
+        // optional fused refill: a world whose population fell below the threshold is re-generated
+        const bool refill = p.refill_threshold >= 0 && n2 < p.refill_threshold;  // uniform per workgroup
+        if (refill) n2 = reset_world_lds<T>(p, s, w, (uint32_t)s.scal[S_EPOCH] + 1u);
+        RL_MARK(19);
         rebuild_gene_counts<T>(p, s, n2);
         build_planes<T>(p, s);
         __syncthreads();
+        RL_MARK(20);
         write_observations<T>(p, s, w, n2, p.uo.obs);
+        RL_MARK(21);
         if (p.uo.src) {
             const size_t b = (size_t)w * p.cap;
             for (int k = tid; k < n2; k += T) p.uo.src[b + k] = s.src[s.order[k]];
         }
         store_world<T>(p, s, w, n2);
-        if (tid == 0) p.st.tick[w] += 1;
+        RL_MARK(22);
+        if (tid == 0 && !refill) p.st.tick[w] = s.scal[S_TICK] + 1;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// synthetic world generator (same rule as oracle/rl_oracle.c reset_world) + refill
+// synthetic world generator (same rule as oracle/rl_oracle.c reset_world), parallel by design:
+// every cell draws one Philox block; cells are ranked by a unique random key; the first n_agents ranks become agents,
+// then Binomial(C,.1) Food, Binomial(C,.05) Poison, one SuperFood (Environment._init_food's counts, environment.py:741-761)
 // ---------------------------------------------------------------------------------------------------------------
+// Leaves LDS holding the new world: type/occ, agents in slots 0..n-1 in row-major order, order[k] = k.  Returns n.
+template <int T>
+__device__ int reset_world_lds(const KParams& p, Smem& s, int w, uint32_t epoch)
+{
+    const int tid = threadIdx.x;
+    // LDS scratch (the observation planes are rebuilt afterwards): key per cell, bucket counters, keys grouped by bucket
+    unsigned* keys = (unsigned*)s.genev;
+    unsigned* cum = (unsigned*)s.foodv;
+    unsigned* sorted = (unsigned*)s.healthv;
+    int lg = 6;
+    while ((2 << lg) <= p.Cp) ++lg;          // NB = largest power of two <= Cp
+    const int NB = 1 << lg, sh = 32 - lg;
+    __syncthreads();
+    if (tid < S_COUNT) s.scal[tid] = 0;
+    for (int b = tid; b < NB; b += T) cum[b] = 0u;
+    __syncthreads();
+    // 1. one Philox block per cell: unique random key, food / poison coins; histogram of the key prefixes
+    int nf = 0, np_ = 0;
+    for (int c = tid; c < p.Cp; c += T) {
+        s.occ[c] = -1;
+        if (c < p.C) {
+            const rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), 0u, RL_SITE_RESET_AGENT, (uint32_t)c);
+            const unsigned key = (r.x & ~0xFFFu) | (unsigned)c;
+            keys[c] = key;
+            atomicAdd(&cum[key >> sh], 1u);
+            nf += rl_u24(r.z) < 0.1; np_ += rl_u24(r.w) < 0.05;
+        }
+    }
+    if (nf) atomicAdd(&s.scal[S_NFOOD], nf);
+    if (np_) atomicAdd(&s.scal[S_NPOISON], np_);
+    __syncthreads();
+    // 2. exclusive scan of the NB bucket counts, in place (each thread owns `per` consecutive buckets)
+    {
+        const int per = (NB + T - 1) / T;
+        const int b0 = tid * per;
+        unsigned local = 0;
+        for (int i = 0; i < per; ++i) if (b0 + i < NB) local += cum[b0 + i];
+        const int incl = wave_incl_scan((int)local);
+        if (lane_id() == 63) s.wred_k[tid >> 6] = incl;
+        __syncthreads();
+        unsigned base = (unsigned)(incl - (int)local);
+        for (int v = 0; v < (tid >> 6); ++v) base += (unsigned)s.wred_k[v];
+        for (int i = 0; i < per; ++i)
+            if (b0 + i < NB) { const unsigned c = cum[b0 + i]; cum[b0 + i] = base; base += c; }
+    }
+    __syncthreads();
+    // 3. counting-sort scatter: afterwards cum[b] is the END of bucket b (= start of bucket b+1)
+    for (int c = tid; c < p.C; c += T) {
+        const unsigned key = keys[c];
+        sorted[atomicAdd(&cum[key >> sh], 1u)] = key;
+    }
+    __syncthreads();
+    // 4. exact rank = bucket start + smaller keys inside the (one- or two-element) bucket; classify the cell
+    const int na = min(p.reset_n_agents, p.C);
+    const int k1 = na, k2 = na + s.scal[S_NFOOD], k3 = k2 + s.scal[S_NPOISON];
+    for (int c = tid; c < p.Cp; c += T) {
+        uint8_t t = kPadCell;
+        if (c < p.C) {
+            const unsigned key = keys[c];
+            const unsigned b = key >> sh;
+            const int start = b ? (int)cum[b - 1] : 0, end = (int)cum[b];
+            int rank = start;
+            for (int j = start; j < end; ++j) rank += sorted[j] < key;
+            t = (uint8_t)(rank < k1 ? RL_AGENT : rank < k2 ? RL_FOOD : rank < k3 ? RL_POISON : rank == k3 ? kSuper : RL_EMPTY);
+        }
+        s.type[c] = t;
+    }
+    __syncthreads();
+    for (int c = tid; c < p.Cp; c += T) {
+        const unsigned long long m = __ballot(s.type[c] == RL_AGENT);
+        if (lane_id() == 0) s.agbits[c >> 6] = m;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int cntw = tid < p.nW ? __popcll(s.agbits[tid]) : 0;
+        const int incl = wave_incl_scan(cntw);
+        s.wordbase[tid] = incl - cntw;
+    }
+    __syncthreads();
+    for (int c = tid; c < p.C; c += T)
+        if (s.type[c] == RL_AGENT) {
+            const int idx = s.wordbase[c >> 6] + __popcll(s.agbits[c >> 6] & lowmask(c & 63));
+            const rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), 0u, RL_SITE_RESET_AGENT, (uint32_t)c);
+            const int gene = (int)rl_mulhi(r.y, (unsigned)p.n_brains);
+            init_newborn(s, idx, c, p.W, gene, gene, idx);
+            s.order[idx] = (short)idx; s.newidx[idx] = (short)idx;
+        }
+    if (tid < RL_N_BEST) {
+        s.best_uid[tid] = -1; s.best_fit[tid] = 0.0; s.best_brain[tid] = 0;
+        p.st.best_uid[(size_t)w * RL_N_BEST + tid] = -1;
+        p.st.best_fit[(size_t)w * RL_N_BEST + tid] = 0.0;
+        p.st.best_brain[(size_t)w * RL_N_BEST + tid] = 0;
+    }
+    if (tid == 0) {
+        p.st.next_uid[w] = na; p.st.max_gene[w] = p.n_brains; p.st.tick[w] = 0; p.st.epoch[w] = (int)epoch;
+        if (p.refill_count) atomicAdd(p.refill_count, 1);
+    }
+    __syncthreads();
+    return na;
+}
+
 template <int T>
 __global__ __launch_bounds__(T) void k_reset(const KParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem s;
     carve(s, smem_raw, p.Cp, p.cap, p.hash_size);
-    const int w = blockIdx.x, tid = threadIdx.x;
-    if (p.refill_threshold >= 0) {
-        if (p.st.n_agents[w] >= p.refill_threshold) return;  // uniform per workgroup
-    }
-    __syncthreads();
-    uint32_t epoch = (uint32_t)p.st.epoch[w];
-    if (p.refill_threshold >= 0) epoch += 1;
-    for (int c = tid; c < p.Cp; c += T) { s.type[c] = c < p.C ? (uint8_t)RL_EMPTY : kPadCell; s.occ[c] = -1; }
-    if (tid < S_COUNT) s.scal[tid] = 0;
-    __syncthreads();
-    const int n_agents = p.reset_n_agents;
-    if (tid < 64) {
-        Placer P;
-        P.word = 0ull;
-        if (tid >= p.nW) P.word = ~0ull;
-        else if (tid == p.nW - 1 && (p.C & 63)) P.word = ~lowmask(p.C & 63);
-        P.n_empty = p.C;
-        int placed = 0;
-        for (int a = 0; a < n_agents && P.n_empty > 0; ++a) {
-            const rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), 0u, RL_SITE_RESET_AGENT, (uint32_t)a);
-            const int cell = placer_take(P, (int)rl_mulhi(r.x, (unsigned)P.n_empty));
-            const int gene = (int)rl_mulhi(r.y, (unsigned)p.n_brains);
-            if (tid == 0) init_newborn(s, a, cell, p.W, gene, gene, a);
-            ++placed;
-        }
-        for (int pass = 0; pass < 2; ++pass) {
-            const uint32_t site = pass == 0 ? RL_SITE_RESET_FOOD : RL_SITE_RESET_POISON;
-            const double prob = pass == 0 ? 0.1 : 0.05;
-            for (int i0 = 0; i0 < p.C; i0 += 64) {
-                // 64 iterations' draws at once, one per lane; placements stay sequential
-                const int i = i0 + tid;
-                rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), 0u, site, (uint32_t)i);
-                const bool want = i < p.C && rl_u24(r.y) < prob;
-                unsigned long long m = __ballot(want);
-                while (m) {
-                    const int l = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    if (P.n_empty <= 0) continue;
-                    const unsigned x = __shfl(r.x, l);
-                    const int cell = placer_take(P, (int)rl_mulhi(x, (unsigned)P.n_empty));
-                    if (tid == 0) s.type[cell] = (uint8_t)(pass == 0 ? RL_FOOD : RL_POISON);
-                }
-            }
-        }
-        if (P.n_empty > 0) {
-            const rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), 0u, RL_SITE_RESET_SUPER, 0u);
-            const int cell = placer_take(P, (int)rl_mulhi(r.x, (unsigned)P.n_empty));
-            if (tid == 0) s.type[cell] = (uint8_t)kSuper;
-        }
-        if (tid == 0) {
-            s.scal[S_NSLOTS] = placed;
-            p.st.next_uid[w] = placed; p.st.max_gene[w] = p.n_brains; p.st.tick[w] = 0; p.st.epoch[w] = (int)epoch;
-            if (p.refill_count) atomicAdd(p.refill_count, 1);
-        }
-        if (tid < RL_N_BEST) {
-            s.best_uid[tid] = -1; s.best_fit[tid] = 0.0; s.best_brain[tid] = 0;
-            p.st.best_uid[(size_t)w * RL_N_BEST + tid] = -1;
-            p.st.best_fit[(size_t)w * RL_N_BEST + tid] = 0.0;
-            p.st.best_brain[(size_t)w * RL_N_BEST + tid] = 0;
-        }
-    }
-    __syncthreads();
-    const int nslots = s.scal[S_NSLOTS];
-    build_order<T>(p, s, nslots, S_N2);
-    const int n = s.scal[S_N2];
+    const int w = blockIdx.x;
+    if (p.refill_threshold >= 0 && p.st.n_agents[w] >= p.refill_threshold) return;  // uniform per workgroup
+    const uint32_t epoch = (uint32_t)p.st.epoch[w] + (p.refill_threshold >= 0 ? 1u : 0u);
+    const int n = reset_world_lds<T>(p, s, w, epoch);
     rebuild_gene_counts<T>(p, s, n);
     build_planes<T>(p, s);
     __syncthreads();
     write_observations<T>(p, s, w, n, p.obs_only);
-    KParams q = p;  // store_world writes best_* only for non-static; done above for both
-    store_world<T>(q, s, w, n);
+    store_world<T>(p, s, w, n);
 }
 
-constexpr int kBlock = 256;
+// 1024 threads per world when there are few worlds (latency-bound: one world per CU), 256 when there are many
+// (throughput-bound: several worlds per CU hide each other's barriers).
+inline int pick_block(const rl_world* h)
+{
+    static const int forced = getenv("RL_WORLD_BLOCK") ? atoi(getenv("RL_WORLD_BLOCK")) : 0;
+    if (forced == 256 || forced == 1024) return forced;
+    return h->cfg.n_worlds <= 768 ? 1024 : 256;
+}
 
 KParams make_params(const rl_world* h)
 {
@@ -885,15 +1017,20 @@ KParams make_params(const rl_world* h)
     p.st = h->st;
     p.err = h->err_flag;
     p.refill_threshold = -1;
+    p.prof = h->prof; p.prof_world = h->prof_world;
+    static const int agg = getenv("RL_HASH_AGG") ? atoi(getenv("RL_HASH_AGG")) : 0;
+    p.hash_agg = agg;
     return p;
 }
-
 
 template <int MODE>
 int launch_world(const rl_world* h, const KParams& p, hipStream_t stream)
 {
     if (int rc = rl_world_prepare_bytes(h->smem_bytes)) return rc;
-    hipLaunchKernelGGL((k_world<kBlock, MODE>), dim3(h->cfg.n_worlds), dim3(kBlock), h->smem_bytes, stream, p);
+    if (pick_block(h) == 1024)
+        hipLaunchKernelGGL((k_world<1024, MODE>), dim3(h->cfg.n_worlds), dim3(1024), h->smem_bytes, stream, p);
+    else
+        hipLaunchKernelGGL((k_world<256, MODE>), dim3(h->cfg.n_worlds), dim3(256), h->smem_bytes, stream, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rl_set_error("world kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
     return RL_OK;
@@ -909,7 +1046,7 @@ size_t rl_world_smem_bytes(int cpad, int cap, int hash)
     Smem s;
     return carve(s, nullptr, cpad, cap, hash);
 }
-int rl_world_block() { return kBlock; }
+int rl_world_block() { return 1024; }
 
 int rl_world_prepare_bytes(size_t bytes)
 {
@@ -918,8 +1055,10 @@ int rl_world_prepare_bytes(size_t bytes)
     if (bytes <= granted) return RL_OK;
     hipError_t e = hipSuccess;
 #define RL_ATTR(K) e = e != hipSuccess ? e : hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    RL_ATTR((k_world<kBlock, MODE_STEP>)) RL_ATTR((k_world<kBlock, MODE_UPDATE>)) RL_ATTR((k_world<kBlock, MODE_TICK>))
-    RL_ATTR((k_world<kBlock, MODE_OBSERVE>)) RL_ATTR((k_reset<kBlock>))
+    RL_ATTR((k_world<256, MODE_STEP>)) RL_ATTR((k_world<256, MODE_UPDATE>)) RL_ATTR((k_world<256, MODE_TICK>))
+    RL_ATTR((k_world<256, MODE_OBSERVE>)) RL_ATTR((k_reset<256>))
+    RL_ATTR((k_world<1024, MODE_STEP>)) RL_ATTR((k_world<1024, MODE_UPDATE>)) RL_ATTR((k_world<1024, MODE_TICK>))
+    RL_ATTR((k_world<1024, MODE_OBSERVE>)) RL_ATTR((k_reset<1024>))
 #undef RL_ATTR
     if (e != hipSuccess) { rl_set_error("hipFuncSetAttribute(%zu bytes of LDS) failed: %s", bytes, hipGetErrorString(e)); return RL_E_LAUNCH; }
     granted = bytes;
@@ -942,13 +1081,14 @@ int rl_world_launch_update(const rl_world* h, const rl_tape* tape, const rl_upda
     return launch_world<MODE_UPDATE>(h, p, st);
 }
 int rl_world_launch_tick(const rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_step_out* so,
-                         const rl_update_out* uo, hipStream_t st)
+                         const rl_update_out* uo, int refill_threshold, int refill_n_agents, int32_t* refill_count, hipStream_t st)
 {
     KParams p = make_params(h);
     p.actions = actions;
     if (tape) p.tape = *tape;
     if (so) p.so = *so;
     if (uo) p.uo = *uo;
+    p.refill_threshold = refill_threshold; p.reset_n_agents = refill_n_agents; p.refill_count = refill_count;
     return launch_world<MODE_TICK>(h, p, st);
 }
 int rl_world_launch_observe(const rl_world* h, float* obs, hipStream_t st)
@@ -962,7 +1102,8 @@ int rl_world_launch_reset(const rl_world* h, int n_agents, int threshold, float*
     KParams p = make_params(h);
     p.reset_n_agents = n_agents; p.refill_threshold = threshold; p.obs_only = obs; p.refill_count = refill_count;
     if (int rc = rl_world_prepare_bytes(h->smem_bytes)) return rc;
-    hipLaunchKernelGGL((k_reset<kBlock>), dim3(h->cfg.n_worlds), dim3(kBlock), h->smem_bytes, st, p);
+    if (pick_block(h) == 1024) hipLaunchKernelGGL((k_reset<1024>), dim3(h->cfg.n_worlds), dim3(1024), h->smem_bytes, st, p);
+    else hipLaunchKernelGGL((k_reset<256>), dim3(h->cfg.n_worlds), dim3(256), h->smem_bytes, st, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rl_set_error("reset kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
     return RL_OK;

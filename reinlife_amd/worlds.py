@@ -163,6 +163,11 @@ class DeviceWorlds:
         _lib.check(self.lib.rl_tick(self.handle, _ptr(self.actions), C.byref(tape) if tape is not None else None,
                                     C.byref(self._step_out), C.byref(self._upd_out), self._stream()), "rl_tick")
 
+    def tick_refill(self, threshold, n_agents):
+        """tick() + refill(threshold, n_agents) in one launch (Philox draws)."""
+        _lib.check(self.lib.rl_tick_refill(self.handle, _ptr(self.actions), C.byref(self._step_out), C.byref(self._upd_out),
+                                           threshold, n_agents, _ptr(self.refill_count), self._stream()), "rl_tick_refill")
+
     def observe(self):
         _lib.check(self.lib.rl_observe(self.handle, _ptr(self.obs2), self._stream()), "rl_observe")
         return self.obs_state()

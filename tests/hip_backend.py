@@ -6,7 +6,7 @@ from reinlife_amd.worlds import DeviceWorlds
 
 class HipBackend:
     def __init__(self, n_worlds, fused=False, **cfg):
-        self.dw = DeviceWorlds(n_worlds=n_worlds, seed=cfg.pop("seed", 0), **cfg)
+        self.dw = DeviceWorlds(n_worlds=n_worlds, seed=cfg.pop("seed", 0), world_base=cfg.pop("world_base", 0), **cfg)
         self.cap = self.dw.cap
         self.fused = fused
 

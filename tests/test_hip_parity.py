@@ -88,6 +88,31 @@ def test_hip_matches_oracle_free_running_philox(static, limit, fused):
             _compare_states(hb, ow, "tick %d refill" % t)
 
 
+def test_hip_fused_tick_refill_matches_oracle():
+    """rl_tick_refill == step + update_env + refill(70, 100), one launch; runs long enough for many refills."""
+    from hip_backend import HipBackend
+    from oracle import oracle as orc
+    R = 40
+    cfg = dict(width=30, height=30, max_agents=100, n_brains=2, static_families=True, limit_reproduction=False,
+               incentivize_killing=True)
+    hb = HipBackend(R, seed=4321, world_base=1000, **cfg)
+    ow = orc.OracleWorlds(n_worlds=R, seed=4321, world_base=1000, **cfg)
+    hb.dw.reset_synthetic(100)
+    ow.reset_synthetic(100)
+    rng = np.random.RandomState(11)
+    refills = 0
+    for t in range(120):
+        acts = rng.randint(0, 8, size=(R, hb.cap)).astype(np.int8)
+        ow.step(acts); ow.update()
+        refills += ow.refill(70, 100)
+        hb.dw.set_actions(acts)
+        hb.dw.tick_refill(70, 100)
+        hb.dw.check_error_flag()
+        _compare_states(hb, ow, "tick %d" % t)
+        _compare_rows(hb.obs2, ow.obs2, ow.s["n_agents"], "tick %d obs2" % t)
+    assert refills > 20 and int(hb.dw.refill_count.item()) == refills
+
+
 def test_hip_small_and_rect_grids_match_oracle():
     from hip_backend import HipBackend
     from oracle import oracle as orc

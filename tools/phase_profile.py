@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Per-phase shader-clock breakdown of the tick kernel for a few worlds (tuning aid; GPU only).
+
+    python tools/phase_profile.py [--worlds 256] [--ticks 60]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from reinlife_amd import _lib  # noqa: E402
+
+NAMES = {1: "load", 2: "act+attack+prep", 3: "conflict loop", 4: "eat/move/death/hash", 5: "rewards", 6: "food count+bitmap",
+         8: "food placement", 9: "order1", 10: "planes1", 11: "obs1 write", 12: "step outputs", 13: "best agents",
+         14: "repro gates+parents+bitmap", 15: "births+produce", 17: "remove dead", 18: "order2", 19: "refill (if any)",
+         20: "genes+planes2", 21: "obs2 write", 22: "store", 100: "  (of load: kernarg + n_agents fetch)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--worlds", type=int, default=256)
+    ap.add_argument("--ticks", type=int, default=60)
+    a = ap.parse_args()
+    args = argparse.Namespace(worlds=a.worlds, workload="c4", seed=1)
+    dw = bench.make_worlds(args, 0, "cuda:0")
+    stamps = torch.zeros(32, dtype=torch.int64, device="cuda:0")
+    lib = _lib.lib()
+    acc = {}
+    totals = []
+    for t in range(a.ticks):
+        world = t % a.worlds
+        _lib.check(lib.rl_bind_phase_profile(dw.handle, C.c_void_p(stamps.data_ptr()), world), "bind")
+        stamps.zero_()
+        dw.act()
+        dw.tick_refill(70, 100)
+        torch.cuda.synchronize()
+        if t < 10:
+            continue
+        st = stamps.cpu().numpy()
+        if st[23]:
+            acc.setdefault(100, []).append(int(st[23] - st[0]))
+            st[23] = 0
+        keys = sorted(k for k in range(32) if st[k] != 0)
+        for prev, k in zip(keys[:-1], keys[1:]):
+            acc.setdefault(k, []).append(int(st[k] - st[prev]))
+        totals.append(int(st[keys[-1]] - st[keys[0]]))
+    print("phase cycles (shader clock, thread 0 of the sampled world), mean over %d ticks" % len(totals))
+    tot = np.mean(totals)
+    for k in sorted(acc):
+        m = np.mean(acc[k])
+        print("  %2d %-30s %9.0f  %5.1f%%" % (k, NAMES.get(k, "?"), m, 100 * m / tot))
+    print("  total %.0f cycles" % tot)
+
+
+if __name__ == "__main__":
+    main()
