@@ -234,8 +234,41 @@ def model_vectors():
     print("wrote %s (%.0f KB)" % (path, os.path.getsize(path) / 1024))
 
 
+def reset_vectors():
+    """Environment.reset() of the reference under fixed numpy seeds (environment.py:133-158): grid + agents."""
+    out = {}
+    for seed, n_brains, w, h in ((1, 2, 30, 30), (2, 3, 30, 30), (3, 5, 30, 20), (4, 2, 7, 5)):
+        rh.seed_all(seed)
+        env = rh.make_env(n_brains=n_brains, width=w, height=h)
+        env.reset()
+        snap, agents = rh.snapshot_world(env)
+        key = "s%d_b%d_%dx%d" % (seed, n_brains, w, h)
+        out[key + "_cell_type"] = snap["cell_type"]
+        for k in ("i", "j", "gene", "uid"):
+            out[key + "_" + k] = snap[k]
+        out[key + "_obs"] = np.stack([a.state for a in agents]).astype(np.float32)
+    path = os.path.join(OUT_DIR, "resets.npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s" % path)
+
+
+def state_dict_keys():
+    """Names and shapes of the reference networks' state dicts (the load_model wire contract)."""
+    import json
+    ref = rh.load_reference()
+    nets = {"DQN": ref.DQN().agent, "D3QN": ref.D3QN().eval_net, "PERD3QN": ref.PERD3QN().eval_net, "PPO": ref.PPO().model}
+    out = {k: [[name, list(t.shape)] for name, t in net.state_dict().items()] for k, net in nets.items()}
+    path = os.path.join(OUT_DIR, "state_dict_keys.json")
+    json.dump(out, open(path, "w"), indent=1)
+    print("wrote %s" % path)
+
+
 def main():
     os.makedirs(OUT_DIR, exist_ok=True)
+    if "--extras-only" in sys.argv:
+        reset_vectors()
+        state_dict_keys()
+        return
     trace_case("natural_static", 11, 120, n_brains=3)
     trace_case("natural_nonstatic", 12, 150, n_brains=2, static=False)
     trace_case("dense100", 13, 30, fill=100)
@@ -246,6 +279,8 @@ def main():
     trace_case("rect30x20_limit", 18, 40, width=30, height=20, fill=60, limit=True, incentive=False, max_agents=80)
     micro_cases()
     model_vectors()
+    reset_vectors()
+    state_dict_keys()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,2 @@
+from .tester import tester  # noqa: F401
+from .trainer import trainer  # noqa: F401

@@ -1,0 +1,229 @@
+"""Environment: the reference's protocol (ReinLife/World/environment.py:16-215) over the HIP world kernels.
+
+Same constructor keywords, `reset() / step() / update_env(n_epi)`, `agents` (row-major list), `brains`, `max_gene`,
+`action_space = 8`, `observation_space = 153`.  Extras (keyword-only): `n_worlds` independent replicas on the device,
+`device`, `seed`.  `env.agents` are lightweight views of world 0; the batched fast path is `env.act(n_epi)`, which runs
+Agent.get_action for every agent of every world on the GPU.
+
+reset() of a single world replays Environment.reset's exact np.random draw order on the host (environment.py:133-158,
+741-761; grid.py:69-83), so the same numpy seed gives the same initial world as the reference.  step()/update_env()
+draw from the in-kernel Philox streams (the reference's MT19937 interleaving is reproduced exactly only through recorded
+tapes, see tests/ and DESIGN.md section 4).  Tracker / Saver / renderer are out of scope.
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+from ..worlds import DeviceWorlds
+from .utils import Actions, EntityTypes
+
+
+class AgentView:
+    """One entry of env.agents: the reference's Agent attributes (entities.py:131-170) read from the device state."""
+
+    def __init__(self, env, k):
+        self._env, self._k = env, k
+        self.prob = None
+        self.info = ""
+
+    def _f(self, name):
+        return self._env._host["a_" + name][self._k]
+
+    i = property(lambda s: int(s._f("i")))
+    j = property(lambda s: int(s._f("j")))
+    coordinates = property(lambda s: [s.i, s.j])
+    health = property(lambda s: int(s._f("health")))
+    max_health = 200
+    age = property(lambda s: int(s._f("age")))
+    max_age = property(lambda s: int(s._f("max_age")))
+    gene = property(lambda s: int(s._f("gene")))
+    fitness = property(lambda s: float(s._f("fitness")))
+    dead = property(lambda s: bool(s._f("flags") & _lib.F_DEAD))
+    reproduced = property(lambda s: bool(s._f("flags") & _lib.F_REPRODUCED))
+    killed = property(lambda s: int(bool(s._f("flags") & _lib.F_KILLED)))
+    ate_super_food = property(lambda s: 1.0 if s._f("flags") & _lib.F_ATE_SUPER else -1)
+    brain = property(lambda s: s._env.brains[int(s._f("brain"))])
+    entity_type = EntityTypes.agent
+
+    @property
+    def action(self):
+        return int(self._env._actions_host[self._k])
+
+    @action.setter
+    def action(self, a):
+        self._env._actions_host[self._k] = int(a)
+        self._env._actions_dirty = True
+
+    @property
+    def state(self):
+        return self._env._state_host[self._k]
+
+    @property
+    def state_prime(self):
+        return self._env._state_prime_host[self._k] if self._env._state_prime_host is not None else self.state
+
+    @property
+    def reward(self):
+        return float(self._env._reward_host[self._k]) if self._env._reward_host is not None else None
+
+    @property
+    def done(self):
+        return bool(self._env._done_host[self._k]) if self._env._done_host is not None else False
+
+    def get_action(self, n_epi):  # entities.py:215-222
+        b = self.brain
+        if b.method == "PPO":
+            r = b.get_action(self.state)
+            self.action, self.prob = r if isinstance(r, tuple) else (r, None)
+        else:
+            self.action = b.get_action(self.state, n_epi)
+
+    def learn(self, **kwargs):  # entities.py:194-208: training is outside this build's scope
+        if self.age > 1:
+            self.brain.learn(**kwargs)
+
+
+class Environment:
+    def __init__(self, width=30, height=30, brains=None, grid_size=16, max_agents=50, update_interval=500, print_results=True,
+                 static_families=True, interactive_results=False, google_colab=False, training=True, save=False,
+                 pastel_colors=False, limit_reproduction=False, incentivize_killing=True, *, n_worlds=1, device="cuda:0",
+                 seed=0):
+        if not brains:
+            raise ValueError("Environment needs a non-empty list of brains")
+        self.width, self.height = width, height
+        self.actions, self.entities = Actions, EntityTypes
+        self.brains = brains
+        self.max_agents = max_agents
+        self.max_gene = len(brains)
+        self.static_families = static_families
+        self.training = training
+        self.save = save
+        self.google_colab = google_colab
+        self.limit_reproduction = limit_reproduction
+        self.incentivize_killing = incentivize_killing
+        self.action_space = 8
+        self.observation_space = 153
+        self.n_worlds = n_worlds
+        self.device = device
+        self.best_agents = []
+        self.tracker = None  # out of scope
+        self.worlds = DeviceWorlds(n_worlds=n_worlds, width=width, height=height, max_agents=max_agents,
+                                   n_brains=len(brains), static_families=static_families,
+                                   limit_reproduction=limit_reproduction, incentivize_killing=incentivize_killing, seed=seed,
+                                   device=device)
+        self.agents = []
+        self._host = None
+        self._state_prime_host = self._reward_host = self._done_host = None
+        self._actions_host = np.full(self.worlds.cap, -1, np.int8)
+        self._actions_dirty = False
+        self._brains_bound = False
+
+    # -- brains -------------------------------------------------------------------------------------------------
+    def _bind_brains(self):
+        self.worlds.set_brains([(b.kind, float(getattr(b, "epsilon", 0.0)), b.packed_weights(self.device)) for b in self.brains])
+        self._brains_bound = True
+
+    # -- reference protocol ---------------------------------------------------------------------------------------
+    def reset(self):
+        """environment.py:133-158.  World 0 (and every replica when n_worlds == 1) follows the reference's np.random
+        draw order exactly; further replicas come from the Philox generator."""
+        if self.n_worlds > 1:  # replicas 1..: Philox generator worlds with len(brains) agents (random genes)
+            self.worlds.reset_synthetic(len(self.brains))
+        snap = host_reset(self.width, self.height, len(self.brains))
+        self.worlds.load_world(0, snap)
+        self.max_gene = len(self.brains)
+        self.worlds.observe()
+        self._refresh(after="update")
+
+    def act(self, n_epi=0):
+        """Agent.get_action for every agent of every world, batched on the GPU (trainer.py:88-89)."""
+        for b in self.brains:
+            b.update_epsilon(n_epi)
+        self._bind_brains()
+        self.worlds.act()
+        self._actions_host = self.worlds.actions[0].cpu().numpy().copy()
+        self._actions_dirty = False
+
+    def step(self):
+        """environment.py:160-186"""
+        if self._actions_dirty:
+            full = self.worlds.actions.cpu().numpy()
+            full[0] = self._actions_host
+            self.worlds.set_actions(full)
+            self._actions_dirty = False
+        self.worlds.step()
+        self._refresh(after="step")
+
+    def update_env(self, n_epi=0):
+        """environment.py:188-215 (Tracker excluded)"""
+        self.worlds.update()
+        self._refresh(after="update")
+
+    def render(self, fps=10):
+        return False  # renderer out of scope
+
+    def save_results(self):
+        raise NotImplementedError("Saver is out of scope of this build (SURVEY.md section 2 row 16)")
+
+    # -- host mirror of world 0 --------------------------------------------------------------------------------------
+    def _refresh(self, after):
+        w = self.worlds
+        torch.cuda.synchronize(w.device)
+        w.check_error_flag()
+        n = int(w.s["n_agents"][0].item())
+        self._host = {k: w.s[k][0, :n].cpu().numpy() for k in w.s if k.startswith("a_")}
+        self.max_gene = int(w.s["max_gene"][0].item())
+        self.grid = w.s["cell_type"][0].cpu().numpy().reshape(self.height, self.width)
+        if after == "step":
+            self._state_prime_host = w.obs_state_prime()[0, :n].cpu().numpy().astype(np.float64)
+            self._reward_host = w.reward[0, :n].cpu().numpy()
+            self._done_host = w.done[0, :n].cpu().numpy()
+            src = w.src1[0, :n].cpu().numpy()
+            self._state_host = self._state_host[src] if len(src) else self._state_host[:0]
+            self._actions_host = np.concatenate([self._actions_host[src], np.full(w.cap - n, -1, np.int8)])
+        else:
+            self._state_host = w.obs_state()[0, :n].cpu().numpy().astype(np.float64)
+            self._state_prime_host = None
+            self._reward_host = self._done_host = None
+            self._actions_host = np.concatenate([self._host["a_action"], np.full(w.cap - n, -1, np.int8)])
+        self.agents = [AgentView(self, k) for k in range(n)]
+
+
+def host_reset(width, height, n_brains):
+    """Environment.reset's world construction with the reference's exact global-np.random draw order
+    (environment.py:147-154 -> _add_agent :483-484 -> Grid.set_random grid.py:69-83; _init_food :741-761)."""
+    C = width * height
+    grid = np.zeros(C, np.uint8)
+    agents = []
+
+    def set_random(kind, p):
+        empties = np.nonzero(grid == _lib.EMPTY)[0]  # row-major, like np.where on the 2-D grid
+        if len(empties) == 0:
+            return None
+        k = np.random.randint(0, len(empties))
+        if np.random.random() < p:
+            grid[empties[k]] = kind
+            return int(empties[k])
+        return None
+
+    for g in range(n_brains):
+        cell = set_random(_lib.AGENT, 1.0)
+        if cell is not None:
+            agents.append((cell, g))
+    for kind, prob in ((_lib.FOOD, 0.1), (_lib.POISON, 0.05)):
+        for _ in range(C):
+            if np.random.random() < prob:
+                set_random(kind, 1)
+    set_random(_lib.SUPER_FOOD, 1)
+    order = sorted(range(len(agents)), key=lambda a: agents[a][0])
+    n = len(agents)
+    cells = np.array([agents[a][0] for a in order], dtype=np.int64).reshape(n)
+    snap = {"cell_type": grid,
+            "i": (cells // width).astype(np.uint8), "j": (cells % width).astype(np.uint8),
+            "health": np.full(n, 200, np.int32), "age": np.zeros(n, np.int32), "max_age": np.full(n, 50, np.int32),
+            "gene": np.array([agents[a][1] for a in order], np.int32).reshape(n),
+            "brain": np.array([agents[a][1] for a in order], np.int32).reshape(n),
+            "uid": np.array(order, np.int32).reshape(n), "flags": np.zeros(n, np.uint8), "action": np.full(n, -1, np.int8),
+            "fitness": np.zeros(n, np.float64), "max_gene": n_brains, "next_uid": n,
+            "best_uid": np.full(_lib.N_BEST, -1, np.int32), "best_fit": np.zeros(_lib.N_BEST), "best_brain": np.zeros(_lib.N_BEST, np.int32)}
+    return snap
