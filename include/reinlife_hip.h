@@ -166,6 +166,10 @@ int rl_policy_forward(int kind, const float* packed, const float* obs, int64_t n
  *           call and owned by this handle afterwards (it carries double-buffered counters between calls)
  *   tape_actions: optional [R][cap] recorded actions (parity mode) that override the selected ones */
 size_t rl_policy_work_bytes(const rl_world* h);
+/* optional: hand the work buffer to the handle so that rl_tick / rl_update / rl_reset_synthetic / rl_refill also emit
+ * the per-brain row lists rl_policy_act needs (saves its bucket launch).  All launches of a handle must be issued in
+ * stream order.  rl_bind_state (call it again after rewriting state buffers yourself) invalidates the lists. */
+int rl_bind_policy_work(rl_world* h, void* work);
 int rl_policy_act(rl_world* h, const rl_brain* brains, int n_brains, const float* obs, int8_t* actions, float* out_q,
                   void* work, void* stream);
 

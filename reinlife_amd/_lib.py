@@ -73,6 +73,7 @@ ABI = [
     ("rl_policy_pack_weights", C.c_int, [C.c_int, _P, _P]),
     ("rl_policy_forward", C.c_int, [C.c_int, _P, _P, C.c_int64, _P, _P]),
     ("rl_policy_work_bytes", C.c_size_t, [_P]),
+    ("rl_bind_policy_work", C.c_int, [_P, _P]),
     ("rl_policy_act", C.c_int, [_P, C.POINTER(Brain), C.c_int, _P, _P, _P, _P, _P]),
     ("rl_philox", None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                          C.POINTER(C.c_uint32 * 4)]),

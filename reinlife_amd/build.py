@@ -6,7 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libreinlife_hip.so")
+PROFILE = bool(os.environ.get("RL_PHASE_PROFILE"))  # tuning build with in-kernel phase stamps
+LIB_PATH = os.path.join(LIB_DIR, "libreinlife_hip_prof.so" if PROFILE else "libreinlife_hip.so")
 SOURCES = ["rl_world.hip", "rl_policy.hip", "rl_capi.hip"]
 HEADERS = ["rl_common.h", os.path.join("..", "..", "include", "reinlife_hip.h")]
 # -ffp-contract=off: the world kernels' float64 reward / fitness arithmetic must round exactly like the CPU path
@@ -27,10 +28,10 @@ def build(force=False, verbose=False):
     objs = []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        obj = os.path.join(LIB_DIR, src.replace(".hip", "_prof.o" if PROFILE else ".o"))
         objs.append(obj)
         if force or _stale(obj, [sp] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", sp, "-o", obj]
+            cmd = [hipcc] + FLAGS + (["-DRL_PHASE_PROFILE"] if PROFILE else []) + ["-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -10,11 +10,11 @@
 // implemented in rl_world.hip / rl_policy.hip
 size_t rl_world_smem_bytes(int cpad, int cap, int hash);
 int rl_world_block();
-int rl_world_launch_step(const rl_world*, const int8_t*, const rl_tape*, const rl_step_out*, hipStream_t);
-int rl_world_launch_update(const rl_world*, const rl_tape*, const rl_update_out*, hipStream_t);
-int rl_world_launch_tick(const rl_world*, const int8_t*, const rl_tape*, const rl_step_out*, const rl_update_out*, int, int, int32_t*, hipStream_t);
+int rl_world_launch_step(rl_world*, const int8_t*, const rl_tape*, const rl_step_out*, hipStream_t);
+int rl_world_launch_update(rl_world*, const rl_tape*, const rl_update_out*, hipStream_t);
+int rl_world_launch_tick(rl_world*, const int8_t*, const rl_tape*, const rl_step_out*, const rl_update_out*, int, int, int32_t*, hipStream_t);
 int rl_world_launch_observe(const rl_world*, float*, hipStream_t);
-int rl_world_launch_reset(const rl_world*, int, int, float*, int32_t*, hipStream_t);
+int rl_world_launch_reset(rl_world*, int, int, float*, int32_t*, hipStream_t);
 int64_t rl_policy_n_params_impl(int);
 int64_t rl_policy_packed_floats_impl(int);
 int rl_policy_pack_impl(int, const float*, float*);
@@ -83,6 +83,7 @@ int rl_bind_state(rl_world* h, const rl_state* s)
         if (!p[i]) { rl_set_error("rl_bind_state: state pointer #%zu is null", i); return RL_E_INVALID; }
     h->st = *s;
     h->bound = 1;
+    h->lists_valid = 0;  // the caller may have rewritten the state
     return RL_OK;
 }
 
@@ -97,6 +98,13 @@ int rl_bind_phase_profile(rl_world* h, long long* device_stamps, int world)
 {
     if (!h) { rl_set_error("rl_bind_phase_profile: null handle"); return RL_E_INVALID; }
     h->prof = device_stamps; h->prof_world = world;
+    return RL_OK;
+}
+
+int rl_bind_policy_work(rl_world* h, void* work)
+{
+    if (!h) { rl_set_error("rl_bind_policy_work: null handle"); return RL_E_INVALID; }
+    h->work = work; h->lists_valid = 0;
     return RL_OK;
 }
 

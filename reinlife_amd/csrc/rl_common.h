@@ -15,7 +15,10 @@ struct rl_world {
     int hash_size;       // power of two >= 2*slot_cap
     size_t smem_bytes;   // dynamic LDS of the world kernels
     int block;           // threads per world workgroup
-    int act_parity;      // which half of the policy work counters the next rl_policy_act uses
+    void* work;          // bound policy work buffer (device) or null
+    int lists_valid;     // the row lists in `work` describe the current world state
+    int lists_parity;    // which counter half holds them
+    int parity_next;     // half the next list producer (world launch or k_bucket) writes
     long long* prof;     // optional device int64[32]: shader-clock stamps of one world's phases
     int prof_world;
 };

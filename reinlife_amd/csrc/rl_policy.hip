@@ -537,16 +537,22 @@ int rl_policy_act_impl(rl_world* h, const rl_brain* brains, int n_brains, const 
                        void* work, hipStream_t st)
 {
     const int R = h->cfg.n_worlds, cap = h->cfg.slot_cap;
-    const int parity = h->act_parity & 1;
-    h->act_parity ^= 1;
-    int* counts = (int*)work + 64 * parity;
-    int* counts_zero = (int*)work + 64 * (parity ^ 1);
-    int* lists = (int*)work + 128;
     const int64_t stride = (int64_t)R * cap;
-    hipLaunchKernelGGL(k_bucket, dim3((R + 3) / 4), dim3(256), 0, st, h->st.n_agents, h->st.a_brain, R, cap, n_brains, counts,
-                       counts_zero, lists, stride);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { rl_set_error("bucket kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
+    int* lists = (int*)work + 128;
+    int* counts;
+    if (h->lists_valid && h->work == work) {
+        counts = (int*)work + 64 * (h->lists_parity & 1);  // produced by the last world launch: no bucket kernel needed
+    } else {
+        const int cur = h->parity_next & 1;
+        h->parity_next ^= 1;
+        counts = (int*)work + 64 * cur;
+        int* counts_zero = (int*)work + 64 * (cur ^ 1);
+        hipLaunchKernelGGL(k_bucket, dim3((R + 3) / 4), dim3(256), 0, st, h->st.n_agents, h->st.a_brain, R, cap, n_brains, counts,
+                           counts_zero, lists, stride);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { rl_set_error("bucket kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
+        if (h->work == work) { h->lists_valid = 1; h->lists_parity = cur; }
+    }
     // every live agent: populations are bounded by 2*max_agents+1 (environment.py:501 snapshot rule)
     const int64_t bound = (int64_t)R * (int64_t)(2 * h->cfg.max_agents + 2 < cap ? 2 * h->cfg.max_agents + 2 : cap);
     for (int kind = RL_DQN; kind <= RL_PPO; ++kind) {

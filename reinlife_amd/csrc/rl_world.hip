@@ -47,7 +47,10 @@ struct KParams {
     int32_t* err;
     int reset_n_agents, refill_threshold;
     int32_t* refill_count;
-    int hash_agg;     // experiment switch: wave-aggregated gene hash (1) or per-agent LDS atomics (0)
+    int* lists_counts;       // optional: per-brain row-list counters of this launch's parity (policy work buffer)
+    int* lists_counts_zero;  //           the other parity, cleared by block 0 for the next producer
+    int* lists;              //           row ids (world*cap + k), [n_brains][list_stride]
+    long long list_stride;
     long long* prof;  // optional: shader-clock stamps of world prof_world's phases (debug / tuning)
     int prof_world;
 };
@@ -80,7 +83,11 @@ struct Smem {
 
 enum { AUX_VANISH = 1, AUX_PARENT = 2 };
 
+#ifdef RL_PHASE_PROFILE
 #define RL_MARK(i) do { if (p.prof && (int)blockIdx.x == p.prof_world && threadIdx.x == 0) p.prof[i] = (long long)clock64(); } while (0)
+#else
+#define RL_MARK(i) do { } while (0)
+#endif
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
@@ -143,12 +150,25 @@ __device__ inline double shfl_xor_f64(double v, int m)
     unsigned lo = __shfl_xor((unsigned)u, m), hi = __shfl_xor((unsigned)(u >> 32), m);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+// inclusive prefix sum over the 64 lanes with DPP (no LDS traffic: __shfl_up lowers to ds_bpermute, ~100 cycles each):
+// Kogge-Stone inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 carry the row totals across rows.
 __device__ inline int wave_incl_scan(int v)
 {
-    const int l = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(v, d); if (l >= d) v += t; }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);  // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);  // row_bcast:31 -> rows 2,3
     return v;
+}
+__device__ inline int read_lane(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
+__device__ inline unsigned long long read_lane_u64(unsigned long long v, int l)
+{
+    const int sl = __builtin_amdgcn_readfirstlane(l);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, sl);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), sl);
+    return ((unsigned long long)hi << 32) | lo;
 }
 __device__ inline unsigned long long lowmask(int b) { return b ? (~0ull >> (64 - b)) : 0ull; }
 
@@ -164,25 +184,32 @@ __device__ inline int neighbour_cell(int i, int j, int d, int W, int H)
 }
 
 // k-th empty cell of Grid.set_random (World/grid.py:69-83) as a select on wave 0's occupancy bitmap.
+// The per-lane inclusive prefix of empty-cell counts is computed once (DPP scan) and then maintained incrementally:
+// a placement in word L just decrements the prefix of lanes >= L.
 struct Placer {
     unsigned long long word;  // lane l: cells 64l..64l+63, bit set = not empty
+    int incl;                 // empty cells in words 0..l
     int n_empty;
 };
+__device__ inline void placer_init(Placer& P, unsigned long long word)
+{
+    P.word = word;
+    P.incl = wave_incl_scan(__popcll(~word));
+    P.n_empty = __builtin_amdgcn_readlane(P.incl, 63);
+}
 __device__ inline int placer_take(Placer& P, int k)
 {
     const int l = lane_id();
-    const int zeros = __popcll(~P.word);
-    const int incl = wave_incl_scan(zeros);
-    const unsigned long long m = __ballot(k < incl);
+    const unsigned long long m = __ballot(k < P.incl);
     const int L = __ffsll((long long)m) - 1;
-    const int excl = __shfl(incl - zeros, L);
-    const unsigned long long z = ~shfl_u64(P.word, L);
-    const int kk = k - excl;
+    const unsigned long long z = ~read_lane_u64(P.word, L);
+    const int kk = k - (read_lane(P.incl, L) - __popcll(z));
     const bool set = (z >> l) & 1ull;
     const int rank = __popcll(z & lowmask(l));
     const unsigned long long hit = __ballot(set && rank == kk);
     const int bit = __ffsll((long long)hit) - 1;
     if (l == L) P.word |= 1ull << bit;
+    if (l >= L) P.incl -= 1;
     P.n_empty -= 1;
     return L * 64 + bit;
 }
@@ -200,48 +227,61 @@ template <int T>
 __device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
 {
     const int tid = threadIdx.x;
+    const size_t b = (size_t)w * p.cap;
+    const uint8_t* gt = p.st.cell_type + (size_t)w * p.C;
+    // ---- issue EVERY global load first (one HBM round trip): nothing below depends on n_agents until the LDS writes.
+    // Slot `tid` of the agent arrays is read unconditionally (inside the allocation; ignored beyond n_agents).
     n0 = p.st.n_agents[w];
-    if (p.prof && (int)blockIdx.x == p.prof_world && threadIdx.x == 0 && n0 >= 0) p.prof[23] = (long long)clock64();
-    // per-world scalars and this tick's actions are fetched now so that no later phase waits on HBM latency
     int sc_val = 0;
     if (tid == S_TICK) sc_val = p.st.tick[w];
     else if (tid == S_EPOCH) sc_val = p.st.epoch[w];
     else if (tid == S_NEXT_UID) sc_val = p.st.next_uid[w];
     else if (tid == S_MAX_GENE) sc_val = p.st.max_gene[w];
-    const uint8_t* gt = p.st.cell_type + (size_t)w * p.C;
-    for (int c = tid; c < p.Cp; c += T) {
-        s.type[c] = c < p.C ? gt[c] : kPadCell;
-        s.occ[c] = -1;
-        ((unsigned*)s.foodv)[c] = 0u;
-    }
-    for (int i = tid; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
-    if (tid < S_COUNT) s.scal[tid] = sc_val;
-    if (tid < RL_MAX_BRAINS) s.present[tid] = 0;
+    int bu = -1, bb = 0; double bf = 0.0;
     if (tid < RL_N_BEST) {
-        s.best_uid[tid] = p.st.best_uid[(size_t)w * RL_N_BEST + tid];
-        s.best_fit[tid] = p.st.best_fit[(size_t)w * RL_N_BEST + tid];
-        s.best_brain[tid] = p.st.best_brain[(size_t)w * RL_N_BEST + tid];
+        bu = p.st.best_uid[(size_t)w * RL_N_BEST + tid];
+        bf = p.st.best_fit[(size_t)w * RL_N_BEST + tid];
+        bb = p.st.best_brain[(size_t)w * RL_N_BEST + tid];
     }
-    const size_t b = (size_t)w * p.cap;
-    for (int a = tid; a < n0; a += T) {
-        s.pos[a] = (unsigned short)(p.st.a_i[b + a] | (p.st.a_j[b + a] << 8));
-        s.health[a] = p.st.a_health[b + a];
-        s.age[a] = p.st.a_age[b + a];
-        s.max_age[a] = p.st.a_max_age[b + a];
-        s.gene[a] = p.st.a_gene[b + a];
-        s.brain[a] = p.st.a_brain[b + a];
-        s.uid[a] = p.st.a_uid[b + a];
-        s.flags[a] = p.st.a_flags[b + a];
-        s.action[a] = p.actions ? p.actions[b + a] : p.st.a_action[b + a];
-        s.fitness[a] = p.st.a_fitness[b + a];
-        s.aux[a] = 0;
-        s.src[a] = (short)a;
-        s.order[a] = (short)a;
-        s.newidx[a] = (short)a;
+    uint8_t ty[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int c = tid + u * T; ty[u] = c < p.C ? gt[c] : kPadCell; }
+    const bool ha = tid < p.cap;
+    uint8_t r_i = 0, r_j = 0, r_fl = 0; signed char r_act = -1;
+    int r_h = 0, r_age = 0, r_ma = 0, r_g = 0, r_b = 0, r_u = 0; double r_f = 0.0;
+    if (ha) {
+        r_i = p.st.a_i[b + tid]; r_j = p.st.a_j[b + tid];
+        r_h = p.st.a_health[b + tid]; r_age = p.st.a_age[b + tid]; r_ma = p.st.a_max_age[b + tid];
+        r_g = p.st.a_gene[b + tid]; r_b = p.st.a_brain[b + tid]; r_u = p.st.a_uid[b + tid];
+        r_fl = p.st.a_flags[b + tid];
+        r_act = p.actions ? p.actions[b + tid] : p.st.a_action[b + tid];
+        r_f = p.st.a_fitness[b + tid];
     }
+    // ---- LDS initialisation that needs no loaded value
+    for (int c = tid; c < p.Cp; c += T) { s.occ[c] = -1; ((unsigned*)s.foodv)[c] = 0u; }
+    for (int i = tid; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
+    if (tid < RL_MAX_BRAINS) s.present[tid] = 0;
+    // ---- consume the loads
+    if (tid < S_COUNT) s.scal[tid] = tid == S_NSLOTS ? n0 : sc_val;
+    if (tid < RL_N_BEST) { s.best_uid[tid] = bu; s.best_fit[tid] = bf; s.best_brain[tid] = bb; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int c = tid + u * T; if (c < p.Cp) s.type[c] = ty[u]; }
+    for (int c = tid + 4 * T; c < p.Cp; c += T) s.type[c] = c < p.C ? gt[c] : kPadCell;
+    auto put = [&](int a, int pi, int pj, int h, int age, int ma, int g, int br, int u, int fl, int act, double f) {
+        s.pos[a] = (unsigned short)(pi | (pj << 8));
+        s.health[a] = h; s.age[a] = age; s.max_age[a] = ma; s.gene[a] = g; s.brain[a] = br; s.uid[a] = u;
+        s.flags[a] = (uint8_t)fl; s.action[a] = (signed char)act; s.fitness[a] = f;
+        s.aux[a] = 0; s.src[a] = (short)a; s.order[a] = (short)a; s.newidx[a] = (short)a;
+    };
+    if (ha && tid < n0) put(tid, r_i, r_j, r_h, r_age, r_ma, r_g, r_b, r_u, r_fl, r_act, r_f);
+    for (int a = tid + T; a < n0; a += T)
+        put(a, p.st.a_i[b + a], p.st.a_j[b + a], p.st.a_health[b + a], p.st.a_age[b + a], p.st.a_max_age[b + a], p.st.a_gene[b + a],
+            p.st.a_brain[b + a], p.st.a_uid[b + a], p.st.a_flags[b + a], p.actions ? p.actions[b + a] : p.st.a_action[b + a],
+            p.st.a_fitness[b + a]);
+    RL_MARK(33);
     __syncthreads();
+    RL_MARK(34);
     for (int a = tid; a < n0; a += T) s.occ[(s.pos[a] & 255) * p.W + (s.pos[a] >> 8)] = (short)a;
-    if (tid == 0) s.scal[S_NSLOTS] = n0;
     __syncthreads();
 }
 
@@ -251,39 +291,27 @@ __device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
 // Must be called by all 64 lanes of the wave; `active` lanes contribute.
 __device__ inline void hash_insert_wave(Smem& s, int mask, bool active, int a, int gene, unsigned add, int agg)
 {
-    if (!agg) {
-        if (active) {
-            unsigned h = ((unsigned)gene * 2654435761u) & (unsigned)mask;
-            for (;;) {
-                const int old = atomicCAS(&s.hkey[h], -1, gene);
-                if (old == -1 || old == gene) break;
-                h = (h + 1) & (unsigned)mask;
-            }
-            if (add) atomicAdd(&s.hcnt[h], add);
-            s.hslot[a] = (unsigned short)h;
-        }
-        return;
-    }
+    (void)agg;
     unsigned long long pending = __ballot(active);
     while (pending) {
-        const int leader = __ffsll((long long)pending) - 1;
-        const int g = __shfl(gene, leader);
+        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)pending) - 1);
+        const int g = __builtin_amdgcn_readlane(gene, leader);
         const bool mine = active && gene == g;
         const unsigned long long m = __ballot(mine);
-        unsigned lo = mine ? (add & 0xFFFFu) : 0u, hi = mine ? (add >> 16) : 0u;
-#pragma unroll
-        for (int d = 32; d; d >>= 1) { lo += __shfl_xor(lo, d); hi += __shfl_xor(hi, d); }
-        unsigned h = 0;
+        const unsigned lo = (unsigned)__popcll(__ballot(mine && (add & 1u)));
+        const unsigned hi = (unsigned)__popcll(__ballot(mine && (add >> 16)));
+        int h = 0;
         if (lane_id() == leader) {
-            h = ((unsigned)g * 2654435761u) & (unsigned)mask;
+            unsigned hh = ((unsigned)g * 2654435761u) & (unsigned)mask;
             for (;;) {
-                const int old = atomicCAS(&s.hkey[h], -1, g);
+                const int old = atomicCAS(&s.hkey[hh], -1, g);
                 if (old == -1 || old == g) break;
-                h = (h + 1) & (unsigned)mask;
+                hh = (hh + 1) & (unsigned)mask;
             }
-            if (lo | hi) atomicAdd(&s.hcnt[h], lo | (hi << 16));
+            if (lo | hi) atomicAdd(&s.hcnt[hh], lo | (hi << 16));
+            h = (int)hh;
         }
-        h = __shfl(h, leader);
+        h = __builtin_amdgcn_readlane(h, leader);
         if (mine) s.hslot[a] = (unsigned short)h;
         pending &= ~m;
     }
@@ -461,15 +489,17 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
         s.aux[a] = ax;
     }
     __syncthreads();
+    RL_MARK(35);
     for (int a = tid; a < n0; a += T) {
         const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
         if (s.tgt[a] != cx) { s.type[cx] = RL_EMPTY; s.occ[cx] = -1; }
     }
     __syncthreads();
+    RL_MARK(36);
     int alive_local = 0;
     const int n0p = (n0 + 63) & ~63;  // whole waves take part in the gene aggregation
     for (int a = tid; a < n0p; a += T) {
-        if (a >= n0) { hash_insert_wave(s, p.hash_mask, false, 0, 0, 0u, p.hash_agg); continue; }
+        if (a >= n0) { hash_insert_wave(s, p.hash_mask, false, 0, 0, 0u, 0); continue; }
         const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
         const int tg = s.tgt[a];
         if (tg != cx) {
@@ -484,8 +514,9 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
         const unsigned alive = (fl & RL_F_DEAD) ? 0u : 1u;
         const unsigned ongrid = (s.aux[a] & AUX_VANISH) ? 0u : 1u;
         alive_local += (int)alive;
-        hash_insert_wave(s, p.hash_mask, true, a, s.gene[a], alive | (ongrid << 16), p.hash_agg);
+        hash_insert_wave(s, p.hash_mask, true, a, s.gene[a], alive | (ongrid << 16), 0);
     }
+    RL_MARK(37);
     if (alive_local) atomicAdd(&s.scal[S_ALIVE], alive_local);
     __syncthreads();
     RL_MARK(4);
@@ -520,11 +551,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
     RL_MARK(6);
     if (tid < 64) {
         Placer P;
-        P.word = tid < p.nW ? s.occbits[tid] : ~0ull;
-        int ne = __popcll(~P.word);
-#pragma unroll
-        for (int m = 32; m; m >>= 1) ne += __shfl_xor(ne, m);
-        P.n_empty = ne;
+        placer_init(P, tid < p.nW ? s.occbits[tid] : ~0ull);
         const bool tape = p.tape.food_k != nullptr;
         unsigned xk = 0; double u = 2.0;
         if (tid < RL_FOOD_TRIES) {
@@ -621,6 +648,7 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
         if (tid == 63) s.scal[S_NELIG] = incl;
     }
     __syncthreads();
+    RL_MARK(38);
     // pass B: gate draw by eligible rank; parents bitmap
     for (int k = tid; k < n1p; k += T) {
         bool par = false;
@@ -636,6 +664,7 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
         if (lane_id() == 0) s.occbits[k >> 6] = m;  // parents bitmap; occbits is rebuilt below before its next use
     }
     __syncthreads();
+    RL_MARK(39);
     // compact parents in list order
     if (tid < 64) {
         const int nw = n1p >> 6;
@@ -649,6 +678,7 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
         if ((s.occbits[k >> 6] >> (k & 63)) & 1ull)
             s.plist[s.wordbase[k >> 6] + __popcll(s.occbits[k >> 6] & lowmask(k & 63))] = s.order[k];
     __syncthreads();
+    RL_MARK(40);
     // occupancy bitmap for placements (dead agents still occupy their cells here)
     for (int c = tid; c < p.Cp; c += T) {
         const unsigned long long m = __ballot(s.type[c] != RL_EMPTY);
@@ -659,11 +689,7 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
     // ---- births: _reproduce placements then _produce (environment.py:502-547), sequential on wave 0 ------------------
     if (tid < 64) {
         Placer P;
-        P.word = tid < p.nW ? s.occbits[tid] : ~0ull;
-        int ne = __popcll(~P.word);
-#pragma unroll
-        for (int m = 32; m; m >>= 1) ne += __shfl_xor(ne, m);
-        P.n_empty = ne;
+        placer_init(P, tid < p.nW ? s.occbits[tid] : ~0ull);
         const int npar = s.scal[S_NPARENTS];
         int next_uid = s.scal[S_NEXT_UID];
         int max_gene = s.scal[S_MAX_GENE];
@@ -691,6 +717,7 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
             if (tid == 0) init_newborn(s, slots, cell, p.W, s.gene[par], p.static_families ? s.gene[par] : s.brain[par], next_uid);
             ++slots; ++next_uid;
         }
+        RL_MARK(41);
         // _produce
         if (room) {
             double u; unsigned x1 = 0;
@@ -730,6 +757,7 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
                 }
             }
         }
+        RL_MARK(42);
         if (tid == 0) { s.scal[S_NSLOTS] = slots; p.st.next_uid[w] = next_uid; p.st.max_gene[w] = max_gene; }
     }
     __syncthreads();
@@ -756,9 +784,39 @@ __device__ void rebuild_gene_counts(const KParams& p, Smem& s, int n)
     for (int k = threadIdx.x; k < np2; k += T) {
         const bool act = k < n;
         const int a = act ? s.order[k] : 0;
-        hash_insert_wave(s, p.hash_mask, act, a, act ? s.gene[a] : 0, 1u << 16, p.hash_agg);
+        hash_insert_wave(s, p.hash_mask, act, a, act ? s.gene[a] : 0, 1u << 16, 0);
     }
     __syncthreads();
+}
+
+// Per-brain row lists for the policy kernel (replaces a separate bucket launch): wave 0 counts the world's agents per
+// brain with ballots (lane b keeps brain b's count), ONE atomic instruction reserves the ranges of all brains, a second
+// pass scatters the row ids.  `brain_of(k)` reads the brain of list entry k (from LDS or from HBM).
+template <typename F>
+__device__ inline void emit_brain_lists_wave0(const KParams& p, int w, int n, F brain_of)
+{
+    const int lane = lane_id();
+    if (blockIdx.x == 0) p.lists_counts_zero[lane] = 0;
+    int cnt = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int k = base + lane;
+        const int b = k < n ? brain_of(k) : -1;
+        for (int bb = 0; bb < p.n_brains; ++bb) {
+            const int c = __popcll(__ballot(b == bb));
+            if (lane == bb) cnt += c;
+        }
+    }
+    int pos = (lane < p.n_brains && cnt) ? atomicAdd(&p.lists_counts[lane], cnt) : 0;
+    for (int base = 0; base < n; base += 64) {
+        const int k = base + lane;
+        const int b = k < n ? brain_of(k) : -1;
+        for (int bb = 0; bb < p.n_brains; ++bb) {
+            const unsigned long long m = __ballot(b == bb);
+            const int start = read_lane(pos, bb);
+            if (b == bb) p.lists[bb * p.list_stride + start + __popcll(m & lowmask(lane))] = w * p.cap + k;
+            if (lane == bb) pos += __popcll(m);
+        }
+    }
 }
 
 template <int T>
@@ -868,6 +926,7 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
             for (int k = tid; k < n2; k += T) p.uo.src[b + k] = s.src[s.order[k]];
         }
         store_world<T>(p, s, w, n2);
+        if (p.lists && tid < 64) emit_brain_lists_wave0(p, w, n2, [&](int k) { return s.brain[s.order[k]]; });
         RL_MARK(22);
         if (tid == 0 && !refill) p.st.tick[w] = s.scal[S_TICK] + 1;
     }
@@ -986,7 +1045,13 @@ __global__ __launch_bounds__(T) void k_reset(const KParams p)
     Smem s;
     carve(s, smem_raw, p.Cp, p.cap, p.hash_size);
     const int w = blockIdx.x;
-    if (p.refill_threshold >= 0 && p.st.n_agents[w] >= p.refill_threshold) return;  // uniform per workgroup
+    if (p.refill_threshold >= 0 && p.st.n_agents[w] >= p.refill_threshold) {  // uniform per workgroup: nothing to re-generate
+        if (p.lists && threadIdx.x < 64) {
+            const int32_t* br = p.st.a_brain + (size_t)w * p.cap;
+            emit_brain_lists_wave0(p, w, p.st.n_agents[w], [&](int k) { return br[k]; });
+        }
+        return;
+    }
     const uint32_t epoch = (uint32_t)p.st.epoch[w] + (p.refill_threshold >= 0 ? 1u : 0u);
     const int n = reset_world_lds<T>(p, s, w, epoch);
     rebuild_gene_counts<T>(p, s, n);
@@ -994,6 +1059,7 @@ __global__ __launch_bounds__(T) void k_reset(const KParams p)
     __syncthreads();
     write_observations<T>(p, s, w, n, p.obs_only);
     store_world<T>(p, s, w, n);
+    if (p.lists && threadIdx.x < 64) emit_brain_lists_wave0(p, w, n, [&](int k) { return s.brain[s.order[k]]; });
 }
 
 // 1024 threads per world when there are few worlds (latency-bound: one world per CU), 256 when there are many
@@ -1018,8 +1084,7 @@ KParams make_params(const rl_world* h)
     p.err = h->err_flag;
     p.refill_threshold = -1;
     p.prof = h->prof; p.prof_world = h->prof_world;
-    static const int agg = getenv("RL_HASH_AGG") ? atoi(getenv("RL_HASH_AGG")) : 0;
-    p.hash_agg = agg;
+    p.lists = nullptr; p.lists_counts = nullptr; p.lists_counts_zero = nullptr; p.list_stride = 0;
     return p;
 }
 
@@ -1034,6 +1099,23 @@ int launch_world(const rl_world* h, const KParams& p, hipStream_t stream)
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rl_set_error("world kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
     return RL_OK;
+}
+
+// A launch that leaves every world policy-ready (tick / update / reset / refill) also produces the per-brain row lists
+// when a policy work buffer is bound; any other launch invalidates them.
+void set_list_production(rl_world* h, KParams& p, bool produces)
+{
+    if (produces && h->work) {
+        const int cur = h->parity_next & 1;
+        int* counts = (int*)h->work;
+        p.lists_counts = counts + 64 * cur;
+        p.lists_counts_zero = counts + 64 * (cur ^ 1);
+        p.lists = counts + 128;
+        p.list_stride = (long long)h->cfg.n_worlds * h->cfg.slot_cap;
+        h->lists_valid = 1; h->lists_parity = cur; h->parity_next ^= 1;
+    } else {
+        h->lists_valid = 0;
+    }
 }
 
 }  // namespace
@@ -1065,25 +1147,28 @@ int rl_world_prepare_bytes(size_t bytes)
     return RL_OK;
 }
 
-int rl_world_launch_step(const rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_step_out* out, hipStream_t st)
+int rl_world_launch_step(rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_step_out* out, hipStream_t st)
 {
     KParams p = make_params(h);
+    set_list_production(h, p, false);
     p.actions = actions;
     if (tape) p.tape = *tape;
     if (out) p.so = *out;
     return launch_world<MODE_STEP>(h, p, st);
 }
-int rl_world_launch_update(const rl_world* h, const rl_tape* tape, const rl_update_out* out, hipStream_t st)
+int rl_world_launch_update(rl_world* h, const rl_tape* tape, const rl_update_out* out, hipStream_t st)
 {
     KParams p = make_params(h);
+    set_list_production(h, p, true);
     if (tape) p.tape = *tape;
     if (out) p.uo = *out;
     return launch_world<MODE_UPDATE>(h, p, st);
 }
-int rl_world_launch_tick(const rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_step_out* so,
+int rl_world_launch_tick(rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_step_out* so,
                          const rl_update_out* uo, int refill_threshold, int refill_n_agents, int32_t* refill_count, hipStream_t st)
 {
     KParams p = make_params(h);
+    set_list_production(h, p, true);
     p.actions = actions;
     if (tape) p.tape = *tape;
     if (so) p.so = *so;
@@ -1097,9 +1182,10 @@ int rl_world_launch_observe(const rl_world* h, float* obs, hipStream_t st)
     p.obs_only = obs;
     return launch_world<MODE_OBSERVE>(h, p, st);
 }
-int rl_world_launch_reset(const rl_world* h, int n_agents, int threshold, float* obs, int32_t* refill_count, hipStream_t st)
+int rl_world_launch_reset(rl_world* h, int n_agents, int threshold, float* obs, int32_t* refill_count, hipStream_t st)
 {
     KParams p = make_params(h);
+    set_list_production(h, p, true);
     p.reset_n_agents = n_agents; p.refill_threshold = threshold; p.obs_only = obs; p.refill_count = refill_count;
     if (int rc = rl_world_prepare_bytes(h->smem_bytes)) return rc;
     if (pick_block(h) == 1024) hipLaunchKernelGGL((k_reset<1024>), dim3(h->cfg.n_worlds), dim3(1024), h->smem_bytes, st, p);

@@ -110,6 +110,7 @@ class DeviceWorlds:
         for key in ("best_uid", "best_fit", "best_brain"):
             if key in snap:
                 self.s[key][w] = torch.as_tensor(np.asarray(snap[key]), device=dev).to(self.s[key].dtype)
+        _lib.check(self.lib.rl_bind_state(self.handle, C.byref(self._state)), "rl_bind_state")  # state rewritten by the host
 
     def world(self, w):
         n = int(self.s["n_agents"][w].item())
@@ -194,6 +195,7 @@ class DeviceWorlds:
         if self._work is None:
             nbytes = self.lib.rl_policy_work_bytes(self.handle)
             self._work = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=self.device)
+            _lib.check(self.lib.rl_bind_policy_work(self.handle, _ptr(self._work)), "rl_bind_policy_work")
 
     def act(self, want_q=False):
         """Agent.get_action for every agent of every world: obs_state -> self.actions (and self.out_q)."""

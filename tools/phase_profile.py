@@ -8,6 +8,8 @@ import ctypes as C
 import os
 import sys
 
+os.environ["RL_PHASE_PROFILE"] = "1"  # selects libreinlife_hip_prof.so (built with -DRL_PHASE_PROFILE)
+
 import numpy as np
 import torch
 
@@ -18,7 +20,7 @@ from reinlife_amd import _lib  # noqa: E402
 NAMES = {1: "load", 2: "act+attack+prep", 3: "conflict loop", 4: "eat/move/death/hash", 5: "rewards", 6: "food count+bitmap",
          8: "food placement", 9: "order1", 10: "planes1", 11: "obs1 write", 12: "step outputs", 13: "best agents",
          14: "repro gates+parents+bitmap", 15: "births+produce", 17: "remove dead", 18: "order2", 19: "refill (if any)",
-         20: "genes+planes2", 21: "obs2 write", 22: "store", 100: "  (of load: kernarg + n_agents fetch)"}
+         20: "genes+planes2", 21: "obs2 write", 22: "store", 32: "load: grid+hash clear issued", 33: "load: agent arrays issued", 34: "load: barrier", 35: "eat+vanish flags (+bar)", 36: "clear old cells (+bar)", 37: "place+death+hash", 38: "elig bitmap+scan", 39: "gates+parents bitmap", 40: "parents compaction", 41: "birth placements", 42: "produce", 100: "  (of load: kernarg + n_agents fetch)"}
 
 
 def main():
@@ -28,10 +30,11 @@ def main():
     a = ap.parse_args()
     args = argparse.Namespace(worlds=a.worlds, workload="c4", seed=1)
     dw = bench.make_worlds(args, 0, "cuda:0")
-    stamps = torch.zeros(32, dtype=torch.int64, device="cuda:0")
+    stamps = torch.zeros(64, dtype=torch.int64, device="cuda:0")
     lib = _lib.lib()
     acc = {}
     totals = []
+    order = []
     for t in range(a.ticks):
         world = t % a.worlds
         _lib.check(lib.rl_bind_phase_profile(dw.handle, C.c_void_p(stamps.data_ptr()), world), "bind")
@@ -45,15 +48,18 @@ def main():
         if st[23]:
             acc.setdefault(100, []).append(int(st[23] - st[0]))
             st[23] = 0
-        keys = sorted(k for k in range(32) if st[k] != 0)
+        order = [0, 32, 33, 34, 1, 2, 3, 35, 36, 37, 4, 5, 6, 8, 9, 10, 11, 12, 13, 38, 39, 40, 14, 41, 42, 15, 17, 18, 19, 20, 21, 22]
+        keys = [k for k in order if st[k] != 0]
         for prev, k in zip(keys[:-1], keys[1:]):
             acc.setdefault(k, []).append(int(st[k] - st[prev]))
         totals.append(int(st[keys[-1]] - st[keys[0]]))
     print("phase cycles (shader clock, thread 0 of the sampled world), mean over %d ticks" % len(totals))
     tot = np.mean(totals)
-    for k in sorted(acc):
+    for k in [k for k in order if k in acc] + [100]:
+        if k not in acc:
+            continue
         m = np.mean(acc[k])
-        print("  %2d %-30s %9.0f  %5.1f%%" % (k, NAMES.get(k, "?"), m, 100 * m / tot))
+        print("  %2d %-34s %9.0f  %5.1f%%" % (k, NAMES.get(k, "?"), m, 100 * m / tot))
     print("  total %.0f cycles" % tot)
 
 
