@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from reinlife_amd import _lib  # noqa: E402
+from reinlife_amd.distributed import reduce_counters  # noqa: E402
 from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights  # noqa: E402
 
 # Algorithmic HBM bytes per agent-step (DESIGN.md "Roofline accounting"; SURVEY.md 8d gives 2,082 B for the whole
@@ -144,9 +145,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world_size > 1:
+    if world_size > 1 or os.environ.get("RL_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world_size))
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPUs visible" % (local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = "cuda:%d" % local_rank
@@ -162,6 +168,11 @@ def main():
     dw.refill_count.zero_()
     if dist is not None:
         dist.barrier()
+        try:  # RCCL prints its banner through C stdio: push it out now so that the JSON line is the LAST line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -173,13 +184,10 @@ def main():
     elapsed = time.perf_counter() - t0
     dw.check_error_flag()
 
+    # the only collective of the job: one RCCL all-reduce of the metric counters over xGMI (reinlife_amd/distributed.py)
     stats = torch.tensor([float(dw.acted_total.item()), float(dw.refill_count.item())], dtype=torch.float64, device=device)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if dist is not None:  # the only collective of the job: RCCL all-reduce of the counters over xGMI
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    stats, elapsed = reduce_counters(stats, elapsed, dist)
     total_agent_steps, refills = stats.tolist()
-    elapsed = float(tmax.item())
 
     # ---- per-kernel durations with HIP events on the launch stream (untimed extra steps) ------------------------------
     roofline, extra = None, {}
@@ -243,8 +251,10 @@ def main():
             "cpu_baseline": cpu,
         }
         out.update(extra)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 
