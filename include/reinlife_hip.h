@@ -39,6 +39,7 @@ extern "C" {
 #define RL_FOOD_TRIES 7  /* 3 Food + 3 Poison + 1 SuperFood set_random calls, environment.py:763-776 */
 #define RL_MAX_CELLS 4096
 #define RL_MAX_BRAINS 64
+#define RL_TRK_VARS 7
 
 typedef enum {
     RL_OK = 0, RL_E_INVALID = -1, RL_E_UNBOUND = -2, RL_E_LAUNCH = -3, RL_E_UNSUPPORTED = -4
@@ -109,6 +110,13 @@ typedef struct {
     int16_t* src;       /* [R][cap]  index of the agent in the PRE-step list (its state/action live there) */
     float* obs;         /* [R][cap][153] Agent.state_prime */
     unsigned long long* acted_total; /* [1] running sum of n_acted over worlds and calls (metric counter) */
+    /* Tracker accumulators (Helpers/tracker.py:178-282), all or none.  G = n_brains (static families) or 1 groups x
+     * RL_TRK_VARS variables [size, age, fitness, best age, attacks, kills, intra kills] over the post-step env.agents;
+     * a per-tick value enters sum/cnt iff it is > -1, exactly like Tracker._aggregate. */
+    double* trk_tick;   /* [R][G][7] this tick's values (-1 = no result) */
+    double* trk_sum;    /* [R][G][7] running sum of valid values (caller zeroes it at interval boundaries) */
+    int32_t* trk_cnt;   /* [R][G][7] number of valid ticks */
+    double* trk_pop;    /* [R][3]    "Avg Number of Populations": this tick, running sum, running count */
 } rl_step_out;
 
 /* Outputs of an update, indexed in the POST-update env.agents order. */

@@ -43,7 +43,10 @@ def record_trace(env, ticks, actions_fn, cap):
         d["init_" + k] = snap0[k]
     d["init_obs"] = (np.stack([a.state for a in agents0]) if agents0 else np.zeros((0, 153))).astype(np.float32)
 
+    env._ref_tracker = rh.make_ref_tracker(env, 10 ** 9)
     recs = [rh.record_tick(env, actions_fn, cap, n_epi=t) for t in range(ticks)]
+    d["trk_tick"] = np.stack([r["post_step"]["trk_tick"] for r in recs])   # [T][G][7] Tracker per-tick values
+    d["trk_pop"] = np.array([r["post_step"]["trk_pop"] for r in recs])
     maxn = max([1] + [max(len(r["actions"]), len(r["post_step"]["i"]), len(r["post_update"]["i"])) for r in recs])
     d["n0"] = np.array([len(r["actions"]) for r in recs], np.int32)
     d["actions"] = np.stack([_pad(r["actions"], cap) for r in recs])

@@ -57,7 +57,7 @@ class Tape(C.Structure):
 
 class StepOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("n_acted", "reward", "done", "src", "obs", "l0_health", "l0_flags",
-                                          "l0_reward", "l0_i", "l0_j")]
+                                          "l0_reward", "l0_i", "l0_j", "trk_tick", "trk_sum", "trk_cnt", "trk_pop")]
 
 
 class UpdateOut(C.Structure):
@@ -114,9 +114,14 @@ class OracleWorlds:
         self.l0_j = np.zeros((self.R, self.cap), np.uint8)
         self.src2 = np.full((self.R, self.cap), -1, np.int16)
         self.obs2 = np.zeros((self.R, self.cap, OBS_DIM), np.float32)
+        self.G = n_brains if static_families else 1
+        self.trk_tick = np.zeros((self.R, self.G, 7), np.float64)
+        self.trk_sum = np.zeros((self.R, self.G, 7), np.float64)
+        self.trk_cnt = np.zeros((self.R, self.G, 7), np.int32)
+        self.trk_pop = np.zeros((self.R, 3), np.float64)
         self._step_out = StepOut(*[_ptr(a) for a in (self.n_acted, self.reward, self.done, self.src1, self.obs1,
                                                      self.l0_health, self.l0_flags, self.l0_reward, self.l0_i,
-                                                     self.l0_j)])
+                                                     self.l0_j, self.trk_tick, self.trk_sum, self.trk_cnt, self.trk_pop)])
         self._upd_out = UpdateOut(_ptr(self.src2), _ptr(self.obs2))
 
     # -- state I/O ----------------------------------------------------------------------------------------------

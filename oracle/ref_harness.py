@@ -349,6 +349,24 @@ def extract_tape(entries, slot_cap, best_agents):
             "n_repro_draws": _np.int32(n_repro), "n_births_drawn": _np.int32(n_birth)}
 
 
+TRACKER_VARS = ("Avg Population Size", "Avg Population Age", "Avg Population Fitness", "Best Population Age",
+                "Avg Number of Attacks", "Avg Number of Kills", "Avg Number of Intra Kills")
+
+
+def make_ref_tracker(env, update_interval):
+    """A real reference Tracker (ReinLife/Helpers/tracker.py) configured like Environment.__init__ does (env.py:125-131)."""
+    from ReinLife.Helpers.tracker import Tracker
+    return Tracker(update_interval=update_interval, interactive=False, print_results=False, google_colab=False,
+                   nr_genes=len(env.brains), static_families=env.static_families, brains=env.brains)
+
+
+def tracker_tick_values(tracker):
+    """Last appended per-tick values as [G][7] + number of populations."""
+    G = tracker.nr_genes
+    vals = _np.array([[tracker.track_results[v][g][-1] for v in TRACKER_VARS] for g in range(G)], dtype=_np.float64)
+    return vals, float(tracker.track_results["Avg Number of Populations"][-1])
+
+
 def record_tick(env, actions_fn, slot_cap, n_epi=0):
     """Run one trainer-loop tick (trainer.py:85-99 minus learn/render) on the real reference, recording everything.
 
@@ -378,6 +396,12 @@ def record_tick(env, actions_fn, slot_cap, n_epi=0):
     post_step["l0_i"] = _np.array([a.i for a in l0], dtype=_np.uint8)
     post_step["l0_j"] = _np.array([a.j for a in l0], dtype=_np.uint8)
     post_step["l0_fitness"] = _np.array([float(a.fitness) for a in l0], dtype=_np.float64)
+
+    trk = getattr(env, "_ref_tracker", None)
+    if trk is not None:  # environment.py:206-207 calls tracker.update_results(self.agents, n_epi) first thing in update_env
+        trk._track_results(env.agents)
+        post_step["trk_tick"], pops = tracker_tick_values(trk)
+        post_step["trk_pop"] = _np.float64(pops)
 
     LOG.clear()
     env.update_env(n_epi)

@@ -195,6 +195,72 @@ static void observe(const world_t* wd, const int* list, int n, float* obs)
 }
 
 /* ------------------------------------------------------------------------------------------------------------ */
+/* numpy's pairwise float64 summation (np.add.reduce on a contiguous array, numpy/core/src/umath/loops_utils.h
+ * pairwise_sum: < 8 sequential; <= 128 eight accumulators + tail; else split at a multiple of 8) -- np.mean of the
+ * tracker's per-agent lists is sum/len with exactly this sum. */
+static double np_pairwise_sum(const double* a, int n)
+{
+    if (n < 8) { double r = 0.0; for (int i = 0; i < n; ++i) r += a[i]; return r; }
+    if (n <= 128) {
+        double r[8]; int i;
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        for (i = 8; i < n - (n % 8); i += 8) for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int n2 = n / 2; n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+/* Tracker._track_results over the post-step env.agents (tracker.py:178-266; called from update_env, environment.py:206) */
+static void track_world(const world_t* wd, const int* l1, int n1, rlo_step_out* out)
+{
+    const rlo_config* cfg = wd->cfg;
+    const int G = cfg->static_families ? cfg->n_brains : 1;
+    double* tick = out->trk_tick + (size_t)wd->w * G * RLO_TRK_VARS;
+    double* sum = out->trk_sum + (size_t)wd->w * G * RLO_TRK_VARS;
+    int32_t* cnt = out->trk_cnt + (size_t)wd->w * G * RLO_TRK_VARS;
+    double* pop = out->trk_pop + (size_t)wd->w * 3;
+    double* rew = (double*)malloc(sizeof(double) * (size_t)(n1 + 1));
+    int n_distinct = 0;
+    for (int k = 0; k < n1; ++k) {
+        int seen = 0;
+        for (int m = 0; m < k; ++m) seen |= (wd->ag[l1[m]].gene == wd->ag[l1[k]].gene);
+        n_distinct += !seen;
+    }
+    for (int g = 0; g < G; ++g) {
+        double v[RLO_TRK_VARS];
+        int m = 0, sum_age = 0, best = 0, attacks = 0, kills = 0;
+        for (int k = 0; k < n1; ++k) {
+            const agent_t* a = &wd->ag[l1[k]];
+            if (cfg->static_families && a->gene != g) continue;
+            rew[m++] = a->reward; sum_age += a->age; best = a->age > best ? a->age : best;
+            attacks += a->action >= 4; kills += a->killed;
+        }
+        if (n1 == 0) { for (int i = 0; i < RLO_TRK_VARS; ++i) v[i] = -1.0; }  /* tracker.py:191-196 */
+        else {
+            if (m == 0) { v[0] = v[1] = v[2] = v[3] = v[4] = -1.0; }
+            else {
+                v[0] = cfg->static_families ? (double)m : (double)n1 / (double)n_distinct; /* np.mean(counts of unique genes) */
+                v[1] = (double)sum_age / (double)m;
+                v[2] = np_pairwise_sum(rew, m) / (double)m;  /* mean of agent.reward, not fitness (tracker.py:221) */
+                v[3] = (double)best;
+                v[4] = (double)attacks / (double)m;
+            }
+            v[5] = (double)kills;                 /* appended even for an empty group (tracker.py:255) */
+            v[6] = kills != 0 ? 1.0 : 0.0;        /* intra_killed is computed exactly like killed (tracker.py:252-260) */
+        }
+        for (int i = 0; i < RLO_TRK_VARS; ++i) {
+            tick[g * RLO_TRK_VARS + i] = v[i];
+            if (v[i] > -1.0) { sum[g * RLO_TRK_VARS + i] += v[i]; cnt[g * RLO_TRK_VARS + i] += 1; }  /* _aggregate, tracker.py:279-282 */
+        }
+    }
+    pop[0] = n1 == 0 ? -1.0 : (double)n_distinct;
+    if (pop[0] > -1.0) { pop[1] += pop[0]; pop[2] += 1.0; }
+    free(rew);
+}
+
 /* Environment.step (environment.py:160-186) */
 static int step_world(world_t* wd, rlo_state* st, const int8_t* actions, rlo_step_out* out)
 {
@@ -303,6 +369,7 @@ static int step_world(world_t* wd, rlo_state* st, const int8_t* actions, rlo_ste
             if (out->done) out->done[b + k] = (uint8_t)ag[l1[k]].done;
             if (out->src) out->src[b + k] = (int16_t)l1[k];
         }
+        if (out->trk_tick) track_world(wd, l1, n1, out);
         for (int k = 0; k < n0; ++k) {
             if (out->l0_health) out->l0_health[b + k] = ag[k].health;
             if (out->l0_flags) out->l0_flags[b + k] = (uint8_t)flags_of(&ag[k]);

@@ -8,7 +8,7 @@ Agent.get_action for every agent of every world on the GPU.
 reset() of a single world replays Environment.reset's exact np.random draw order on the host (environment.py:133-158,
 741-761; grid.py:69-83), so the same numpy seed gives the same initial world as the reference.  step()/update_env()
 draw from the in-kernel Philox streams (the reference's MT19937 interleaving is reproduced exactly only through recorded
-tapes, see tests/ and DESIGN.md section 4).  Tracker / Saver / renderer are out of scope.
+tapes, see tests/ and DESIGN.md section 4).  The Tracker's statistics are accumulated in the step kernel (Helpers/tracker.py); Saver / renderer are out of scope.
 """
 import numpy as np
 import torch
@@ -106,11 +106,14 @@ class Environment:
         self.n_worlds = n_worlds
         self.device = device
         self.best_agents = []
-        self.tracker = None  # out of scope
         self.worlds = DeviceWorlds(n_worlds=n_worlds, width=width, height=height, max_agents=max_agents,
                                    n_brains=len(brains), static_families=static_families,
                                    limit_reproduction=limit_reproduction, incentivize_killing=incentivize_killing, seed=seed,
                                    device=device)
+        # results tracker (environment.py:125-131); numeric part only, fed by the step kernel
+        from ..Helpers.tracker import Tracker
+        self.tracker = Tracker(update_interval=update_interval, interactive=False, print_results=print_results, nr_genes=len(brains),
+                               static_families=static_families, brains=brains, worlds=self.worlds if training else None)
         self.agents = []
         self._host = None
         self._state_prime_host = self._reward_host = self._done_host = None
@@ -155,7 +158,9 @@ class Environment:
         self._refresh(after="step")
 
     def update_env(self, n_epi=0):
-        """environment.py:188-215 (Tracker excluded)"""
+        """environment.py:188-215"""
+        if self.training:
+            self.tracker.update_results(self.agents, n_epi)
         self.worlds.update()
         self._refresh(after="update")
 

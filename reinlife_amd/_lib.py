@@ -27,7 +27,8 @@ STATE_FIELDS = ("cell_type", "n_agents", "a_i", "a_j", "a_health", "a_age", "a_m
                 "a_flags", "a_action", "a_fitness", "max_gene", "next_uid", "tick", "epoch", "best_uid", "best_fit",
                 "best_brain")
 TAPE_FIELDS = ("food_k", "food_u", "repro_u", "birth_k", "produce_u", "produce_choice")
-STEP_OUT_FIELDS = ("n_acted", "reward", "done", "src", "obs", "acted_total")
+STEP_OUT_FIELDS = ("n_acted", "reward", "done", "src", "obs", "acted_total", "trk_tick", "trk_sum", "trk_cnt", "trk_pop")
+TRK_VARS = 7
 UPDATE_OUT_FIELDS = ("src", "obs")
 
 

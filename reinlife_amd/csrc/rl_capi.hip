@@ -143,9 +143,18 @@ static int check_tape(const rl_tape* t, const char* fn)
     return RL_OK;
 }
 
+static int check_step_out(const rl_step_out* o, const char* fn)
+{
+    if (!o) return RL_OK;
+    const int n = (o->trk_tick != nullptr) + (o->trk_sum != nullptr) + (o->trk_cnt != nullptr) + (o->trk_pop != nullptr);
+    if (n != 0 && n != 4) { rl_set_error("%s: the four tracker pointers must be given together", fn); return RL_E_INVALID; }
+    return RL_OK;
+}
+
 int rl_step(rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_step_out* out, void* stream)
 {
     RL_CHECK_BOUND("rl_step")
+    if (int rc = check_step_out(out, "rl_step")) return rc;
     if (!actions) { rl_set_error("rl_step: null actions"); return RL_E_INVALID; }
     if (int rc = check_tape(tape, "rl_step")) return rc;
     return rl_world_launch_step(h, actions, tape, out, (hipStream_t)stream);
@@ -163,6 +172,7 @@ int rl_tick(rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_st
     RL_CHECK_BOUND("rl_tick")
     if (!actions) { rl_set_error("rl_tick: null actions"); return RL_E_INVALID; }
     if (int rc = check_tape(tape, "rl_tick")) return rc;
+    if (int rc = check_step_out(sout, "rl_tick")) return rc;
     return rl_world_launch_tick(h, actions, tape, sout, uout, -1, 0, nullptr, (hipStream_t)stream);
 }
 
@@ -172,6 +182,7 @@ int rl_tick_refill(rl_world* h, const int8_t* actions, const rl_step_out* sout, 
     RL_CHECK_BOUND("rl_tick_refill")
     if (!actions) { rl_set_error("rl_tick_refill: null actions"); return RL_E_INVALID; }
     if (threshold < 0 || n_agents < 0 || n_agents > h->cfg.slot_cap || n_agents > h->cells) { rl_set_error("rl_tick_refill: bad arguments"); return RL_E_INVALID; }
+    if (int rc = check_step_out(sout, "rl_tick_refill")) return rc;
     return rl_world_launch_tick(h, actions, nullptr, sout, uout, threshold, n_agents, refill_count, (hipStream_t)stream);
 }
 

@@ -74,7 +74,7 @@ struct Smem {
     short* occ;                   // [Cp]
     uint8_t* type;                // [Cp]
     int *health, *age, *max_age, *gene, *brain, *uid;  // [cap]
-    double *fitness, *reward;                          // [cap]
+    double *fitness, *reward, *trk_rew;                // [cap]
     unsigned short *pos, *tgt, *hslot;                 // [cap]
     short *newidx, *order, *src, *plist;               // [cap]
     uint8_t *flags, *aux;                              // [cap]
@@ -101,6 +101,7 @@ __host__ __device__ inline size_t carve(Smem& s, char* base, int Cp, int cap, in
     CARVE(wred_f, double, 16)
     CARVE(fitness, double, cap)
     CARVE(reward, double, cap)
+    CARVE(trk_rew, double, cap)
     CARVE(wordbase, int, 64)
     CARVE(scal, int, S_COUNT)
     CARVE(best_uid, int, 16)
@@ -789,6 +790,127 @@ __device__ void rebuild_gene_counts(const KParams& p, Smem& s, int n)
     __syncthreads();
 }
 
+// inclusive running maximum over the 64 lanes (values >= 0), same DPP pattern as wave_incl_scan
+__device__ inline int wave_incl_scan_max(int v)
+{
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true));
+    return v;
+}
+
+// numpy's pairwise float64 summation (np.add.reduce; what np.mean of the Tracker's per-agent lists does): blocks of
+// <= 128 use eight accumulators + a sequential tail, longer arrays split at a multiple of 8.
+__device__ __noinline__ double np_pairwise_block(const double* a, int n)
+{
+    if (n < 8) { double r = 0.0; for (int i = 0; i < n; ++i) r += a[i]; return r; }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) { r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3]; r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7]; }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+template <int DEPTH>
+__device__ inline double np_pairwise_sum(const double* a, int n)
+{
+    if (n <= 128) return np_pairwise_block(a, n);
+    int n2 = n / 2; n2 -= n2 % 8;
+    return np_pairwise_sum<DEPTH - 1>(a, n2) + np_pairwise_sum<DEPTH - 1>(a + n2, n - n2);
+}
+template <>
+__device__ inline double np_pairwise_sum<0>(const double* a, int n) { return np_pairwise_block(a, n); }
+
+// Tracker._track_results over the post-step list (Helpers/tracker.py:178-266), executed by wave 0 without atomics:
+// lane g owns group g (gene g with static families, everybody otherwise).
+__device__ void track_world_wave0(const KParams& p, Smem& s, int w, int n1)
+{
+    const int lane = lane_id();
+    const int G = p.static_families ? p.n_brains : 1;
+    int m = 0, sum_age = 0, best = 0, attacks = 0, kills = 0;  // lane g: statistics of group g
+    // pass 1: per-group integer statistics, one ballot-aggregated step per distinct group of every 64-agent chunk
+    for (int base = 0; base < n1; base += 64) {
+        const int k = base + lane;
+        const bool act = k < n1;
+        const int a = act ? s.order[k] : 0;
+        const int g = act ? (p.static_families ? s.gene[a] : 0) : -1;
+        const bool in_range = act && g >= 0 && g < G;
+        unsigned long long pending = __ballot(in_range);
+        while (pending) {
+            const int gg = read_lane(g, __ffsll((long long)pending) - 1);
+            const bool mine = in_range && g == gg;
+            const unsigned long long mm = __ballot(mine);
+            const int age_sum = read_lane(wave_incl_scan(mine ? s.age[a] : 0), 63);
+            const int age_max = read_lane(wave_incl_scan_max(mine ? s.age[a] : 0), 63);
+            const int att = __popcll(__ballot(mine && s.action[a] >= 4));
+            const int kil = __popcll(__ballot(mine && (s.flags[a] & RL_F_KILLED)));
+            if (lane == gg) { m += __popcll(mm); sum_age += age_sum; best = max(best, age_max); attacks += att; kills += kil; }
+            pending &= ~mm;
+        }
+    }
+    // pass 2: rewards of each group contiguous and in list order (np.mean's summation order depends on it)
+    const int incl = wave_incl_scan(lane < G ? m : 0);
+    const int off = incl - (lane < G ? m : 0);
+    int run = off;
+    for (int base = 0; base < n1; base += 64) {
+        const int k = base + lane;
+        const bool act = k < n1;
+        const int a = act ? s.order[k] : 0;
+        const int g = act ? (p.static_families ? s.gene[a] : 0) : -1;
+        const bool in_range = act && g >= 0 && g < G;
+        unsigned long long pending = __ballot(in_range);
+        while (pending) {
+            const int gg = read_lane(g, __ffsll((long long)pending) - 1);
+            const bool mine = in_range && g == gg;
+            const unsigned long long mm = __ballot(mine);
+            const int start = read_lane(run, gg);
+            if (mine) s.trk_rew[start + __popcll(mm & lowmask(lane))] = s.reward[a];
+            if (lane == gg) run += __popcll(mm);
+            pending &= ~mm;
+        }
+    }
+    // number of populations = distinct genes on the grid
+    int n_distinct;
+    if (p.static_families) n_distinct = __popcll(__ballot(lane < G && m > 0));
+    else {
+        int c = 0;
+        for (int i = lane; i < p.hash_size; i += 64) c += (s.hkey[i] != -1 && (s.hcnt[i] >> 16) != 0);
+        n_distinct = read_lane(wave_incl_scan(c), 63);
+    }
+    if (lane < G) {
+        double v[RL_TRK_VARS];
+        if (n1 == 0) {
+#pragma unroll
+            for (int i = 0; i < RL_TRK_VARS; ++i) v[i] = -1.0;
+        } else {
+            if (m == 0) { v[0] = v[1] = v[2] = v[3] = v[4] = -1.0; }
+            else {
+                v[0] = p.static_families ? (double)m : (double)n1 / (double)n_distinct;
+                v[1] = (double)sum_age / (double)m;
+                v[2] = np_pairwise_sum<5>(s.trk_rew + off, m) / (double)m;
+                v[3] = (double)best;
+                v[4] = (double)attacks / (double)m;
+            }
+            v[5] = (double)kills;
+            v[6] = kills != 0 ? 1.0 : 0.0;
+        }
+        const size_t o = ((size_t)w * G + lane) * RL_TRK_VARS;
+#pragma unroll
+        for (int i = 0; i < RL_TRK_VARS; ++i) {
+            p.so.trk_tick[o + i] = v[i];
+            if (v[i] > -1.0) { p.so.trk_sum[o + i] += v[i]; p.so.trk_cnt[o + i] += 1; }
+        }
+    }
+    if (lane == 0) {
+        const double pv = n1 == 0 ? -1.0 : (double)n_distinct;
+        p.so.trk_pop[(size_t)w * 3] = pv;
+        if (pv > -1.0) { p.so.trk_pop[(size_t)w * 3 + 1] += pv; p.so.trk_pop[(size_t)w * 3 + 2] += 1.0; }
+    }
+}
+
 // Per-brain row lists for the policy kernel (replaces a separate bucket launch): wave 0 counts the world's agents per
 // brain with ballots (lane b keeps brain b's count), ONE atomic instruction reserves the ranges of all brains, a second
 // pass scatters the row ids.  `brain_of(k)` reads the brain of list entry k (from LDS or from HBM).
@@ -895,6 +1017,7 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
         }
         if (tid == 0 && p.so.n_acted) p.so.n_acted[w] = n0;
         if (tid == 0 && p.so.acted_total && n0) atomicAdd(p.so.acted_total, (unsigned long long)n0);
+        if (p.so.trk_tick && tid < 64) track_world_wave0(p, s, w, n1);
         n_cur = n1;
         if (MODE == MODE_STEP) { store_world<T>(p, s, w, n1); return; }
         __syncthreads();

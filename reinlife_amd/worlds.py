@@ -60,11 +60,17 @@ class DeviceWorlds:
             self.err = torch.zeros(4, dtype=torch.int32, device=self.device)
             self.refill_count = torch.zeros(1, dtype=torch.int32, device=self.device)
             self.acted_total = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self.G = n_brains if static_families else 1
+            self.trk_tick = torch.zeros((R, self.G, _lib.TRK_VARS), dtype=torch.float64, device=self.device)
+            self.trk_sum = torch.zeros((R, self.G, _lib.TRK_VARS), dtype=torch.float64, device=self.device)
+            self.trk_cnt = torch.zeros((R, self.G, _lib.TRK_VARS), dtype=torch.int32, device=self.device)
+            self.trk_pop = torch.zeros((R, 3), dtype=torch.float64, device=self.device)
         self._state = _lib.State(*[_ptr(self.s[n]) for n in _lib.STATE_FIELDS])
         _lib.check(self.lib.rl_bind_state(self.handle, C.byref(self._state)), "rl_bind_state")
         _lib.check(self.lib.rl_bind_error_flag(self.handle, _ptr(self.err)), "rl_bind_error_flag")
         self._step_out = _lib.StepOut(_ptr(self.n_acted), _ptr(self.reward), _ptr(self.done), _ptr(self.src1),
-                                      _ptr(self.obs1), _ptr(self.acted_total))
+                                      _ptr(self.obs1), _ptr(self.acted_total), None, None, None, None)
+        self.tracking = False
         self._upd_out = _lib.UpdateOut(_ptr(self.src2), _ptr(self.obs2))
         self._work = None
         self._brains = None
@@ -141,6 +147,16 @@ class DeviceWorlds:
         return _lib.Tape(*[_ptr(self._tape_keep[n]) for n in _lib.TAPE_FIELDS])
 
     # -- the path -----------------------------------------------------------------------------------------------
+    def enable_tracking(self, on=True):
+        """Accumulate the Tracker statistics (Helpers/tracker.py) inside step()/tick() launches."""
+        self.tracking = bool(on)
+        t = (self.trk_tick, self.trk_sum, self.trk_cnt, self.trk_pop) if on else (None, None, None, None)
+        self._step_out = _lib.StepOut(_ptr(self.n_acted), _ptr(self.reward), _ptr(self.done), _ptr(self.src1), _ptr(self.obs1),
+                                      _ptr(self.acted_total), *[_ptr(x) for x in t])
+
+    def reset_tracking(self):
+        self.trk_sum.zero_(); self.trk_cnt.zero_(); self.trk_pop[:, 1:].zero_()
+
     def set_actions(self, actions):
         a = torch.as_tensor(np.ascontiguousarray(actions, dtype=np.int8) if not torch.is_tensor(actions) else actions,
                             device=self.device).to(torch.int8)

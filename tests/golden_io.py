@@ -87,6 +87,9 @@ def replay_trace(make_backend, path, n_worlds=1, obs_exact=True):
             _eq(tag, "done", np.asarray(be.done)[w, :n1], tr["step_done"][t][:n1])
             _cmp_obs(tag + " reward", np.asarray(be.reward)[w, :n1], tr["step_reward"][t][:n1], obs_exact)
             _cmp_obs(tag + " obs", np.asarray(be.obs1)[w, :n1], tr["step_obs"][t][:n1], obs_exact)
+            if "trk_tick" in tr.files and getattr(be, "trk_tick", None) is not None:  # Tracker per-tick values, bit-exact
+                _eq(tag, "trk_tick", np.asarray(be.trk_tick)[w], tr["trk_tick"][t])
+                _eq(tag, "trk_pop", float(np.asarray(be.trk_pop)[w, 0]), float(tr["trk_pop"][t]))
         be.update(tape)
         n2 = int(tr["upd_n"][t])
         for w in range(n_worlds):

@@ -8,6 +8,7 @@ class HipBackend:
     def __init__(self, n_worlds, fused=False, **cfg):
         self.dw = DeviceWorlds(n_worlds=n_worlds, seed=cfg.pop("seed", 0), world_base=cfg.pop("world_base", 0), **cfg)
         self.cap = self.dw.cap
+        self.dw.enable_tracking(True)
         self.fused = fused
 
     def load_world(self, w, snap):
@@ -41,3 +42,7 @@ class HipBackend:
     src2 = property(lambda s: s.dw.src2.cpu().numpy())
     obs1 = property(lambda s: s.dw.obs_state_prime().cpu().numpy())
     obs2 = property(lambda s: s.dw.obs_state().cpu().numpy())
+    trk_tick = property(lambda s: s.dw.trk_tick.cpu().numpy())
+    trk_pop = property(lambda s: s.dw.trk_pop.cpu().numpy())
+    trk_sum = property(lambda s: s.dw.trk_sum.cpu().numpy())
+    trk_cnt = property(lambda s: s.dw.trk_cnt.cpu().numpy())

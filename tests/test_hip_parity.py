@@ -76,6 +76,8 @@ def test_hip_matches_oracle_free_running_philox(static, limit, fused):
         _compare_rows(hb.done, ow.done, ow_n1, "tick %d done" % t)
         _compare_rows(hb.src1, ow.src1, ow_n1, "tick %d src1" % t)
         _compare_rows(hb.obs1, ow.obs1, ow_n1, "tick %d obs1" % t)
+        assert np.array_equal(hb.trk_tick, ow.trk_tick) and np.array_equal(hb.trk_pop, ow.trk_pop), "tick %d tracker" % t
+        assert np.array_equal(hb.trk_sum, ow.trk_sum) and np.array_equal(hb.trk_cnt, ow.trk_cnt), "tick %d tracker sums" % t
         if not fused:
             ow.update()
             hb.update()
