@@ -117,6 +117,10 @@ typedef struct {
     double* trk_sum;    /* [R][G][7] running sum of valid values (caller zeroes it at interval boundaries) */
     int32_t* trk_cnt;   /* [R][G][7] number of valid ticks */
     double* trk_pop;    /* [R][3]    "Avg Number of Populations": this tick, running sum, running count */
+    /* post-step list attributes that a fused rl_tick would otherwise lose (needed by rl_capture_transitions) */
+    int32_t* n_post;    /* [R]       length of the post-step list (len(env.agents) after step()) */
+    int32_t* age;       /* [R][cap]  Agent.age after the step */
+    int32_t* brain;     /* [R][cap]  brains-list index of the agent's brain */
 } rl_step_out;
 
 /* Outputs of an update, indexed in the POST-update env.agents order. */
@@ -124,6 +128,22 @@ typedef struct {
     int16_t* src;       /* [R][cap]  index in the post-step list, -1 for newborns */
     float* obs;         /* [R][cap][153] Agent.state (what the policy reads next tick) */
 } rl_update_out;
+
+/* Replay ring of ONE brain (caller-owned device buffers): what Agent.learn hands to brain.learn each tick
+ * (World/entities.py:194-208 -> DQN.py:73-84, D3QN.py:94-96, PERD3QN.py:91-92,117-125, PPO.py:69-76), stored in
+ * slot (count % capacity) in Agent.learn call order per world. */
+typedef struct {
+    float* state;                /* [capacity][153] observation the policy read before the step */
+    float* state_prime;          /* [capacity][153] post-step observation */
+    int8_t* action;              /* [capacity] */
+    float* reward;               /* [capacity] raw Agent.reward (the PPO brain divides by 100 itself, PPO.py:71) */
+    uint8_t* done;               /* [capacity] */
+    float* prob;                 /* [capacity] policy output of the taken action (PPO: prob[action]) if outputs are given */
+    int32_t* age;                /* [capacity] post-step age (train_freq logic, e.g. DQN.py:86) */
+    unsigned long long* count;   /* [1] transitions stored so far */
+    int64_t capacity;
+} rl_replay;
+#define RL_MAX_CAPTURE_BRAINS 16
 
 /* One brain of the brains list. */
 typedef struct {
@@ -157,6 +177,16 @@ int rl_tick(rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_st
 /* rl_tick (Philox draws) followed, in the same launch, by rl_refill(threshold, n_agents) of every world */
 int rl_tick_refill(rl_world* h, const int8_t* actions, const rl_step_out* sout, const rl_update_out* uout,
                    int threshold, int n_agents, int32_t* refill_count, void* stream);
+
+/* trainer.py:95-96 for every world: agents of the post-step list with age > 1 append (state, action, reward,
+ * state_prime, done[, prob]) to the replay ring of their brain.
+ *   state      [R][cap][153] the observation buffer the policy read for this tick (keep it: ping-pong rl_update_out.obs)
+ *   actions    [R][cap]      this tick's actions (pre-step list order)
+ *   policy_out [R][cap][8]   optional rl_policy_act outputs of this tick
+ *   step       outputs of this tick's rl_step / rl_tick; needs reward, done, src, obs, n_post, age, brain
+ *   replays    host array of n_brains rings (n_brains <= RL_MAX_CAPTURE_BRAINS) */
+int rl_capture_transitions(rl_world* h, const float* state, const int8_t* actions, const float* policy_out,
+                           const rl_step_out* step, const rl_replay* replays, int n_brains, void* stream);
 
 /* ---- policy ------------------------------------------------------------------------------------------------- */
 /* number of floats in a brain's state dict (flat, registration order) / in its packed MFMA layout */

@@ -62,6 +62,8 @@ def record_trace(env, ticks, actions_fn, cap):
         d[phase + "_max_gene"] = np.array([r[key]["max_gene"] for r in recs], np.int32)
         for k in ("best_uid", "best_fit", "best_brain"):
             d[phase + "_" + k] = np.stack([r[key][k] for r in recs])
+    d["step_learn_n"] = np.array([len(r["post_step"]["learn_k"]) for r in recs], np.int32)
+    d["step_learn_k"] = np.stack([_pad(r["post_step"]["learn_k"], maxn, -1) for r in recs])  # Agent.learn call order
     d["step_reward"] = np.stack([_pad(r["post_step"]["reward"].astype(np.float32), maxn) for r in recs])
     d["step_done"] = np.stack([_pad(r["post_step"]["done"], maxn) for r in recs])
     for k in ("l0_health", "l0_flags", "l0_reward", "l0_i", "l0_j"):

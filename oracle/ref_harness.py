@@ -204,10 +204,15 @@ def seed_all(seed):
 
 
 class NullBrain:
-    """A brain that is never asked for an action (the harness writes agent.action itself)."""
+    """A brain that is never asked for an action (the harness writes agent.action itself); learn() records what
+    Agent.learn hands over (entities.py:194-208)."""
 
     def __init__(self, method="DQN"):
         self.method = method
+        self.learned = []
+
+    def learn(self, **kwargs):
+        self.learned.append(kwargs)
 
     def apply_gaussian_noise(self):
         pass
@@ -396,6 +401,22 @@ def record_tick(env, actions_fn, slot_cap, n_epi=0):
     post_step["l0_i"] = _np.array([a.i for a in l0], dtype=_np.uint8)
     post_step["l0_j"] = _np.array([a.j for a in l0], dtype=_np.uint8)
     post_step["l0_fitness"] = _np.array([float(a.fitness) for a in l0], dtype=_np.float64)
+
+    # trainer.py:95-96: every agent of the post-step list is asked to learn; Agent.learn filters age > 1
+    for b in env.brains:
+        if hasattr(b, "learned"):
+            del b.learned[:]
+    order = []
+    orig_learn = {}
+    for k, a in enumerate(l1):
+        before = {id(b): len(getattr(b, "learned", ())) for b in [a.brain]}
+        a.learn(n_epi=n_epi) if a.brain.method not in ("DQN", "PPO", "A2C", "PERDQN") else a.learn()
+        if hasattr(a.brain, "learned") and len(a.brain.learned) > before[id(a.brain)]:
+            kw = a.brain.learned[-1]
+            assert kw["state"] is a.state and kw["state_prime"] is a.state_prime and kw["action"] == a.action
+            assert kw["reward"] == a.reward and kw["done"] == a.done and kw["age"] == a.age and kw["dead"] == a.dead
+            order.append(k)
+    post_step["learn_k"] = _np.array(order, dtype=_np.int16)  # post-step list indices handed to brain.learn, in call order
 
     trk = getattr(env, "_ref_tracker", None)
     if trk is not None:  # environment.py:206-207 calls tracker.update_results(self.agents, n_epi) first thing in update_env

@@ -27,7 +27,8 @@ STATE_FIELDS = ("cell_type", "n_agents", "a_i", "a_j", "a_health", "a_age", "a_m
                 "a_flags", "a_action", "a_fitness", "max_gene", "next_uid", "tick", "epoch", "best_uid", "best_fit",
                 "best_brain")
 TAPE_FIELDS = ("food_k", "food_u", "repro_u", "birth_k", "produce_u", "produce_choice")
-STEP_OUT_FIELDS = ("n_acted", "reward", "done", "src", "obs", "acted_total", "trk_tick", "trk_sum", "trk_cnt", "trk_pop")
+STEP_OUT_FIELDS = ("n_acted", "reward", "done", "src", "obs", "acted_total", "trk_tick", "trk_sum", "trk_cnt", "trk_pop", "n_post",
+                   "age", "brain")
 TRK_VARS = 7
 UPDATE_OUT_FIELDS = ("src", "obs")
 
@@ -46,6 +47,10 @@ class StepOut(C.Structure):
 
 class UpdateOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in UPDATE_OUT_FIELDS]
+
+
+class Replay(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("state", "state_prime", "action", "reward", "done", "prob", "age", "count")] + [("capacity", C.c_int64)]
 
 
 class Brain(C.Structure):
@@ -69,6 +74,7 @@ ABI = [
     ("rl_update", C.c_int, [_P, C.POINTER(Tape), C.POINTER(UpdateOut), _P]),
     ("rl_tick", C.c_int, [_P, _P, C.POINTER(Tape), C.POINTER(StepOut), C.POINTER(UpdateOut), _P]),
     ("rl_tick_refill", C.c_int, [_P, _P, C.POINTER(StepOut), C.POINTER(UpdateOut), C.c_int, C.c_int, _P, _P]),
+    ("rl_capture_transitions", C.c_int, [_P, _P, _P, _P, C.POINTER(StepOut), C.POINTER(Replay), C.c_int, _P]),
     ("rl_policy_n_params", C.c_int64, [C.c_int]),
     ("rl_policy_packed_floats", C.c_int64, [C.c_int]),
     ("rl_policy_pack_weights", C.c_int, [C.c_int, _P, _P]),

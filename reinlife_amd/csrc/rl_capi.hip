@@ -15,6 +15,7 @@ int rl_world_launch_update(rl_world*, const rl_tape*, const rl_update_out*, hipS
 int rl_world_launch_tick(rl_world*, const int8_t*, const rl_tape*, const rl_step_out*, const rl_update_out*, int, int, int32_t*, hipStream_t);
 int rl_world_launch_observe(const rl_world*, float*, hipStream_t);
 int rl_world_launch_reset(rl_world*, int, int, float*, int32_t*, hipStream_t);
+int rl_world_launch_capture(rl_world*, const float*, const int8_t*, const float*, const rl_step_out*, const rl_replay*, int, hipStream_t);
 int64_t rl_policy_n_params_impl(int);
 int64_t rl_policy_packed_floats_impl(int);
 int rl_policy_pack_impl(int, const float*, float*);
@@ -184,6 +185,19 @@ int rl_tick_refill(rl_world* h, const int8_t* actions, const rl_step_out* sout, 
     if (threshold < 0 || n_agents < 0 || n_agents > h->cfg.slot_cap || n_agents > h->cells) { rl_set_error("rl_tick_refill: bad arguments"); return RL_E_INVALID; }
     if (int rc = check_step_out(sout, "rl_tick_refill")) return rc;
     return rl_world_launch_tick(h, actions, nullptr, sout, uout, threshold, n_agents, refill_count, (hipStream_t)stream);
+}
+
+int rl_capture_transitions(rl_world* h, const float* state, const int8_t* actions, const float* policy_out, const rl_step_out* step,
+                           const rl_replay* replays, int n_brains, void* stream)
+{
+    RL_CHECK_BOUND("rl_capture_transitions")
+    if (!state || !actions || !step || !replays) { rl_set_error("rl_capture_transitions: null argument"); return RL_E_INVALID; }
+    if (n_brains != h->cfg.n_brains || n_brains > RL_MAX_CAPTURE_BRAINS) { rl_set_error("rl_capture_transitions: n_brains %d (config %d, max %d)", n_brains, h->cfg.n_brains, RL_MAX_CAPTURE_BRAINS); return RL_E_INVALID; }
+    if (!step->reward || !step->done || !step->src || !step->obs || !step->n_post || !step->age || !step->brain) { rl_set_error("rl_capture_transitions: step outputs reward/done/src/obs/n_post/age/brain are required"); return RL_E_INVALID; }
+    if (h->cfg.slot_cap > 4096) { rl_set_error("rl_capture_transitions: slot_cap > 4096"); return RL_E_UNSUPPORTED; }
+    for (int i = 0; i < n_brains; ++i)
+        if (!replays[i].state || !replays[i].state_prime || !replays[i].action || !replays[i].reward || !replays[i].done || !replays[i].age || !replays[i].count || replays[i].capacity < 1) { rl_set_error("rl_capture_transitions: replay %d incomplete", i); return RL_E_INVALID; }
+    return rl_world_launch_capture(h, state, actions, policy_out, step, replays, n_brains, (hipStream_t)stream);
 }
 
 int64_t rl_policy_n_params(int kind) { return rl_policy_n_params_impl(kind); }

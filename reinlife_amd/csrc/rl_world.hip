@@ -1014,8 +1014,11 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
             if (p.so.reward) p.so.reward[b + k] = (float)s.reward[a];
             if (p.so.done) p.so.done[b + k] = (s.flags[a] & RL_F_DEAD) ? 1 : 0;
             if (p.so.src) p.so.src[b + k] = (short)a;
+            if (p.so.age) p.so.age[b + k] = s.age[a];
+            if (p.so.brain) p.so.brain[b + k] = s.brain[a];
         }
         if (tid == 0 && p.so.n_acted) p.so.n_acted[w] = n0;
+        if (tid == 0 && p.so.n_post) p.so.n_post[w] = n1;
         if (tid == 0 && p.so.acted_total && n0) atomicAdd(p.so.acted_total, (unsigned long long)n0);
         if (p.so.trk_tick && tid < 64) track_world_wave0(p, s, w, n1);
         n_cur = n1;
@@ -1224,6 +1227,71 @@ int launch_world(const rl_world* h, const KParams& p, hipStream_t stream)
     return RL_OK;
 }
 
+// trainer.py:95-96 + entities.py:194-208 for one world per workgroup: wave 0 reserves ring slots per brain (ballots, one
+// atomic per brain), then the four waves copy the two 153-float rows of every transition.
+struct CaptureArgs {
+    rl_replay rp[RL_MAX_CAPTURE_BRAINS];
+    int n_brains, cap;
+    const float* state; const int8_t* actions; const float* policy_out;
+    rl_step_out so;
+};
+
+__global__ __launch_bounds__(256) void k_capture(const CaptureArgs A)
+{
+    __shared__ int slot[4096];
+    __shared__ int n_tx;
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int n1 = A.so.n_post[w];
+    const size_t b = (size_t)w * A.cap;
+    if (tid < 64) {
+        int cnt = 0;
+        for (int base = 0; base < n1; base += 64) {
+            const int k = base + lane;
+            const bool act = k < n1 && A.so.age[b + k] > 1;  // Agent.learn: `if self.age > 1` (entities.py:196)
+            const int br = act ? A.so.brain[b + k] : -1;
+            for (int bb = 0; bb < A.n_brains; ++bb) { const int c = __popcll(__ballot(br == bb)); if (lane == bb) cnt += c; }
+        }
+        unsigned long long pos = 0;
+        if (lane < A.n_brains && cnt) pos = atomicAdd(A.rp[lane].count, (unsigned long long)cnt);
+        int ntx = 0;
+        for (int base = 0; base < n1; base += 64) {
+            const int k = base + lane;
+            const bool act = k < n1 && A.so.age[b + k] > 1;
+            const int br = act ? A.so.brain[b + k] : -1;
+            int myslot = -1;
+            for (int bb = 0; bb < A.n_brains; ++bb) {
+                const unsigned long long m = __ballot(br == bb);
+                const unsigned long long start = read_lane_u64(pos, bb);
+                if (br == bb) myslot = (int)((start + (unsigned long long)__popcll(m & lowmask(lane))) % (unsigned long long)A.rp[bb].capacity);
+                if (lane == bb) pos += (unsigned long long)__popcll(m);
+            }
+            if (k < n1) slot[k] = myslot;
+            ntx += __popcll(__ballot(act));
+        }
+        if (lane == 0) n_tx = ntx;
+    }
+    __syncthreads();
+    for (int k = tid >> 6; k < n1; k += 4) {  // one wave per transition
+        const int sl = slot[k];
+        if (sl < 0) continue;
+        const rl_replay R = A.rp[A.so.brain[b + k]];
+        const int src = A.so.src[b + k];
+        const float* s0 = A.state + (b + src) * RL_OBS_DIM;
+        const float* s1 = A.so.obs + (b + k) * RL_OBS_DIM;
+        float* d0 = R.state + (size_t)sl * RL_OBS_DIM;
+        float* d1 = R.state_prime + (size_t)sl * RL_OBS_DIM;
+        for (int f = lane; f < RL_OBS_DIM; f += 64) { d0[f] = s0[f]; d1[f] = s1[f]; }
+        if (lane == 0) {
+            const int a = A.actions[b + src];
+            R.action[sl] = (int8_t)a;
+            R.reward[sl] = A.so.reward[b + k];
+            R.done[sl] = A.so.done[b + k];
+            R.age[sl] = A.so.age[b + k];
+            if (A.policy_out && R.prob && a >= 0 && a < 8) R.prob[sl] = A.policy_out[(b + src) * 8 + a];
+        }
+    }
+}
+
 // A launch that leaves every world policy-ready (tick / update / reset / refill) also produces the per-brain row lists
 // when a policy work buffer is bound; any other launch invalidates them.
 void set_list_production(rl_world* h, KParams& p, bool produces)
@@ -1315,5 +1383,17 @@ int rl_world_launch_reset(rl_world* h, int n_agents, int threshold, float* obs, 
     else hipLaunchKernelGGL((k_reset<256>), dim3(h->cfg.n_worlds), dim3(256), h->smem_bytes, st, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rl_set_error("reset kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
+    return RL_OK;
+}
+
+int rl_world_launch_capture(rl_world* h, const float* state, const int8_t* actions, const float* policy_out, const rl_step_out* so,
+                            const rl_replay* replays, int n_brains, hipStream_t st)
+{
+    CaptureArgs a{};
+    for (int i = 0; i < n_brains; ++i) a.rp[i] = replays[i];
+    a.n_brains = n_brains; a.cap = h->cfg.slot_cap; a.state = state; a.actions = actions; a.policy_out = policy_out; a.so = *so;
+    hipLaunchKernelGGL(k_capture, dim3(h->cfg.n_worlds), dim3(256), 0, st, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rl_set_error("capture kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
     return RL_OK;
 }

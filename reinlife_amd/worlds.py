@@ -55,7 +55,13 @@ class DeviceWorlds:
             # +1 row of padding keeps 16-byte row reads of the policy kernel inside the allocation
             self.obs1 = torch.zeros((R * cap + 1, _lib.OBS_DIM), dtype=torch.float32, device=self.device)
             self.src2 = torch.full((R, cap), -1, dtype=torch.int16, device=self.device)
-            self.obs2 = torch.zeros((R * cap + 1, _lib.OBS_DIM), dtype=torch.float32, device=self.device)
+            # Agent.state lives in a ping-pong pair: a tick writes the new observations into the other buffer, so the
+            # observations the policy read for that tick stay available for transition capture
+            self._obs2 = [torch.zeros((R * cap + 1, _lib.OBS_DIM), dtype=torch.float32, device=self.device) for _ in range(2)]
+            self._cur = 0
+            self.n_post = torch.zeros(R, dtype=torch.int32, device=self.device)
+            self.age1 = torch.zeros((R, cap), dtype=torch.int32, device=self.device)
+            self.brain1 = torch.zeros((R, cap), dtype=torch.int32, device=self.device)
             self.out_q = torch.zeros((R, cap, 8), dtype=torch.float32, device=self.device)
             self.err = torch.zeros(4, dtype=torch.int32, device=self.device)
             self.refill_count = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -68,11 +74,11 @@ class DeviceWorlds:
         self._state = _lib.State(*[_ptr(self.s[n]) for n in _lib.STATE_FIELDS])
         _lib.check(self.lib.rl_bind_state(self.handle, C.byref(self._state)), "rl_bind_state")
         _lib.check(self.lib.rl_bind_error_flag(self.handle, _ptr(self.err)), "rl_bind_error_flag")
-        self._step_out = _lib.StepOut(_ptr(self.n_acted), _ptr(self.reward), _ptr(self.done), _ptr(self.src1),
-                                      _ptr(self.obs1), _ptr(self.acted_total), None, None, None, None)
         self.tracking = False
-        self._upd_out = _lib.UpdateOut(_ptr(self.src2), _ptr(self.obs2))
+        self.replays = None
+        self._build_step_out()
         self._work = None
+        self._ticked = False
         self._brains = None
         self._tape_keep = None
 
@@ -147,12 +153,56 @@ class DeviceWorlds:
         return _lib.Tape(*[_ptr(self._tape_keep[n]) for n in _lib.TAPE_FIELDS])
 
     # -- the path -----------------------------------------------------------------------------------------------
+    @property
+    def obs2(self):
+        return self._obs2[self._cur]
+
+    def _build_step_out(self):
+        t = (self.trk_tick, self.trk_sum, self.trk_cnt, self.trk_pop) if self.tracking else (None, None, None, None)
+        c = (self.n_post, self.age1, self.brain1) if self.replays is not None else (None, None, None)
+        self._step_out = _lib.StepOut(_ptr(self.n_acted), _ptr(self.reward), _ptr(self.done), _ptr(self.src1), _ptr(self.obs1),
+                                      _ptr(self.acted_total), *[_ptr(x) for x in t], *[_ptr(x) for x in c])
+
+    def _next_upd_out(self):
+        """update_env writes Agent.state into the OTHER buffer of the ping-pong pair, which then becomes current."""
+        self._cur ^= 1
+        return _lib.UpdateOut(_ptr(self.src2), _ptr(self._obs2[self._cur]))
+
+    def prev_state(self):
+        """[R, cap, 153] observations the policy read for the last tick (valid between a tick/update and the next one)."""
+        return self._obs2[self._cur ^ 1][: self.R * self.cap].view(self.R, self.cap, _lib.OBS_DIM)
+
     def enable_tracking(self, on=True):
         """Accumulate the Tracker statistics (Helpers/tracker.py) inside step()/tick() launches."""
         self.tracking = bool(on)
-        t = (self.trk_tick, self.trk_sum, self.trk_cnt, self.trk_pop) if on else (None, None, None, None)
-        self._step_out = _lib.StepOut(_ptr(self.n_acted), _ptr(self.reward), _ptr(self.done), _ptr(self.src1), _ptr(self.obs1),
-                                      _ptr(self.acted_total), *[_ptr(x) for x in t])
+        self._build_step_out()
+
+    def enable_capture(self, capacity, with_prob=False):
+        """Allocate one replay ring per brain (rl_replay) for capture_transitions()."""
+        self.replays = []
+        arr = (_lib.Replay * self.n_brains)()
+        for b in range(self.n_brains):
+            r = {"state": torch.zeros((capacity, _lib.OBS_DIM), dtype=torch.float32, device=self.device),
+                 "state_prime": torch.zeros((capacity, _lib.OBS_DIM), dtype=torch.float32, device=self.device),
+                 "action": torch.zeros(capacity, dtype=torch.int8, device=self.device),
+                 "reward": torch.zeros(capacity, dtype=torch.float32, device=self.device),
+                 "done": torch.zeros(capacity, dtype=torch.uint8, device=self.device),
+                 "prob": torch.zeros(capacity, dtype=torch.float32, device=self.device) if with_prob else None,
+                 "age": torch.zeros(capacity, dtype=torch.int32, device=self.device),
+                 "count": torch.zeros(1, dtype=torch.int64, device=self.device)}
+            self.replays.append(r)
+            arr[b] = _lib.Replay(*[_ptr(r[n]) for n in ("state", "state_prime", "action", "reward", "done", "prob", "age", "count")], capacity)
+        self._replay_arr = arr
+        self._build_step_out()  # the step launches now also emit n_post / age / brain of the post-step list
+
+    def capture_transitions(self, with_policy_out=False):
+        """trainer.py:95-96 on the device: call after step()/tick() of a tick whose actions are still in self.actions."""
+        if self.replays is None:
+            raise _lib.ReinLifeHipError("enable_capture() was not called")
+        _lib.check(self.lib.rl_capture_transitions(self.handle, _ptr(self._obs2[self._cur ^ 1] if self._ticked else self._obs2[self._cur]),
+                                                   _ptr(self.actions), _ptr(self.out_q) if with_policy_out else None,
+                                                   C.byref(self._step_out), self._replay_arr, self.n_brains, self._stream()),
+                   "rl_capture_transitions")
 
     def reset_tracking(self):
         self.trk_sum.zero_(); self.trk_cnt.zero_(); self.trk_pop[:, 1:].zero_()
@@ -168,22 +218,29 @@ class DeviceWorlds:
             self.set_actions(actions)
         _lib.check(self.lib.rl_step(self.handle, _ptr(self.actions), C.byref(tape) if tape is not None else None,
                                     C.byref(self._step_out), self._stream()), "rl_step")
+        self._ticked = False  # Agent.state of this tick is still the current buffer
 
     def update(self, tape=None):
-        _lib.check(self.lib.rl_update(self.handle, C.byref(tape) if tape is not None else None,
-                                      C.byref(self._upd_out), self._stream()), "rl_update")
+        uo = self._next_upd_out()
+        _lib.check(self.lib.rl_update(self.handle, C.byref(tape) if tape is not None else None, C.byref(uo), self._stream()),
+                   "rl_update")
+        self._ticked = True
 
     def tick(self, actions=None, tape=None):
         """step() + update_env() of one trainer-loop iteration in ONE kernel launch."""
         if actions is not None:
             self.set_actions(actions)
+        uo = self._next_upd_out()
         _lib.check(self.lib.rl_tick(self.handle, _ptr(self.actions), C.byref(tape) if tape is not None else None,
-                                    C.byref(self._step_out), C.byref(self._upd_out), self._stream()), "rl_tick")
+                                    C.byref(self._step_out), C.byref(uo), self._stream()), "rl_tick")
+        self._ticked = True
 
     def tick_refill(self, threshold, n_agents):
         """tick() + refill(threshold, n_agents) in one launch (Philox draws)."""
-        _lib.check(self.lib.rl_tick_refill(self.handle, _ptr(self.actions), C.byref(self._step_out), C.byref(self._upd_out),
+        uo = self._next_upd_out()
+        _lib.check(self.lib.rl_tick_refill(self.handle, _ptr(self.actions), C.byref(self._step_out), C.byref(uo),
                                            threshold, n_agents, _ptr(self.refill_count), self._stream()), "rl_tick_refill")
+        self._ticked = True
 
     def observe(self):
         _lib.check(self.lib.rl_observe(self.handle, _ptr(self.obs2), self._stream()), "rl_observe")

@@ -107,3 +107,112 @@ def test_tracker_interval_aggregates_match_reference_rule():
                 assert (np.isnan(want) and np.isnan(got)) or abs(got - want) <= 1e-12 * max(1.0, abs(want)), (k, v, g, got, want)
         pv = tr["trk_pop"][win]
         assert abs(trk.results["Avg Number of Populations"][k] - pv[pv > -1].mean()) <= 1e-12
+
+
+def _check_rings(dw, expected, seen):
+    """expected: per brain list of transition dicts appended this tick (call order); seen: counts before."""
+    for b, exp in enumerate(expected):
+        r = dw.replays[b]
+        total = int(r["count"].item())
+        assert total == seen[b] + len(exp["action"]), (b, total, seen[b], len(exp["action"]))
+        cap = r["state"].shape[0]
+        idx = (np.arange(seen[b], total) % cap)
+        for key in ("action", "reward", "done", "age"):
+            assert np.array_equal(r[key].cpu().numpy()[idx], exp[key]), (b, key)
+        assert np.array_equal(r["state"].cpu().numpy()[idx], exp["state"].astype(np.float32)), (b, "state")
+        assert np.array_equal(r["state_prime"].cpu().numpy()[idx], exp["state_prime"].astype(np.float32)), (b, "state_prime")
+        seen[b] = total
+
+
+def test_transition_capture_matches_the_reference_learn_calls():
+    """rl_capture_transitions == what trainer.py:95-96 / entities.py:194-208 hand to brain.learn, per brain, in call order
+    (golden trace: the recorded learn() call list; ring capacity small enough to wrap)."""
+    import golden_io
+    from hip_backend import HipBackend
+    from oracle import capture_np
+    path = [p for p in golden_io.trace_files("trace_") if "dense100.npz" in p][0]
+    tr = np.load(path)
+    cfg, ticks = golden_io.trace_cfg(tr)
+    hb = HipBackend(1, **cfg)
+    hb.load_world(0, golden_io.initial_snapshot(tr))
+    hb.observe()
+    hb.dw.enable_capture(capacity=700)
+    seen = [0] * cfg["n_brains"]
+    prev = tr["init_obs"]
+    for t in range(ticks):
+        n0, n1 = int(tr["n0"][t]), int(tr["step_n"][t])
+        acts = np.zeros((1, hb.cap), np.int8)
+        acts[0, :n0] = tr["actions"][t][:n0]
+        tape = hb.make_tape([golden_io.tick_tape(tr, t)])
+        hb.step(acts, tape)
+        hb.dw.capture_transitions()
+        tx = capture_np.transitions(prev, tr["actions"][t], tr["step_src"][t][:n1], tr["step_age"][t][:n1], tr["step_flags"][t][:n1],
+                                    tr["step_reward"][t][:n1], tr["step_done"][t][:n1], tr["step_obs"][t][:n1], tr["step_brain"][t][:n1])
+        assert np.array_equal(tx["k"], tr["step_learn_k"][t][: int(tr["step_learn_n"][t])])  # the reference's own call list
+        exp = [{k: v[tx["brain"] == b] for k, v in tx.items()} for b in range(cfg["n_brains"])]
+        _check_rings(hb.dw, exp, seen)
+        hb.update(tape)
+        prev = tr["upd_obs"][t][: int(tr["upd_n"][t])]
+    assert sum(seen) > 1500
+
+
+def test_transition_capture_after_fused_ticks_with_policy_outputs():
+    """Fused tick + batched policy: the ring rows are the policy-read observations / outputs of THAT tick (ping-pong state)."""
+    import torch
+    from hip_backend import HipBackend
+    from oracle import capture_np, oracle as orc
+    from reinlife_amd import _lib
+    from reinlife_amd.worlds import pack_brain_weights
+    import golden_io
+    m = np.load(golden_io.GOLDEN_DIR + "/models.npz")
+    R = 6
+    cfg = dict(width=30, height=30, max_agents=100, n_brains=2, static_families=True, limit_reproduction=False, incentivize_killing=True)
+    hb = HipBackend(R, seed=31, **cfg)
+    ow = orc.OracleWorlds(n_worlds=R, seed=31, **cfg)
+    hb.dw.set_brains([(_lib.PPO, 0.0, pack_brain_weights(_lib.PPO, m["PPO_weights"])),
+                      (_lib.PERD3QN, 0.1, pack_brain_weights(_lib.PERD3QN, m["PERD3QN_weights"]))])
+    hb.dw.reset_synthetic(100)
+    ow.reset_synthetic(100)
+    hb.dw.enable_capture(capacity=5000, with_prob=True)
+    seen = [0, 0]
+    for t in range(12):
+        hb.dw.act(want_q=True)
+        torch.cuda.synchronize()
+        acts = hb.dw.actions.cpu().numpy().copy()
+        q = hb.dw.out_q.cpu().numpy().copy()
+        prev_obs = ow.obs2.copy()
+        n0 = ow.s["n_agents"].copy()
+        full = np.zeros((R, hb.cap), np.int8)
+        for w in range(R):
+            full[w, : n0[w]] = acts[w, : n0[w]]
+        ow.step(full)
+        n1 = ow.s["n_agents"].copy()
+        l1 = {k: ow.s[k].copy() for k in ("a_age", "a_flags", "a_brain")}
+        rew, done, src, obs1 = ow.reward.copy(), ow.done.copy(), ow.src1.copy(), ow.obs1.copy()
+        ow.update()
+        hb.dw.tick()
+        hb.dw.capture_transitions(with_policy_out=True)
+        exp = [dict(action=[], reward=[], done=[], age=[], state=[], state_prime=[], prob=[]) for _ in range(2)]
+        for w in range(R):  # worlds append in any order; compare as multisets per brain below
+            tx = capture_np.transitions(prev_obs[w], full[w], src[w, : n1[w]], l1["a_age"][w, : n1[w]], l1["a_flags"][w, : n1[w]],
+                                        rew[w, : n1[w]], done[w, : n1[w]], obs1[w, : n1[w]], l1["a_brain"][w, : n1[w]])
+            s = src[w, : n1[w]][tx["k"]]
+            for b in range(2):
+                sel = tx["brain"] == b
+                for key in ("action", "reward", "done", "age", "state", "state_prime"):
+                    exp[b][key].append(tx[key][sel])
+                exp[b]["prob"].append(q[w, s[sel], tx["action"][sel]])
+        for b in range(2):
+            r = hb.dw.replays[b]
+            total = int(r["count"].item())
+            want = {k: np.concatenate(v) for k, v in exp[b].items()}
+            assert total == seen[b] + len(want["action"])
+            idx = np.arange(seen[b], total)
+            got = {k: r[k].cpu().numpy()[idx] for k in ("action", "reward", "done", "age", "prob")}
+            got["state"] = r["state"].cpu().numpy()[idx]; got["state_prime"] = r["state_prime"].cpu().numpy()[idx]
+            def key_rows(d):
+                return sorted(map(tuple, np.concatenate([d["state_prime"].astype(np.float32), d["state"].astype(np.float32),
+                                                          np.stack([d["action"], d["reward"], d["done"], d["age"], d["prob"]], 1).astype(np.float32)], 1).tolist()))
+            assert key_rows(got) == key_rows(want), (t, b)
+            seen[b] = total
+    assert min(seen) > 1000
