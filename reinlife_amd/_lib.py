@@ -97,7 +97,7 @@ def lib():
     """Load (building it first if the sources are newer / it is absent) the HIP library.  Never falls back."""
     global _lib
     if _lib is None:
-        path = _build.LIB_PATH
+        path = os.environ.get("REINLIFE_HIP_LIB") or _build.LIB_PATH  # override: A/B of alternative builds (tuning)
         if not os.path.exists(path) or os.environ.get("REINLIFE_REBUILD"):
             try:
                 _build.build()

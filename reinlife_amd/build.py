@@ -12,6 +12,7 @@ SOURCES = ["rl_world.hip", "rl_policy.hip", "rl_capi.hip"]
 HEADERS = ["rl_common.h", os.path.join("..", "..", "include", "reinlife_hip.h")]
 # -ffp-contract=off: the world kernels' float64 reward / fitness arithmetic must round exactly like the CPU path
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("RL_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _stale(target, deps):

@@ -66,6 +66,14 @@ __host__ __device__ inline Layout layout_of(int kind)
 // ---------------------------------------------------------------------------------------------------------------
 // device building blocks (everything fully unrolled: accumulators must stay in registers)
 // ---------------------------------------------------------------------------------------------------------------
+// LDS-only workgroup barrier: lds_barrier() would also wait vmcnt(0), i.e. drain the weight-prefetch ring at every
+// layer boundary; waves only exchange activations / partial sums through LDS.
+#ifdef RL_FULL_FENCE
+__device__ inline void lds_barrier() { __syncthreads(); }
+#else
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
+
 __device__ inline f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
 // x quad q of this lane: row j = lane&31, half h = lane>>5 covers k = 80h + 4q + e; k == 153 is the bias input.
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(256) void k_policy(const PolicyArgs A)
             layer_in<4, 1, 1, 4>(packed + L.l1, lane, v, xrow, h1);
             relu_inplace<1>(h1);
             publish_tile(lds_h, v, lane, h1[0]);
-            __syncthreads();
+            lds_barrier();
             if (v < 2) {  // the second hidden layer has 2 output tiles: waves 0 and 1
                 float q8[8];
                 layer_hidden<4, 2, 1, 1, 4>(packed + L.l2a, lane, v, lds_h, h2);
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(256) void k_policy(const PolicyArgs A)
             layer_in<4, 1, 1, 4>(packed + L.l1, lane, v, xrow, h1);
             relu_inplace<1>(h1);  // relu(feature) feeds both branches (PERD3QN.py:200-201)
             publish_tile(lds_h, v, lane, h1[0]);
-            __syncthreads();
+            lds_barrier();
             layer_hidden<4, 4, 1, 1, 4>(packed + L.l2a, lane, v, lds_h, h2);
             relu_inplace<1>(h2);
             head_partial<1, 1, 8>(packed + L.ha, h, v, h2, adv);
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(256) void k_policy(const PolicyArgs A)
             relu_inplace<2>(h1);
             publish_tile(lds_h, v, lane, h1[0]);
             publish_tile(lds_h, v + 4, lane, h1[1]);
-            __syncthreads();
+            lds_barrier();
             layer_hidden<8, 8, 2, 4, 3>(packed + L.l2a, lane, v, lds_h, h2);
             relu_inplace<2>(h2);
             head_partial<2, 4, 8>(packed + L.ha, h, v, h2, q8);
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(256) void k_policy(const PolicyArgs A)
 #pragma unroll
             for (int i = 0; i < 9; ++i) lds_part[v][j][i] = part[i];
         }
-        __syncthreads();
+        lds_barrier();
         if (v == 0 && h == 0) {
             float q[8];
             float sum9[9];
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(256) void k_policy(const PolicyArgs A)
                 }
             }
         }
-        __syncthreads();  // lds_h / lds_part are reused by the next tile
+        lds_barrier();  // lds_h / lds_part are reused by the next tile
     }
 }
 

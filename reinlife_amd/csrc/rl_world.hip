@@ -23,6 +23,8 @@
 #include "rl_common.h"
 
 int rl_world_prepare_bytes(size_t bytes);
+static int g_ablate = 0;  // tuning only
+extern "C" void rl_debug_set_ablate(int mask) { g_ablate = mask; }
 
 namespace {
 
@@ -31,7 +33,7 @@ constexpr uint8_t kPadCell = 0xFF;  // grid padding up to a multiple of 64 cells
 
 // scalar slots in LDS
 enum { S_ALIVE = 0, S_NFOOD, S_NPOISON, S_NSUPER, S_NSLOTS, S_N1, S_N2, S_NPARENTS, S_NELIG, S_BESTK, S_ERR, S_TICK, S_EPOCH,
-       S_NEXT_UID, S_MAX_GENE, S_COUNT = 16 };
+       S_NEXT_UID, S_MAX_GENE, S_ANYFLAG0, S_ANYFLAG1, S_COUNT = 24 };
 
 struct KParams {
     int W, H, C, Cp, nW;
@@ -51,6 +53,7 @@ struct KParams {
     int* lists_counts_zero;  //           the other parity, cleared by block 0 for the next producer
     int* lists;              //           row ids (world*cap + k), [n_brains][list_stride]
     long long list_stride;
+    int ablate;       // tuning only (env RL_ABLATE): bit mask of sections to skip -- results are then WRONG
     long long* prof;  // optional: shader-clock stamps of world prof_world's phases (debug / tuning)
     int prof_world;
 };
@@ -84,8 +87,10 @@ struct Smem {
 enum { AUX_VANISH = 1, AUX_PARENT = 2 };
 
 #ifdef RL_PHASE_PROFILE
+#define RL_ABL(bit) (p.ablate & (bit))  /* tuning build only: skip a section (results are then WRONG) */
 #define RL_MARK(i) do { if (p.prof && (int)blockIdx.x == p.prof_world && threadIdx.x == 0) p.prof[i] = (long long)clock64(); } while (0)
 #else
+#define RL_ABL(bit) 0
 #define RL_MARK(i) do { } while (0)
 #endif
 
@@ -139,6 +144,28 @@ __host__ __device__ inline size_t carve(Smem& s, char* base, int Cp, int cap, in
 // small device helpers
 // ---------------------------------------------------------------------------------------------------------------
 __device__ inline int lane_id() { return threadIdx.x & 63; }
+
+// Workgroup barrier for LDS-only communication.  lds_barrier() is a full workgroup fence: it emits
+// s_waitcnt vmcnt(0), which on gfx950 also waits for every outstanding global STORE (observation rows, outputs) -- an
+// HBM write round trip (~1 us) at each of the ~40 barriers of a tick.  Threads of these kernels only ever exchange data
+// through LDS, so waiting for the LDS queue is sufficient; global stores drain in the background.
+#ifdef RL_FULL_FENCE
+__device__ inline void lds_barrier() { __syncthreads(); }
+#else
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
+
+// block-wide OR over LDS flags (replaces __syncthreads_or, which carries the same full fence); `flags` is int[2] in LDS,
+// zero-initialised, `phase` a per-thread register toggled identically by all threads
+__device__ inline bool block_any(int* flags, int& phase, bool pred)
+{
+    if (pred) flags[phase] = 1;
+    lds_barrier();
+    const bool r = flags[phase] != 0;
+    phase ^= 1;
+    if (threadIdx.x == 0) flags[phase] = 0;  // next use of this slot is after at least one more barrier
+    return r;
+}
 __device__ inline unsigned long long shfl_u64(unsigned long long v, int src)
 {
     unsigned lo = __shfl((unsigned)v, src), hi = __shfl((unsigned)(v >> 32), src);
@@ -280,10 +307,10 @@ __device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
             p.st.a_brain[b + a], p.st.a_uid[b + a], p.st.a_flags[b + a], p.actions ? p.actions[b + a] : p.st.a_action[b + a],
             p.st.a_fitness[b + a]);
     RL_MARK(33);
-    __syncthreads();
+    lds_barrier();
     RL_MARK(34);
     for (int a = tid; a < n0; a += T) s.occ[(s.pos[a] & 255) * p.W + (s.pos[a] >> 8)] = (short)a;
-    __syncthreads();
+    lds_barrier();
 }
 
 // gene -> (alive count, on-grid count) open-addressing table; every agent remembers its slot.  Lanes of a wave that
@@ -327,14 +354,14 @@ __device__ void build_order(const KParams& p, Smem& s, int nslots, int out_slot)
         const unsigned long long m = __ballot(s.type[c] == RL_AGENT);
         if (lane_id() == 0) s.agbits[c >> 6] = m;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < 64) {
         const int cntw = tid < p.nW ? __popcll(s.agbits[tid]) : 0;
         const int incl = wave_incl_scan(cntw);
         s.wordbase[tid] = incl - cntw;
         if (tid == 63) s.scal[out_slot] = incl;
     }
-    __syncthreads();
+    lds_barrier();
     for (int a = tid; a < nslots; a += T) {
         const int cell = (s.pos[a] & 255) * p.W + (s.pos[a] >> 8);
         short ni = -1;
@@ -344,13 +371,14 @@ __device__ void build_order(const KParams& p, Smem& s, int nslots, int out_slot)
         }
         s.newidx[a] = ni;
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // _prepare_observations (environment.py:377-404) into LDS planes
 template <int T>
 __device__ void build_planes(const KParams& p, Smem& s)
 {
+    if (RL_ABL(2)) return;
     const bool float_mode = s.type[0] == RL_AGENT;  // np.vectorize dtype inference from cell (0,0)
     for (int c = threadIdx.x; c < p.C; c += T) {
         const int t = s.type[c];
@@ -375,7 +403,7 @@ __device__ void build_planes(const KParams& p, Smem& s)
 template <int T>
 __device__ void write_observations(const KParams& p, Smem& s, int w, int n, float* obs)
 {
-    if (!obs) return;
+    if (!obs || RL_ABL(1)) return;
     float* base = obs + (size_t)w * p.cap * RL_OBS_DIM;
     const int total = n * 49;
     for (int q = threadIdx.x; q < total; q += T) {
@@ -448,10 +476,11 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
         s.tgt[a] = (unsigned short)tg;
         atomicAdd(&cnt[tg], 1u);
     }
-    __syncthreads();
+    lds_barrier();
     RL_MARK(2);
     // ---- _execute_movement: Jacobi fixed point (environment.py:637-644) --------------------------------------------
-    for (;;) {
+    int any_phase = 0;
+    for (; !RL_ABL(16);) {
         int conflict = 0;
         for (int a = tid; a < n0; a += T) {
             const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
@@ -459,7 +488,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
             s.aux[a] = c ? 0x80 : 0;
             conflict |= c;
         }
-        if (!__syncthreads_or(conflict)) break;
+        if (!block_any(&s.scal[S_ANYFLAG0], any_phase, conflict != 0)) break;
         for (int a = tid; a < n0; a += T)
             if (s.aux[a] & 0x80) {
                 const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
@@ -467,7 +496,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
                 atomicAdd(&cnt[cx], 1u);
                 s.tgt[a] = (unsigned short)cx;
             }
-        __syncthreads();
+        lds_barrier();
     }
     RL_MARK(3);
     // ---- _eat + vanish rule (reads the pre-move grid) ----------------------------------------------------------------
@@ -489,13 +518,13 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
         }
         s.aux[a] = ax;
     }
-    __syncthreads();
+    lds_barrier();
     RL_MARK(35);
     for (int a = tid; a < n0; a += T) {
         const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
         if (s.tgt[a] != cx) { s.type[cx] = RL_EMPTY; s.occ[cx] = -1; }
     }
-    __syncthreads();
+    lds_barrier();
     RL_MARK(36);
     int alive_local = 0;
     const int n0p = (n0 + 63) & ~63;  // whole waves take part in the gene aggregation
@@ -519,7 +548,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
     }
     RL_MARK(37);
     if (alive_local) atomicAdd(&s.scal[S_ALIVE], alive_local);
-    __syncthreads();
+    lds_barrier();
     RL_MARK(4);
     // ---- _get_rewards over the _act list incl. vanished agents (environment.py:291-311) ------------------------------
     const int alive = s.scal[S_ALIVE];
@@ -548,9 +577,9 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
     if (nf) atomicAdd(&s.scal[S_NFOOD], nf);
     if (np_) atomicAdd(&s.scal[S_NPOISON], np_);
     if (ns) atomicAdd(&s.scal[S_NSUPER], ns);
-    __syncthreads();
+    lds_barrier();
     RL_MARK(6);
-    if (tid < 64) {
+    if (tid < 64 && !RL_ABL(4)) {
         Placer P;
         placer_init(P, tid < p.nW ? s.occbits[tid] : ~0ull);
         const bool tape = p.tape.food_k != nullptr;
@@ -565,20 +594,24 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
         const bool en_food = (double)s.scal[S_NFOOD] <= (double)p.C / 10.0;
         const bool en_poison = (double)s.scal[S_NPOISON] <= (double)p.C / 20.0;
         const bool en_super = s.scal[S_NSUPER] == 0;
-        for (int t = 0; t < RL_FOOD_TRIES; ++t) {
-            const bool en = t < 3 ? en_food : (t < 6 ? en_poison : en_super);
-            if (!en || P.n_empty <= 0) continue;  // empty grid: randint raises, nothing is drawn (grid.py:82-83)
-            const unsigned x = __shfl(xk, t);
-            const double ut = shfl_f64(u, t);
+        // a try whose coin fails changes nothing (its two draws are simply consumed), so only the placing tries are
+        // walked, in order; all coins are evaluated in parallel (lane t = try t)
+        const bool en = tid < 3 ? en_food : (tid < 6 ? en_poison : en_super);
+        const bool places = tid < RL_FOOD_TRIES && en && u < (tid < 6 ? 0.2 : 1.0);
+        unsigned long long todo = __ballot(places);
+        while (todo) {
+            const int t = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            if (P.n_empty <= 0) break;  // full grid: randint raises, nothing is placed (grid.py:82-83)
+            const unsigned x = (unsigned)read_lane((int)xk, t);
             const int k = tape ? (int)x : (int)rl_mulhi(x, (unsigned)P.n_empty);
             if (k < 0 || k >= P.n_empty) { if (tid == 0) flag_error(p, s, 1, w, t, k); continue; }
-            if (!(ut < (t < 6 ? 0.2 : 1.0))) continue;
             const int cell = placer_take(P, k);
             if (tid == 0) s.type[cell] = (uint8_t)(t < 3 ? RL_FOOD : (t < 6 ? RL_POISON : kSuper));
         }
         if (tid < p.nW) s.occbits[tid] = P.word;
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 __device__ inline void init_newborn(Smem& s, int idx, int cell, int W, int gene, int brain, int uid)
@@ -594,7 +627,7 @@ __device__ inline void init_newborn(Smem& s, int idx, int cell, int W, int gene,
 
 // Environment.update_env up to (not including) the observation pass.  order[0..n1) is the grid list.
 template <int T>
-__device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslots)
+__device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslots, bool fresh_bitmap)
 {
     const int tid = threadIdx.x;
     // ---- _update_best_agents (environment.py:728-739) ----------------------------------------------------------------
@@ -610,7 +643,7 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
             if (of > bf || (of == bf && ok < bk)) { bf = of; bk = ok; }
         }
         if (lane_id() == 0) { s.wred_f[tid >> 6] = bf; s.wred_k[tid >> 6] = bk; }
-        __syncthreads();
+        lds_barrier();
         if (tid == 0 && n1 > 0) {
             for (int v = 1; v < T / 64; ++v)
                 if (s.wred_f[v] > bf || (s.wred_f[v] == bf && s.wred_k[v] < bk)) { bf = s.wred_f[v]; bk = s.wred_k[v]; }
@@ -621,77 +654,51 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
             for (int b = 0; b < RL_N_BEST; ++b) present |= s.best_uid[b] == s.uid[a];
             if (!present && bf > s.best_fit[mi]) { s.best_uid[mi] = s.uid[a]; s.best_fit[mi] = bf; s.best_brain[mi] = s.brain[a]; }
         }
-        __syncthreads();
+        lds_barrier();
     }
     RL_MARK(13);
-    // ---- _reproduce gates (environment.py:500-501): eligible agents in list order, one draw each ---------------------
+    // ---- _reproduce + _produce (environment.py:488-547): wave 0 alone, no workgroup barriers -------------------------
+    // gates: eligible agents in list order, one draw each (rank among the eligible = draw index); births are placed
+    // sequentially on the occupancy bitmap, the newborns themselves are initialised in parallel afterwards.
     const bool room = n1 <= p.max_agents;
     const bool tape = p.tape.food_k != nullptr;
     const uint32_t epoch = (uint32_t)s.scal[S_EPOCH], tick = (uint32_t)s.scal[S_TICK];
-    // pass A: eligibility bitmap over list index (reuses agbits/wordbase; rebuilt by build_order afterwards)
-    const int n1p = (n1 + 63) & ~63;
-    for (int k = tid; k < n1p; k += T) {
-        bool e = false;
-        if (k < n1) {
-            const int a = s.order[k];
-            e = room && !(s.flags[a] & (RL_F_DEAD | RL_F_REPRODUCED)) && s.age[a] > 5;  // can_reproduce, entities.py:244
-            if (p.static_families && s.gene[a] >= 0 && s.gene[a] < RL_MAX_BRAINS) s.present[s.gene[a]] = 1;
+    RL_MARK(13);
+    if (!fresh_bitmap) {  // standalone update: rebuild the occupancy bitmap (a fused tick reuses the food phase's)
+        for (int c = tid; c < p.Cp; c += T) {
+            const unsigned long long m = __ballot(s.type[c] != RL_EMPTY);
+            if (lane_id() == 0) s.occbits[c >> 6] = m;
         }
-        const unsigned long long m = __ballot(e);
-        if (lane_id() == 0) s.agbits[k >> 6] = m;
+        lds_barrier();
     }
-    __syncthreads();
-    if (tid < 64) {
-        const int nw = n1p >> 6;
-        const int cntw = tid < nw ? __popcll(s.agbits[tid]) : 0;
-        const int incl = wave_incl_scan(cntw);
-        s.wordbase[tid] = incl - cntw;
-        if (tid == 63) s.scal[S_NELIG] = incl;
-    }
-    __syncthreads();
-    RL_MARK(38);
-    // pass B: gate draw by eligible rank; parents bitmap
-    for (int k = tid; k < n1p; k += T) {
-        bool par = false;
-        if (k < n1 && ((s.agbits[k >> 6] >> (k & 63)) & 1ull)) {
-            const int rank = s.wordbase[k >> 6] + __popcll(s.agbits[k >> 6] & lowmask(k & 63));
-            double u;
-            if (tape) u = p.tape.repro_u[(size_t)w * p.cap + rank];
-            else u = rl_u24(rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_REPRO, (uint32_t)rank).x);
-            par = u > 0.95;
-            if (par && p.limit_reproduction) s.flags[s.order[k]] |= RL_F_REPRODUCED;
+    if (tid < 64 && !RL_ABL(8)) {
+        const int lane = tid;
+        int rank_base = 0, npar = 0;
+        for (int base = 0; base < n1; base += 64) {
+            const int k = base + lane;
+            const bool act = k < n1;
+            const int a = act ? s.order[k] : 0;
+            const int fl = act ? s.flags[a] : 0;
+            const bool e = act && room && !(fl & (RL_F_DEAD | RL_F_REPRODUCED)) && s.age[a] > 5;  // can_reproduce, entities.py:244
+            if (act && p.static_families && s.gene[a] >= 0 && s.gene[a] < RL_MAX_BRAINS) s.present[s.gene[a]] = 1;
+            const unsigned long long em = __ballot(e);
+            bool par = false;
+            if (e) {
+                const int rank = rank_base + __popcll(em & lowmask(lane));
+                double u;
+                if (tape) u = p.tape.repro_u[(size_t)w * p.cap + rank];
+                else u = rl_u24(rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_REPRO, (uint32_t)rank).x);
+                par = u > 0.95;
+                if (par && p.limit_reproduction) s.flags[a] = (uint8_t)(fl | RL_F_REPRODUCED);
+            }
+            const unsigned long long pm = __ballot(par);
+            if (par) s.plist[npar + __popcll(pm & lowmask(lane))] = (short)a;
+            npar += __popcll(pm);
+            rank_base += __popcll(em);
         }
-        const unsigned long long m = __ballot(par);
-        if (lane_id() == 0) s.occbits[k >> 6] = m;  // parents bitmap; occbits is rebuilt below before its next use
-    }
-    __syncthreads();
-    RL_MARK(39);
-    // compact parents in list order
-    if (tid < 64) {
-        const int nw = n1p >> 6;
-        const int cntw = tid < nw ? __popcll(s.occbits[tid]) : 0;
-        const int incl = wave_incl_scan(cntw);
-        s.wordbase[tid] = incl - cntw;
-        if (tid == 63) s.scal[S_NPARENTS] = incl;
-    }
-    __syncthreads();
-    for (int k = tid; k < n1; k += T)
-        if ((s.occbits[k >> 6] >> (k & 63)) & 1ull)
-            s.plist[s.wordbase[k >> 6] + __popcll(s.occbits[k >> 6] & lowmask(k & 63))] = s.order[k];
-    __syncthreads();
-    RL_MARK(40);
-    // occupancy bitmap for placements (dead agents still occupy their cells here)
-    for (int c = tid; c < p.Cp; c += T) {
-        const unsigned long long m = __ballot(s.type[c] != RL_EMPTY);
-        if (lane_id() == 0) s.occbits[c >> 6] = m;
-    }
-    __syncthreads();
-    RL_MARK(14);
-    // ---- births: _reproduce placements then _produce (environment.py:502-547), sequential on wave 0 ------------------
-    if (tid < 64) {
+        RL_MARK(14);
         Placer P;
         placer_init(P, tid < p.nW ? s.occbits[tid] : ~0ull);
-        const int npar = s.scal[S_NPARENTS];
         int next_uid = s.scal[S_NEXT_UID];
         int max_gene = s.scal[S_MAX_GENE];
         int n_birth = 0, slots = nslots;
@@ -704,19 +711,24 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
                 if (tape) bdraw = mine <= p.cap ? (unsigned)p.tape.birth_k[(size_t)w * (p.cap + 1) + mine] : 0u;
                 else bdraw = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_BIRTH, (uint32_t)mine).x;
             }
-            return __shfl(bdraw, b & 63);
+            return (unsigned)read_lane((int)bdraw, b & 63);
         };
-        for (int b = 0; b < npar; ++b) {
-            if (P.n_empty <= 0) continue;  // full grid: randint raises, no draw, no offspring (grid.py:82-83)
+        // sequential part: only the placement; (cell, gene, brain) of newborn i are parked in tgt/gene/brain of its slot
+        auto place_birth = [&](int gene, int brain, int errtag) {
             const unsigned x = birth_draw(n_birth);  // draw indices advance only when a draw happens
             const int k = tape ? (int)x : (int)rl_mulhi(x, (unsigned)P.n_empty);
             ++n_birth;
-            if (k < 0 || k >= P.n_empty) { if (tid == 0) flag_error(p, s, 2, w, b, k); continue; }
+            if (k < 0 || k >= P.n_empty) { if (tid == 0) flag_error(p, s, 2, w, errtag, k); return; }
             const int cell = placer_take(P, k);
-            if (slots >= p.cap) { if (tid == 0) flag_error(p, s, 3, w, slots, 0); continue; }
+            if (slots >= p.cap) { if (tid == 0) flag_error(p, s, 3, w, slots, 0); return; }
+            if (tid == 0) { s.tgt[slots] = (unsigned short)cell; s.gene[slots] = gene; s.brain[slots] = brain; }
+            ++slots;
+        };
+        for (int b = 0; b < npar; ++b) {
+            if (P.n_empty <= 0) continue;  // full grid: randint raises, no draw, no offspring (grid.py:82-83)
             const int par = s.plist[b];
-            if (tid == 0) init_newborn(s, slots, cell, p.W, s.gene[par], p.static_families ? s.gene[par] : s.brain[par], next_uid);
-            ++slots; ++next_uid;
+            const int g = s.gene[par];
+            place_birth(g, p.static_families ? g : s.brain[par], b);
         }
         RL_MARK(41);
         // _produce
@@ -746,33 +758,30 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
                     brain = (c >= 0 && c < RL_N_BEST) ? s.best_brain[c] : 0;
                     if (c < 0 || c >= RL_N_BEST) { if (tid == 0) flag_error(p, s, 4, w, c, 0); }
                 }
-                if (P.n_empty > 0 && gene >= 0) {
-                    const unsigned x = birth_draw(n_birth);
-                    const int k = tape ? (int)x : (int)rl_mulhi(x, (unsigned)P.n_empty);
-                    if (k < 0 || k >= P.n_empty) { if (tid == 0) flag_error(p, s, 2, w, -1, k); }
-                    else {
-                        const int cell = placer_take(P, k);
-                        if (slots >= p.cap) { if (tid == 0) flag_error(p, s, 3, w, slots, 0); }
-                        else { if (tid == 0) init_newborn(s, slots, cell, p.W, gene, brain, next_uid); ++slots; ++next_uid; }
-                    }
-                }
+                if (P.n_empty > 0 && gene >= 0) place_birth(gene, brain, -1);
             }
         }
         RL_MARK(42);
+        // newborns (entities.py:145-159), initialised in parallel: lane i -> slot nslots + i
+        for (int i = nslots + lane; i < slots; i += 64) {
+            const int cell = s.tgt[i];
+            init_newborn(s, i, cell, p.W, s.gene[i], s.brain[i], next_uid + (i - nslots));
+        }
+        next_uid += slots - nslots;
         if (tid == 0) { s.scal[S_NSLOTS] = slots; p.st.next_uid[w] = next_uid; p.st.max_gene[w] = max_gene; }
-    }
-    __syncthreads();
-    nslots = s.scal[S_NSLOTS];
-    RL_MARK(15);
-    // ---- _remove_dead_agents (environment.py:795-799): corpses become Food ---------------------------------------------
-    for (int k = tid; k < n1; k += T) {
-        const int a = s.order[k];
-        if (s.flags[a] & RL_F_DEAD) {
-            const int cell = (s.pos[a] & 255) * p.W + (s.pos[a] >> 8);
-            s.type[cell] = RL_FOOD; s.occ[cell] = -1;
+        // _remove_dead_agents (environment.py:795-799): corpses become Food -- after the placements, which must still
+        // see their cells as occupied; same wave, so no barrier in between
+        for (int k = lane; k < n1; k += 64) {
+            const int a = s.order[k];
+            if (s.flags[a] & RL_F_DEAD) {
+                const int cell = (s.pos[a] & 255) * p.W + (s.pos[a] >> 8);
+                s.type[cell] = RL_FOOD; s.occ[cell] = -1;
+            }
         }
     }
-    __syncthreads();
+    lds_barrier();
+    nslots = s.scal[S_NSLOTS];
+    RL_MARK(15);
 }
 
 // on-grid gene counts for the observation's percent_genes (environment.py:357)
@@ -780,14 +789,14 @@ template <int T>
 __device__ void rebuild_gene_counts(const KParams& p, Smem& s, int n)
 {
     for (int i = threadIdx.x; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
-    __syncthreads();
+    lds_barrier();
     const int np2 = (n + 63) & ~63;
     for (int k = threadIdx.x; k < np2; k += T) {
         const bool act = k < n;
         const int a = act ? s.order[k] : 0;
         hash_insert_wave(s, p.hash_mask, act, a, act ? s.gene[a] : 0, 1u << 16, 0);
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // inclusive running maximum over the 64 lanes (values >= 0), same DPP pattern as wave_incl_scan
@@ -945,22 +954,28 @@ template <int T>
 __device__ void store_world(const KParams& p, Smem& s, int w, int n)
 {
     const int tid = threadIdx.x;
+    if (RL_ABL(64)) return;
     uint8_t* gt = p.st.cell_type + (size_t)w * p.C;
-    for (int c = tid; c < p.C; c += T) gt[c] = s.type[c];
+    if (!RL_ABL(1024)) for (int c = tid; c < p.C; c += T) gt[c] = s.type[c];
     const size_t b = (size_t)w * p.cap;
+    if (!RL_ABL(2048))
     for (int k = tid; k < n; k += T) {
         const int a = s.order[k];
+        if (!RL_ABL(4096)) {
         p.st.a_i[b + k] = (uint8_t)(s.pos[a] & 255);
         p.st.a_j[b + k] = (uint8_t)(s.pos[a] >> 8);
+        p.st.a_flags[b + k] = s.flags[a];
+        p.st.a_action[b + k] = s.action[a];
+        }
+        if (!RL_ABL(8192)) {
         p.st.a_health[b + k] = s.health[a];
         p.st.a_age[b + k] = s.age[a];
         p.st.a_max_age[b + k] = s.max_age[a];
         p.st.a_gene[b + k] = s.gene[a];
         p.st.a_brain[b + k] = s.brain[a];
         p.st.a_uid[b + k] = s.uid[a];
-        p.st.a_flags[b + k] = s.flags[a];
-        p.st.a_action[b + k] = s.action[a];
-        p.st.a_fitness[b + k] = s.fitness[a];
+        }
+        if (!RL_ABL(16384)) p.st.a_fitness[b + k] = s.fitness[a];
     }
     if (tid == 0) p.st.n_agents[w] = n;
     if (tid < RL_N_BEST && !p.static_families) {
@@ -985,26 +1000,28 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
     const int tid = threadIdx.x;
     int n0;
     RL_MARK(0);
+    if (RL_ABL(32768)) return;
     load_world<T>(p, s, w, n0);
     RL_MARK(1);
+    if (RL_ABL(65536)) return;
     int nslots = n0;
     int n_cur = n0;  // length of order[]
 
     if (MODE == MODE_OBSERVE) {
         rebuild_gene_counts<T>(p, s, n0);
         build_planes<T>(p, s);
-        __syncthreads();
+        lds_barrier();
         write_observations<T>(p, s, w, n0, p.obs_only);
         return;
     }
     if (MODE == MODE_STEP || MODE == MODE_TICK) {
-        phase_step<T>(p, s, w, n0);
+        if (!RL_ABL(512)) phase_step<T>(p, s, w, n0);
         RL_MARK(8);
         build_order<T>(p, s, nslots, S_N1);
         RL_MARK(9);
         const int n1 = s.scal[S_N1];
         build_planes<T>(p, s);
-        __syncthreads();
+        lds_barrier();
         RL_MARK(10);
         write_observations<T>(p, s, w, n1, p.so.obs);
         RL_MARK(11);
@@ -1023,16 +1040,15 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
         if (p.so.trk_tick && tid < 64) track_world_wave0(p, s, w, n1);
         n_cur = n1;
         if (MODE == MODE_STEP) { store_world<T>(p, s, w, n1); return; }
-        __syncthreads();
+        lds_barrier();
         // fused tick: agents keep their LDS slot; remember their post-step list index for uo.src
         for (int a = tid; a < nslots; a += T) s.src[a] = s.newidx[a];
-        if (tid < RL_MAX_BRAINS) s.present[tid] = 0;
-        __syncthreads();
+        lds_barrier();
     }
     if (MODE == MODE_UPDATE || MODE == MODE_TICK) {
         const int n1 = n_cur;
         RL_MARK(12);
-        phase_update<T>(p, s, w, n1, nslots);
+        if (!RL_ABL(256)) phase_update<T>(p, s, w, n1, nslots, MODE == MODE_TICK);
         RL_MARK(17);
         build_order<T>(p, s, nslots, S_N2);
         RL_MARK(18);
@@ -1043,7 +1059,7 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
         RL_MARK(19);
         rebuild_gene_counts<T>(p, s, n2);
         build_planes<T>(p, s);
-        __syncthreads();
+        lds_barrier();
         RL_MARK(20);
         write_observations<T>(p, s, w, n2, p.uo.obs);
         RL_MARK(21);
@@ -1052,7 +1068,7 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
             for (int k = tid; k < n2; k += T) p.uo.src[b + k] = s.src[s.order[k]];
         }
         store_world<T>(p, s, w, n2);
-        if (p.lists && tid < 64) emit_brain_lists_wave0(p, w, n2, [&](int k) { return s.brain[s.order[k]]; });
+        if (p.lists && tid < 64 && !RL_ABL(128)) emit_brain_lists_wave0(p, w, n2, [&](int k) { return s.brain[s.order[k]]; });
         RL_MARK(22);
         if (tid == 0 && !refill) p.st.tick[w] = s.scal[S_TICK] + 1;
     }
@@ -1075,10 +1091,10 @@ __device__ int reset_world_lds(const KParams& p, Smem& s, int w, uint32_t epoch)
     int lg = 6;
     while ((2 << lg) <= p.Cp) ++lg;          // NB = largest power of two <= Cp
     const int NB = 1 << lg, sh = 32 - lg;
-    __syncthreads();
+    lds_barrier();
     if (tid < S_COUNT) s.scal[tid] = 0;
     for (int b = tid; b < NB; b += T) cum[b] = 0u;
-    __syncthreads();
+    lds_barrier();
     // 1. one Philox block per cell: unique random key, food / poison coins; histogram of the key prefixes
     int nf = 0, np_ = 0;
     for (int c = tid; c < p.Cp; c += T) {
@@ -1093,7 +1109,7 @@ __device__ int reset_world_lds(const KParams& p, Smem& s, int w, uint32_t epoch)
     }
     if (nf) atomicAdd(&s.scal[S_NFOOD], nf);
     if (np_) atomicAdd(&s.scal[S_NPOISON], np_);
-    __syncthreads();
+    lds_barrier();
     // 2. exclusive scan of the NB bucket counts, in place (each thread owns `per` consecutive buckets)
     {
         const int per = (NB + T - 1) / T;
@@ -1102,19 +1118,19 @@ __device__ int reset_world_lds(const KParams& p, Smem& s, int w, uint32_t epoch)
         for (int i = 0; i < per; ++i) if (b0 + i < NB) local += cum[b0 + i];
         const int incl = wave_incl_scan((int)local);
         if (lane_id() == 63) s.wred_k[tid >> 6] = incl;
-        __syncthreads();
+        lds_barrier();
         unsigned base = (unsigned)(incl - (int)local);
         for (int v = 0; v < (tid >> 6); ++v) base += (unsigned)s.wred_k[v];
         for (int i = 0; i < per; ++i)
             if (b0 + i < NB) { const unsigned c = cum[b0 + i]; cum[b0 + i] = base; base += c; }
     }
-    __syncthreads();
+    lds_barrier();
     // 3. counting-sort scatter: afterwards cum[b] is the END of bucket b (= start of bucket b+1)
     for (int c = tid; c < p.C; c += T) {
         const unsigned key = keys[c];
         sorted[atomicAdd(&cum[key >> sh], 1u)] = key;
     }
-    __syncthreads();
+    lds_barrier();
     // 4. exact rank = bucket start + smaller keys inside the (one- or two-element) bucket; classify the cell
     const int na = min(p.reset_n_agents, p.C);
     const int k1 = na, k2 = na + s.scal[S_NFOOD], k3 = k2 + s.scal[S_NPOISON];
@@ -1130,18 +1146,18 @@ __device__ int reset_world_lds(const KParams& p, Smem& s, int w, uint32_t epoch)
         }
         s.type[c] = t;
     }
-    __syncthreads();
+    lds_barrier();
     for (int c = tid; c < p.Cp; c += T) {
         const unsigned long long m = __ballot(s.type[c] == RL_AGENT);
         if (lane_id() == 0) s.agbits[c >> 6] = m;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < 64) {
         const int cntw = tid < p.nW ? __popcll(s.agbits[tid]) : 0;
         const int incl = wave_incl_scan(cntw);
         s.wordbase[tid] = incl - cntw;
     }
-    __syncthreads();
+    lds_barrier();
     for (int c = tid; c < p.C; c += T)
         if (s.type[c] == RL_AGENT) {
             const int idx = s.wordbase[c >> 6] + __popcll(s.agbits[c >> 6] & lowmask(c & 63));
@@ -1160,7 +1176,7 @@ __device__ int reset_world_lds(const KParams& p, Smem& s, int w, uint32_t epoch)
         p.st.next_uid[w] = na; p.st.max_gene[w] = p.n_brains; p.st.tick[w] = 0; p.st.epoch[w] = (int)epoch;
         if (p.refill_count) atomicAdd(p.refill_count, 1);
     }
-    __syncthreads();
+    lds_barrier();
     return na;
 }
 
@@ -1182,7 +1198,7 @@ __global__ __launch_bounds__(T) void k_reset(const KParams p)
     const int n = reset_world_lds<T>(p, s, w, epoch);
     rebuild_gene_counts<T>(p, s, n);
     build_planes<T>(p, s);
-    __syncthreads();
+    lds_barrier();
     write_observations<T>(p, s, w, n, p.obs_only);
     store_world<T>(p, s, w, n);
     if (p.lists && threadIdx.x < 64) emit_brain_lists_wave0(p, w, n, [&](int k) { return s.brain[s.order[k]]; });
@@ -1193,7 +1209,7 @@ __global__ __launch_bounds__(T) void k_reset(const KParams p)
 inline int pick_block(const rl_world* h)
 {
     static const int forced = getenv("RL_WORLD_BLOCK") ? atoi(getenv("RL_WORLD_BLOCK")) : 0;
-    if (forced == 256 || forced == 1024) return forced;
+    if (forced == 256 || forced == 512 || forced == 1024) return forced;
     return h->cfg.n_worlds <= 768 ? 1024 : 256;
 }
 
@@ -1211,6 +1227,7 @@ KParams make_params(const rl_world* h)
     p.refill_threshold = -1;
     p.prof = h->prof; p.prof_world = h->prof_world;
     p.lists = nullptr; p.lists_counts = nullptr; p.lists_counts_zero = nullptr; p.list_stride = 0;
+    p.ablate = g_ablate;
     return p;
 }
 
@@ -1218,8 +1235,11 @@ template <int MODE>
 int launch_world(const rl_world* h, const KParams& p, hipStream_t stream)
 {
     if (int rc = rl_world_prepare_bytes(h->smem_bytes)) return rc;
-    if (pick_block(h) == 1024)
+    const int blk = pick_block(h);
+    if (blk == 1024)
         hipLaunchKernelGGL((k_world<1024, MODE>), dim3(h->cfg.n_worlds), dim3(1024), h->smem_bytes, stream, p);
+    else if (blk == 512)
+        hipLaunchKernelGGL((k_world<512, MODE>), dim3(h->cfg.n_worlds), dim3(512), h->smem_bytes, stream, p);
     else
         hipLaunchKernelGGL((k_world<256, MODE>), dim3(h->cfg.n_worlds), dim3(256), h->smem_bytes, stream, p);
     const hipError_t e = hipGetLastError();
@@ -1270,7 +1290,7 @@ __global__ __launch_bounds__(256) void k_capture(const CaptureArgs A)
         }
         if (lane == 0) n_tx = ntx;
     }
-    __syncthreads();
+    lds_barrier();
     for (int k = tid >> 6; k < n1; k += 4) {  // one wave per transition
         const int sl = slot[k];
         if (sl < 0) continue;
@@ -1330,6 +1350,7 @@ int rl_world_prepare_bytes(size_t bytes)
 #define RL_ATTR(K) e = e != hipSuccess ? e : hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     RL_ATTR((k_world<256, MODE_STEP>)) RL_ATTR((k_world<256, MODE_UPDATE>)) RL_ATTR((k_world<256, MODE_TICK>))
     RL_ATTR((k_world<256, MODE_OBSERVE>)) RL_ATTR((k_reset<256>))
+    RL_ATTR((k_world<512, MODE_TICK>)) RL_ATTR((k_world<512, MODE_STEP>)) RL_ATTR((k_world<512, MODE_UPDATE>)) RL_ATTR((k_world<512, MODE_OBSERVE>))
     RL_ATTR((k_world<1024, MODE_STEP>)) RL_ATTR((k_world<1024, MODE_UPDATE>)) RL_ATTR((k_world<1024, MODE_TICK>))
     RL_ATTR((k_world<1024, MODE_OBSERVE>)) RL_ATTR((k_reset<1024>))
 #undef RL_ATTR
