@@ -192,34 +192,41 @@ def main():
     # ---- per-kernel durations with HIP events on the launch stream (untimed extra steps) ------------------------------
     roofline, extra = None, {}
     if rank == 0 and not args.no_kernel_timing:
-        n_probe = 40
+        # back-to-back launches, no host sync inside the probe (a launch from an idle stream costs ~8 us extra): the event
+        # pairs then agree with rocprofv3's per-kernel average (profiles/r01c_kernel_stats.txt)
+        n_probe = 60
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_probe)]
-        probe_acted = 0
+        acted_before = int(dw.acted_total.item())
+        for _ in range(5):
+            one_step(dw)
+        acted_before = int(dw.acted_total.item())
         for i in range(n_probe):
             ev[i][0].record(); dw.act(); ev[i][1].record(); dw.tick_refill(70, 100); ev[i][2].record()
-            probe_acted += int(dw.n_acted.sum().item())
         torch.cuda.synchronize()
-        t_act = np.mean([e[0].elapsed_time(e[1]) for e in ev]) * 1e-3
-        t_tick = np.mean([e[1].elapsed_time(e[2]) for e in ev]) * 1e-3
+        probe_acted = int(dw.acted_total.item()) - acted_before
+        t_act = float(np.median([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
+        t_tick = float(np.median([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
         per_launch = probe_acted / n_probe
         wl = WORKLOADS[args.workload]
         flop = np.mean([POLICY_FLOP_PER_AGENT[n] for n in wl["brains"]])
         tick_gbs = per_launch * TICK_BYTES_PER_AGENT_STEP / t_tick / 1e9
         pol_tflops = per_launch * flop / t_act / 1e12
-        traffic = None
+        traffic = pol_traffic = None  # PMC HBM bytes per launch, measured separately (tools/pmc_traffic.sh, 256 worlds/GPU)
         tpath = os.path.join(ROOT, "profiles", "tick_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.worlds == 256 and args.workload == "c4":
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic, pol_traffic = tj.get("hbm_bytes_per_launch"), tj.get("policy_hbm_bytes_per_launch")
             except Exception:  # noqa: BLE001
-                traffic = None
+                traffic = pol_traffic = None
         tick_roof = {"kernel": "k_world<TICK> (rl_tick_refill)", "bound": "hbm", "achieved": round(tick_gbs, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(tick_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "avg_launch_us": round(t_tick * 1e6, 2), "agent_steps_per_launch": round(per_launch, 1),
                      "bytes_per_agent_step": TICK_BYTES_PER_AGENT_STEP}
-        pol_roof = {"kernel": "k_bucket + k_policy (rl_policy_act)", "bound": "mfma", "achieved": round(pol_tflops, 3),
+        pol_roof = {"kernel": "k_policy (rl_policy_act: one launch per brain kind)", "bound": "mfma", "achieved": round(pol_tflops, 3),
                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(pol_tflops / MFMA_F32_PEAK_TFLOPS, 5),
-                    "traffic": None, "avg_launch_us": round(t_act * 1e6, 2), "flop_per_agent": flop}
+                    "traffic": pol_traffic, "avg_launch_us": round(t_act * 1e6, 2), "flop_per_agent": flop,
+                    "agent_steps_per_launch": round(per_launch, 1)}
         roofline = tick_roof if t_tick >= t_act else pol_roof
         extra = {"roofline_tick": tick_roof, "roofline_policy": pol_roof}
 
