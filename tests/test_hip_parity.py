@@ -195,3 +195,80 @@ def test_hip_policy_act_over_worlds_matches_oracle():
         ow.step(full); ow.update()
         hb.tick(full)
         _compare_rows(hb.obs2, ow.obs2, ow.s["n_agents"], "obs after act tick %d" % t)
+
+
+def _mk(R, seed=3, **over):
+    from hip_backend import HipBackend
+    from oracle import oracle as orc
+    cfg = dict(width=30, height=30, max_agents=100, n_brains=2, static_families=True, limit_reproduction=False,
+               incentivize_killing=True)
+    cfg.update(over)
+    return HipBackend(R, seed=seed, **cfg), orc.OracleWorlds(n_worlds=R, seed=seed, **cfg), cfg
+
+
+def _run_both(hb, ow, ticks, rng, fused=False, action_fn=None):
+    for t in range(ticks):
+        acts = (action_fn(rng) if action_fn else rng.randint(0, 8, size=(ow.R, hb.cap))).astype(np.int8)
+        ow.step(acts); ow.update()
+        if fused:
+            hb.tick(acts)
+        else:
+            hb.step(acts); hb.update()
+        _compare_states(hb, ow, "tick %d" % t)
+        _compare_rows(hb.obs2, ow.obs2, ow.s["n_agents"], "tick %d obs2" % t)
+
+
+def test_edge_empty_worlds_repopulate_through_produce():
+    """No agents at all: step/update are no-ops except _add_food and _produce (environment.py:528), which re-seeds."""
+    hb, ow, _ = _mk(32, n_brains=3)
+    hb.dw.reset_synthetic(0); ow.reset_synthetic(0)
+    _compare_states(hb, ow, "empty reset")
+    _run_both(hb, ow, 120, np.random.RandomState(1))
+    assert ow.s["n_agents"].sum() > 0  # produce fired somewhere
+
+
+def test_edge_full_grid_set_random_finds_no_cell():
+    """A grid without empty cells: Grid.set_random returns None without drawing (grid.py:82-83); movers all conflict."""
+    from oracle import oracle as orc
+    hb, ow, cfg = _mk(4, width=8, height=8, max_agents=40)
+    hb.dw.reset_synthetic(30); ow.reset_synthetic(30)
+    for w in range(4):
+        snap = ow.world(w)
+        ct = snap["cell_type"].copy()
+        ct[ct == orc.EMPTY] = orc.POISON if w % 2 else orc.FOOD
+        snap["cell_type"] = ct
+        snap["age"] = np.full_like(snap["age"], 10)  # old enough to reproduce: births must find no cell
+        ow.load_world(w, snap); hb.load_world(w, snap)
+    _run_both(hb, ow, 25, np.random.RandomState(2))
+
+
+def test_edge_invalid_and_unset_actions_are_noops():
+    """Newborns carry action -1 (entities.py:153); out-of-range actions neither move nor attack here."""
+    hb, ow, _ = _mk(8)
+    hb.dw.reset_synthetic(100); ow.reset_synthetic(100)
+    _run_both(hb, ow, 20, np.random.RandomState(3), action_fn=lambda r: r.randint(-1, 10, size=(8, 256)))
+
+
+def test_edge_minimum_grid_and_many_brains():
+    hb, ow, _ = _mk(6, width=3, height=3, max_agents=4, n_brains=64)
+    hb.dw.reset_synthetic(4); ow.reset_synthetic(4)
+    _run_both(hb, ow, 60, np.random.RandomState(4), fused=True)
+    hb, ow, _ = _mk(3, width=64, height=64, max_agents=300, n_brains=5, static_families=False)  # largest world: 120 KB of LDS
+    hb.dw.reset_synthetic(500); ow.reset_synthetic(500)
+    _run_both(hb, ow, 8, np.random.RandomState(5), fused=True, action_fn=lambda r: r.randint(0, 8, size=(3, hb.cap)))
+
+
+def test_edge_inconsistent_tape_sets_the_error_flag():
+    """A recorded draw that cannot belong to this world (index beyond the number of empty cells) must be reported through
+    the device error flag, not silently wrapped (the oracle returns an error for the same tape)."""
+    from oracle import oracle as orc
+    from reinlife_amd import _lib
+    hb, ow, _ = _mk(2)
+    hb.dw.reset_synthetic(50); ow.reset_synthetic(50)
+    bad = {"food_k": np.full(7, 5000, np.int32), "food_u": np.zeros(7), "repro_u": np.zeros(hb.cap), "birth_k": np.zeros(hb.cap + 1, np.int32),
+           "produce_u": 0.0, "produce_choice": 0}
+    acts = np.zeros((2, hb.cap), np.int8)
+    with pytest.raises(RuntimeError):
+        ow.step(acts, ow.make_tape([bad, bad]))
+    with pytest.raises(_lib.ReinLifeHipError, match="code 1"):
+        hb.step(acts, hb.make_tape([bad, bad]))
