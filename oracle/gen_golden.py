@@ -266,6 +266,14 @@ def state_dict_keys():
     path = os.path.join(OUT_DIR, "state_dict_keys.json")
     json.dump(out, open(path, "w"), indent=1)
     print("wrote %s" % path)
+    # scalar brain attributes Saver._save_params writes to parameters_*.json (saver.py:170-194)
+    import inspect
+    brains = {"DQN": ref.DQN(max_epi=100), "D3QN": ref.D3QN(), "PERD3QN": ref.PERD3QN(), "PPO": ref.PPO()}
+    params = {k: {n: v for n, v in inspect.getmembers(b, lambda a: not inspect.isroutine(a)) if type(v) in (float, int, bool, str) and not n.startswith("__")}  # no docstrings: data only
+              for k, b in brains.items()}
+    path = os.path.join(OUT_DIR, "brain_param_keys.json")
+    json.dump(params, open(path, "w"), indent=1)
+    print("wrote %s" % path)
 
 
 def main():

@@ -167,8 +167,17 @@ class Environment:
     def render(self, fps=10):
         return False  # renderer out of scope
 
-    def save_results(self):
-        raise NotImplementedError("Saver is out of scope of this build (SURVEY.md section 2 row 16)")
+    def save_results(self, main_folder="experiments"):
+        """environment.py:233-256: brains + parameters + results.json + settings.json in the reference's layout."""
+        from ..Helpers.saver import SavedAgent, Saver
+        settings = {"Update interval": self.tracker.update_interval, "Width": self.width, "Height": self.height,
+                    "Max agents": self.max_agents, "Families": self.static_families}
+        if self.static_families:
+            agents = [SavedAgent(g, b) for g, b in enumerate(self.brains)]
+        else:  # the brains the best agents descend from (inference-time copies share their weights)
+            bb = self.worlds.s["best_brain"][0].cpu().numpy()
+            agents = [SavedAgent(int(self.max_gene), self.brains[int(b)]) for b in bb]
+        return Saver(main_folder, google_colab=self.google_colab).save(agents, self.static_families, self.tracker.results, settings)
 
     # -- host mirror of world 0 --------------------------------------------------------------------------------------
     def _refresh(self, after):

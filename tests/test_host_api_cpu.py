@@ -51,3 +51,29 @@ def test_trainer_tester_environment_signatures_match_the_reference():
                         "limit_reproduction", "incentivize_killing"]
     d = inspect.signature(reinlife_amd.trainer).parameters
     assert d["n_episodes"].default == 10_000 and d["max_agents"].default == 100 and d["save"].default is True
+
+
+def test_saver_writes_the_reference_layout_and_loadable_state_dicts(tmp_path, monkeypatch):
+    """saver.py:58-194 layout; the .pt files carry the reference's state-dict keys, parameters_*.json the reference's scalar
+    brain attributes (tests/golden/brain_param_keys.json, recorded from the reference's brains)."""
+    import torch
+    from reinlife_amd import Models
+    from reinlife_amd.Helpers.saver import SavedAgent, Saver
+    monkeypatch.chdir(tmp_path)
+    brains = [Models.PERD3QN(), Models.DQN(max_epi=100), Models.PPO(), Models.D3QN()]
+    results = {"Avg Population Size": {0: [1.5]}, "Avg Number of Populations": [2.0]}
+    exp = Saver("experiments").save([SavedAgent(g, b) for g, b in enumerate(brains)], True, results, {"Width": 30})
+    exp2 = Saver("experiments").save([SavedAgent(g, b) for g, b in enumerate(brains[:2])], False, results, {"Width": 30})
+    assert exp.endswith("_V1") and exp2.endswith("_V2")
+    keys = json.load(open(os.path.join(golden_io.GOLDEN_DIR, "state_dict_keys.json")))
+    want_params = json.load(open(os.path.join(golden_io.GOLDEN_DIR, "brain_param_keys.json")))
+    for g, b in enumerate(brains):
+        sd = torch.load(os.path.join(exp, b.method, "brain_gene_%d.pt" % g))
+        assert [[k, list(v.shape)] for k, v in sd.items()] == keys[b.method]
+        fresh = type(b)(load_model=os.path.join(exp, b.method, "brain_gene_%d.pt" % g))  # load_model= round trip
+        assert all(torch.equal(x, y) for x, y in zip(fresh._net().state_dict().values(), b._net().state_dict().values()))
+        params = json.load(open(os.path.join(exp, b.method, "parameters_gene_%d.json" % g)))
+        for k, v in want_params[b.method].items():
+            assert k in params and (params[k] == v or k in ("load_model",)), (b.method, k, params.get(k), v)
+    assert os.path.exists(os.path.join(exp2, "PERD3QN", "brain_1.pt")) and os.path.exists(os.path.join(exp2, "DQN", "parameters_1.json"))
+    assert json.load(open(os.path.join(exp, "results.json")))["Avg Number of Populations"] == [2.0]
