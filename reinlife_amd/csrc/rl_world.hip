@@ -145,6 +145,17 @@ __host__ __device__ inline size_t carve(Smem& s, char* base, int Cp, int cap, in
 // ---------------------------------------------------------------------------------------------------------------
 __device__ inline int lane_id() { return threadIdx.x & 63; }
 
+// The kernel argument block (KParams is the only kernel parameter, so it starts at offset 0 of the kernarg segment), made
+// opaque so that every use site re-reads the few pointers it needs with s_load instead of keeping all ~45 pointers alive
+// from kernel entry to the final store (which spilled >150 SGPRs into VGPR lanes).
+struct KParams;
+__device__ inline const KParams* kernargs()
+{
+    const void* q = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));
+    return (const KParams*)q;
+}
+
 // Workgroup barrier for LDS-only communication.  lds_barrier() is a full workgroup fence: it emits
 // s_waitcnt vmcnt(0), which on gfx950 also waits for every outstanding global STORE (observation rows, outputs) -- an
 // HBM write round trip (~1 us) at each of the ~40 barriers of a tick.  Threads of these kernels only ever exchange data
@@ -255,21 +266,22 @@ template <int T>
 __device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
 {
     const int tid = threadIdx.x;
+    const KParams* q = kernargs();
     const size_t b = (size_t)w * p.cap;
-    const uint8_t* gt = p.st.cell_type + (size_t)w * p.C;
+    const uint8_t* gt = q->st.cell_type + (size_t)w * p.C;
     // ---- issue EVERY global load first (one HBM round trip): nothing below depends on n_agents until the LDS writes.
     // Slot `tid` of the agent arrays is read unconditionally (inside the allocation; ignored beyond n_agents).
-    n0 = p.st.n_agents[w];
+    n0 = q->st.n_agents[w];
     int sc_val = 0;
-    if (tid == S_TICK) sc_val = p.st.tick[w];
-    else if (tid == S_EPOCH) sc_val = p.st.epoch[w];
-    else if (tid == S_NEXT_UID) sc_val = p.st.next_uid[w];
-    else if (tid == S_MAX_GENE) sc_val = p.st.max_gene[w];
+    if (tid == S_TICK) sc_val = q->st.tick[w];
+    else if (tid == S_EPOCH) sc_val = q->st.epoch[w];
+    else if (tid == S_NEXT_UID) sc_val = q->st.next_uid[w];
+    else if (tid == S_MAX_GENE) sc_val = q->st.max_gene[w];
     int bu = -1, bb = 0; double bf = 0.0;
     if (tid < RL_N_BEST) {
-        bu = p.st.best_uid[(size_t)w * RL_N_BEST + tid];
-        bf = p.st.best_fit[(size_t)w * RL_N_BEST + tid];
-        bb = p.st.best_brain[(size_t)w * RL_N_BEST + tid];
+        bu = q->st.best_uid[(size_t)w * RL_N_BEST + tid];
+        bf = q->st.best_fit[(size_t)w * RL_N_BEST + tid];
+        bb = q->st.best_brain[(size_t)w * RL_N_BEST + tid];
     }
     uint8_t ty[4];
 #pragma unroll
@@ -278,12 +290,12 @@ __device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
     uint8_t r_i = 0, r_j = 0, r_fl = 0; signed char r_act = -1;
     int r_h = 0, r_age = 0, r_ma = 0, r_g = 0, r_b = 0, r_u = 0; double r_f = 0.0;
     if (ha) {
-        r_i = p.st.a_i[b + tid]; r_j = p.st.a_j[b + tid];
-        r_h = p.st.a_health[b + tid]; r_age = p.st.a_age[b + tid]; r_ma = p.st.a_max_age[b + tid];
-        r_g = p.st.a_gene[b + tid]; r_b = p.st.a_brain[b + tid]; r_u = p.st.a_uid[b + tid];
-        r_fl = p.st.a_flags[b + tid];
-        r_act = p.actions ? p.actions[b + tid] : p.st.a_action[b + tid];
-        r_f = p.st.a_fitness[b + tid];
+        r_i = q->st.a_i[b + tid]; r_j = q->st.a_j[b + tid];
+        r_h = q->st.a_health[b + tid]; r_age = q->st.a_age[b + tid]; r_ma = q->st.a_max_age[b + tid];
+        r_g = q->st.a_gene[b + tid]; r_b = q->st.a_brain[b + tid]; r_u = q->st.a_uid[b + tid];
+        r_fl = q->st.a_flags[b + tid];
+        r_act = q->actions ? q->actions[b + tid] : q->st.a_action[b + tid];
+        r_f = q->st.a_fitness[b + tid];
     }
     // ---- LDS initialisation that needs no loaded value
     for (int c = tid; c < p.Cp; c += T) { s.occ[c] = -1; ((unsigned*)s.foodv)[c] = 0u; }
@@ -303,9 +315,9 @@ __device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
     };
     if (ha && tid < n0) put(tid, r_i, r_j, r_h, r_age, r_ma, r_g, r_b, r_u, r_fl, r_act, r_f);
     for (int a = tid + T; a < n0; a += T)
-        put(a, p.st.a_i[b + a], p.st.a_j[b + a], p.st.a_health[b + a], p.st.a_age[b + a], p.st.a_max_age[b + a], p.st.a_gene[b + a],
-            p.st.a_brain[b + a], p.st.a_uid[b + a], p.st.a_flags[b + a], p.actions ? p.actions[b + a] : p.st.a_action[b + a],
-            p.st.a_fitness[b + a]);
+        put(a, q->st.a_i[b + a], q->st.a_j[b + a], q->st.a_health[b + a], q->st.a_age[b + a], q->st.a_max_age[b + a], q->st.a_gene[b + a],
+            q->st.a_brain[b + a], q->st.a_uid[b + a], q->st.a_flags[b + a], q->actions ? q->actions[b + a] : q->st.a_action[b + a],
+            q->st.a_fitness[b + a]);
     RL_MARK(33);
     lds_barrier();
     RL_MARK(34);
@@ -435,7 +447,7 @@ __device__ void write_observations(const KParams& p, Smem& s, int w, int n, floa
 }
 
 // Environment.step up to (not including) the observation pass
-template <int T>
+template <int T, bool LEAN>
 __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
 {
     const int tid = threadIdx.x;
@@ -582,7 +594,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
     if (tid < 64 && !RL_ABL(4)) {
         Placer P;
         placer_init(P, tid < p.nW ? s.occbits[tid] : ~0ull);
-        const bool tape = p.tape.food_k != nullptr;
+        const bool tape = !LEAN && p.tape.food_k != nullptr;
         unsigned xk = 0; double u = 2.0;
         if (tid < RL_FOOD_TRIES) {
             if (tape) { xk = (unsigned)p.tape.food_k[(size_t)w * RL_FOOD_TRIES + tid]; u = p.tape.food_u[(size_t)w * RL_FOOD_TRIES + tid]; }
@@ -626,7 +638,7 @@ __device__ inline void init_newborn(Smem& s, int idx, int cell, int W, int gene,
 }
 
 // Environment.update_env up to (not including) the observation pass.  order[0..n1) is the grid list.
-template <int T>
+template <int T, bool LEAN>
 __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslots, bool fresh_bitmap)
 {
     const int tid = threadIdx.x;
@@ -661,7 +673,7 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
     // gates: eligible agents in list order, one draw each (rank among the eligible = draw index); births are placed
     // sequentially on the occupancy bitmap, the newborns themselves are initialised in parallel afterwards.
     const bool room = n1 <= p.max_agents;
-    const bool tape = p.tape.food_k != nullptr;
+    const bool tape = !LEAN && p.tape.food_k != nullptr;
     const uint32_t epoch = (uint32_t)s.scal[S_EPOCH], tick = (uint32_t)s.scal[S_TICK];
     RL_MARK(13);
     if (!fresh_bitmap) {  // standalone update: rebuild the occupancy bitmap (a fused tick reuses the food phase's)
@@ -954,34 +966,35 @@ template <int T>
 __device__ void store_world(const KParams& p, Smem& s, int w, int n)
 {
     const int tid = threadIdx.x;
+    const KParams* q = kernargs();
     if (RL_ABL(64)) return;
-    uint8_t* gt = p.st.cell_type + (size_t)w * p.C;
+    uint8_t* gt = q->st.cell_type + (size_t)w * p.C;
     if (!RL_ABL(1024)) for (int c = tid; c < p.C; c += T) gt[c] = s.type[c];
     const size_t b = (size_t)w * p.cap;
     if (!RL_ABL(2048))
     for (int k = tid; k < n; k += T) {
         const int a = s.order[k];
         if (!RL_ABL(4096)) {
-        p.st.a_i[b + k] = (uint8_t)(s.pos[a] & 255);
-        p.st.a_j[b + k] = (uint8_t)(s.pos[a] >> 8);
-        p.st.a_flags[b + k] = s.flags[a];
-        p.st.a_action[b + k] = s.action[a];
+        q->st.a_i[b + k] = (uint8_t)(s.pos[a] & 255);
+        q->st.a_j[b + k] = (uint8_t)(s.pos[a] >> 8);
+        q->st.a_flags[b + k] = s.flags[a];
+        q->st.a_action[b + k] = s.action[a];
         }
         if (!RL_ABL(8192)) {
-        p.st.a_health[b + k] = s.health[a];
-        p.st.a_age[b + k] = s.age[a];
-        p.st.a_max_age[b + k] = s.max_age[a];
-        p.st.a_gene[b + k] = s.gene[a];
-        p.st.a_brain[b + k] = s.brain[a];
-        p.st.a_uid[b + k] = s.uid[a];
+        q->st.a_health[b + k] = s.health[a];
+        q->st.a_age[b + k] = s.age[a];
+        q->st.a_max_age[b + k] = s.max_age[a];
+        q->st.a_gene[b + k] = s.gene[a];
+        q->st.a_brain[b + k] = s.brain[a];
+        q->st.a_uid[b + k] = s.uid[a];
         }
-        if (!RL_ABL(16384)) p.st.a_fitness[b + k] = s.fitness[a];
+        if (!RL_ABL(16384)) q->st.a_fitness[b + k] = s.fitness[a];
     }
-    if (tid == 0) p.st.n_agents[w] = n;
+    if (tid == 0) q->st.n_agents[w] = n;
     if (tid < RL_N_BEST && !p.static_families) {
-        p.st.best_uid[(size_t)w * RL_N_BEST + tid] = s.best_uid[tid];
-        p.st.best_fit[(size_t)w * RL_N_BEST + tid] = s.best_fit[tid];
-        p.st.best_brain[(size_t)w * RL_N_BEST + tid] = s.best_brain[tid];
+        q->st.best_uid[(size_t)w * RL_N_BEST + tid] = s.best_uid[tid];
+        q->st.best_fit[(size_t)w * RL_N_BEST + tid] = s.best_fit[tid];
+        q->st.best_brain[(size_t)w * RL_N_BEST + tid] = s.best_brain[tid];
     }
 }
 
@@ -990,7 +1003,9 @@ __device__ int reset_world_lds(const KParams& p, Smem& s, int w, uint32_t epoch)
 
 enum { MODE_STEP = 0, MODE_UPDATE = 1, MODE_TICK = 2, MODE_OBSERVE = 3 };
 
-template <int T, int MODE>
+// LEAN = performance path: no recorded tape, no tracker, no capture outputs (their pointers are known to be null), which
+// lets the compiler drop those parameters and branches (SGPR pressure: the full kernel keeps ~45 pointers alive)
+template <int T, int MODE, bool LEAN>
 __global__ __launch_bounds__(T) void k_world(const KParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1015,7 +1030,7 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
         return;
     }
     if (MODE == MODE_STEP || MODE == MODE_TICK) {
-        if (!RL_ABL(512)) phase_step<T>(p, s, w, n0);
+        if (!RL_ABL(512)) phase_step<T, LEAN>(p, s, w, n0);
         RL_MARK(8);
         build_order<T>(p, s, nslots, S_N1);
         RL_MARK(9);
@@ -1031,13 +1046,13 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
             if (p.so.reward) p.so.reward[b + k] = (float)s.reward[a];
             if (p.so.done) p.so.done[b + k] = (s.flags[a] & RL_F_DEAD) ? 1 : 0;
             if (p.so.src) p.so.src[b + k] = (short)a;
-            if (p.so.age) p.so.age[b + k] = s.age[a];
-            if (p.so.brain) p.so.brain[b + k] = s.brain[a];
+            if (!LEAN && p.so.age) p.so.age[b + k] = s.age[a];
+            if (!LEAN && p.so.brain) p.so.brain[b + k] = s.brain[a];
         }
         if (tid == 0 && p.so.n_acted) p.so.n_acted[w] = n0;
-        if (tid == 0 && p.so.n_post) p.so.n_post[w] = n1;
+        if (!LEAN && tid == 0 && p.so.n_post) p.so.n_post[w] = n1;
         if (tid == 0 && p.so.acted_total && n0) atomicAdd(p.so.acted_total, (unsigned long long)n0);
-        if (p.so.trk_tick && tid < 64) track_world_wave0(p, s, w, n1);
+        if (!LEAN && p.so.trk_tick && tid < 64) track_world_wave0(p, s, w, n1);
         n_cur = n1;
         if (MODE == MODE_STEP) { store_world<T>(p, s, w, n1); return; }
         lds_barrier();
@@ -1048,7 +1063,7 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
     if (MODE == MODE_UPDATE || MODE == MODE_TICK) {
         const int n1 = n_cur;
         RL_MARK(12);
-        if (!RL_ABL(256)) phase_update<T>(p, s, w, n1, nslots, MODE == MODE_TICK);
+        if (!RL_ABL(256)) phase_update<T, LEAN>(p, s, w, n1, nslots, MODE == MODE_TICK);
         RL_MARK(17);
         build_order<T>(p, s, nslots, S_N2);
         RL_MARK(18);
@@ -1231,20 +1246,27 @@ KParams make_params(const rl_world* h)
     return p;
 }
 
+template <int MODE, bool LEAN>
+int launch_world_v(const rl_world* h, const KParams& p, hipStream_t stream)
+{
+    const int blk = pick_block(h);
+    if (blk == 1024)
+        hipLaunchKernelGGL((k_world<1024, MODE, LEAN>), dim3(h->cfg.n_worlds), dim3(1024), h->smem_bytes, stream, p);
+    else if (blk == 512)
+        hipLaunchKernelGGL((k_world<512, MODE, LEAN>), dim3(h->cfg.n_worlds), dim3(512), h->smem_bytes, stream, p);
+    else
+        hipLaunchKernelGGL((k_world<256, MODE, LEAN>), dim3(h->cfg.n_worlds), dim3(256), h->smem_bytes, stream, p);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rl_set_error("world kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
+    return RL_OK;
+}
+
 template <int MODE>
 int launch_world(const rl_world* h, const KParams& p, hipStream_t stream)
 {
     if (int rc = rl_world_prepare_bytes(h->smem_bytes)) return rc;
-    const int blk = pick_block(h);
-    if (blk == 1024)
-        hipLaunchKernelGGL((k_world<1024, MODE>), dim3(h->cfg.n_worlds), dim3(1024), h->smem_bytes, stream, p);
-    else if (blk == 512)
-        hipLaunchKernelGGL((k_world<512, MODE>), dim3(h->cfg.n_worlds), dim3(512), h->smem_bytes, stream, p);
-    else
-        hipLaunchKernelGGL((k_world<256, MODE>), dim3(h->cfg.n_worlds), dim3(256), h->smem_bytes, stream, p);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { rl_set_error("world kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
-    return RL_OK;
+    const bool lean = MODE == MODE_TICK && !p.tape.food_k && !p.so.trk_tick && !p.so.age && !p.so.brain && !p.so.n_post && !p.prof;
+    return lean ? launch_world_v<MODE, true>(h, p, stream) : launch_world_v<MODE, false>(h, p, stream);
 }
 
 // trainer.py:95-96 + entities.py:194-208 for one world per workgroup: wave 0 reserves ring slots per brain (ballots, one
@@ -1348,11 +1370,10 @@ int rl_world_prepare_bytes(size_t bytes)
     if (bytes <= granted) return RL_OK;
     hipError_t e = hipSuccess;
 #define RL_ATTR(K) e = e != hipSuccess ? e : hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    RL_ATTR((k_world<256, MODE_STEP>)) RL_ATTR((k_world<256, MODE_UPDATE>)) RL_ATTR((k_world<256, MODE_TICK>))
-    RL_ATTR((k_world<256, MODE_OBSERVE>)) RL_ATTR((k_reset<256>))
-    RL_ATTR((k_world<512, MODE_TICK>)) RL_ATTR((k_world<512, MODE_STEP>)) RL_ATTR((k_world<512, MODE_UPDATE>)) RL_ATTR((k_world<512, MODE_OBSERVE>))
-    RL_ATTR((k_world<1024, MODE_STEP>)) RL_ATTR((k_world<1024, MODE_UPDATE>)) RL_ATTR((k_world<1024, MODE_TICK>))
-    RL_ATTR((k_world<1024, MODE_OBSERVE>)) RL_ATTR((k_reset<1024>))
+#define RL_ATTR_T(T) RL_ATTR((k_world<T, MODE_STEP, false>)) RL_ATTR((k_world<T, MODE_UPDATE, false>)) RL_ATTR((k_world<T, MODE_TICK, false>)) \
+    RL_ATTR((k_world<T, MODE_TICK, true>)) RL_ATTR((k_world<T, MODE_OBSERVE, false>)) RL_ATTR((k_reset<T>))
+    RL_ATTR_T(256) RL_ATTR_T(512) RL_ATTR_T(1024)
+#undef RL_ATTR_T
 #undef RL_ATTR
     if (e != hipSuccess) { rl_set_error("hipFuncSetAttribute(%zu bytes of LDS) failed: %s", bytes, hipGetErrorString(e)); return RL_E_LAUNCH; }
     granted = bytes;
