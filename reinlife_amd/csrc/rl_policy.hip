@@ -27,6 +27,10 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+// weight pointers come out of a runtime-indexed brain table, which makes them generic (flat_load, counted on lgkmcnt AND
+// vmcnt); they always point to device global memory, so say so: global_load + a prefetch ring that survives LDS barriers
+typedef const float __attribute__((address_space(1))) gfloat;
+typedef const f32x4 __attribute__((address_space(1))) gf32x4;
 
 constexpr int kInQuads = 20;     // input layer: K padded to 160 = 2 halves x 20 quads x 4
 constexpr int kHalfK = 80;
@@ -98,9 +102,9 @@ __device__ inline f32x4 load_xq(const float* __restrict__ row, int h, int q)
 // D = prefetch ring depth in K-quad steps: a step is only 4*NT MFMAs (256*NT cycles), an L2 round trip under load is
 // 2-3x that, so D steps of operands are kept in flight.
 template <int TOUT, int NT, int TSTRIDE, int D>
-__device__ inline void layer_in(const float* __restrict__ pw, int lane, int t0, const float* __restrict__ row, f32x16 (&acc)[NT])
+__device__ inline void layer_in(gfloat* __restrict__ pw, int lane, int t0, const float* __restrict__ row, f32x16 (&acc)[NT])
 {
-    const f32x4* p = (const f32x4*)pw + t0 * 64 + lane;
+    gf32x4* p = (gf32x4*)pw + t0 * 64 + lane;
     const int h = lane >> 5;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -153,11 +157,11 @@ __device__ inline void publish_tile(f32x4* lds, int t, int lane, const f32x16& h
 
 // layer_hidden: input = TIN published tiles in LDS; this wave computes output tiles {t0, t0 + TSTRIDE, ...}.
 template <int TIN, int TOUT, int NT, int TSTRIDE, int D>
-__device__ inline void layer_hidden(const float* __restrict__ pw, int lane, int t0, const f32x4* __restrict__ hin, f32x16 (&acc)[NT])
+__device__ inline void layer_hidden(gfloat* __restrict__ pw, int lane, int t0, const f32x4* __restrict__ hin, f32x16 (&acc)[NT])
 {
     constexpr int NS = TIN * 4;  // step s = t*4 + q covers input features 32t + 8q + 4h + e
-    const f32x4* p = (const f32x4*)pw + t0 * 64 + lane;
-    const float* bias = pw + (int64_t)NS * TOUT * 64 * 4 + t0 * 64 + lane;
+    gf32x4* p = (gf32x4*)pw + t0 * 64 + lane;
+    gfloat* bias = pw + (int64_t)NS * TOUT * 64 * 4 + t0 * 64 + lane;
     const float one = lane < 32 ? 1.0f : 0.0f;
     f32x4 a[D][NT], b[2];
 #pragma unroll
@@ -196,20 +200,20 @@ __device__ inline void layer_hidden(const float* __restrict__ pw, int lane, int 
 // narrow head on the VALU, partial over this wave's NT tiles {t0, t0+TSTRIDE, ..}: out[i] = sum_f W[i][f] h[f]
 // (both halves of the wave end with the sum over the wave's features; bias and the cross-wave sum come later)
 template <int NT, int TSTRIDE, int NOUT>
-__device__ inline void head_partial(const float* __restrict__ hw, int h, int t0, const f32x16 (&hin)[NT], float (&out)[NOUT])
+__device__ inline void head_partial(gfloat* __restrict__ hw, int h, int t0, const f32x16 (&hin)[NT], float (&out)[NOUT])
 {
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) out[i] = 0.0f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const float* wp = hw + ((t0 + t * TSTRIDE) * 16 * 2 + h) * NOUT;  // [tile][r][h][NOUT]
+        gfloat* wp = hw + ((t0 + t * TSTRIDE) * 16 * 2 + h) * NOUT;  // [tile][r][h][NOUT]
 #pragma unroll
         for (int rg = 0; rg < 16; rg += 4) {
 #pragma unroll
             for (int r = rg; r < rg + 4; ++r) {
-                const float* w = wp + (r - rg) * 2 * NOUT;
+                gfloat* w = wp + (r - rg) * 2 * NOUT;
                 if (NOUT == 8) {
-                    const f32x4 w0 = *(const f32x4*)w, w1 = *(const f32x4*)(w + 4);
+                    const f32x4 w0 = *(gf32x4*)w, w1 = *(gf32x4*)(w + 4);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { out[i] = fmaf(hin[t][r], w0[i], out[i]); out[4 + i] = fmaf(hin[t][r], w1[i], out[4 + i]); }
                 } else {
@@ -252,7 +256,7 @@ struct PolicyArgs {
 // One launch serves every brain of one kind: the tile space is the concatenation of the brains' 32-row tiles; one
 // 4-wave workgroup per tile.
 template <int KIND>
-__global__ __launch_bounds__(256) void k_policy(const PolicyArgs A)
+__global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const PolicyArgs A)
 {
     constexpr int HID_TILES = KIND == RL_PPO ? 8 : 4;          // tiles of the first hidden layer
     __shared__ __attribute__((aligned(16))) f32x4 lds_h[HID_TILES * 4 * 64];  // published activations (16 / 32 KiB)
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(256) void k_policy(const PolicyArgs A)
             tile -= nt;
         }
         const BrainSlot B = A.b[bi];
-        const float* __restrict__ packed = B.packed;
+        gfloat* __restrict__ packed = (gfloat*)B.packed;
         const int li = tile * 32 + j;
         const bool valid = li < n;
         const int64_t row = valid ? (B.rowlist ? (int64_t)B.rowlist[li] : (int64_t)li) : (B.rowlist ? (int64_t)B.rowlist[tile * 32] : (int64_t)tile * 32);
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(256) void k_policy(const PolicyArgs A)
 #pragma unroll
             for (int i = 0; i < 9; ++i) sum9[i] = ((lds_part[0][j][i] + lds_part[1][j][i]) + lds_part[2][j][i]) + lds_part[3][j][i];
             if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
-                const float* ba = packed + L.ha + 4 * 16 * 2 * 8;
+                gfloat* ba = packed + L.ha + 4 * 16 * 2 * 8;
                 const float bv = packed[L.hb + 4 * 16 * 2 * 1];
                 float adv[8], mean = 0.0f;  // advantage.mean() of the [1,8] tensor == per-row mean when batched
 #pragma unroll
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(256) void k_policy(const PolicyArgs A)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) q[i] = adv[i] + val - mean;
             } else {
-                const float* bq = packed + L.ha + (KIND == RL_DQN ? 2 : 8) * 16 * 2 * 8;
+                gfloat* bq = packed + L.ha + (KIND == RL_DQN ? 2 : 8) * 16 * 2 * 8;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) q[i] = sum9[i] + bq[i];
                 if (KIND == RL_PPO) {
