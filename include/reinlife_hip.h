@@ -171,6 +171,13 @@ int rl_reset_synthetic(rl_world* h, int n_agents, float* obs, void* stream);
 int rl_refill(rl_world* h, int threshold, int n_agents, float* obs, int32_t* refill_count, void* stream);
 int rl_observe(rl_world* h, float* obs, void* stream);
 int rl_step(rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_step_out* out, void* stream);
+/* Environment.step() in two launches, for callers that draw _add_food's random numbers themselves from the reference's
+ * own np.random stream (their count and arguments depend on the post-movement grid, environment.py:763-776):
+ *   rl_step_split  everything up to and including _get_rewards; pre_counts [R][4] = food, poison, super food and empty
+ *                  cells after movement; the outputs except `obs` are produced here
+ *   rl_step_food   _add_food driven by tape->food_k / food_u, then the observation pass into `obs` (state_prime) */
+int rl_step_split(rl_world* h, const int8_t* actions, const rl_step_out* out, int32_t* pre_counts, void* stream);
+int rl_step_food(rl_world* h, const rl_tape* tape, float* obs, void* stream);
 int rl_update(rl_world* h, const rl_tape* tape, const rl_update_out* out, void* stream);
 int rl_tick(rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_step_out* sout,
             const rl_update_out* uout, void* stream);

@@ -5,10 +5,13 @@ Same constructor keywords, `reset() / step() / update_env(n_epi)`, `agents` (row
 `device`, `seed`.  `env.agents` are lightweight views of world 0; the batched fast path is `env.act(n_epi)`, which runs
 Agent.get_action for every agent of every world on the GPU.
 
-reset() of a single world replays Environment.reset's exact np.random draw order on the host (environment.py:133-158,
-741-761; grid.py:69-83), so the same numpy seed gives the same initial world as the reference.  step()/update_env()
-draw from the in-kernel Philox streams (the reference's MT19937 interleaving is reproduced exactly only through recorded
-tapes, see tests/ and DESIGN.md section 4).  The Tracker's statistics are accumulated in the step kernel (Helpers/tracker.py); Saver / renderer are out of scope.
+Random numbers.  `rng="reference"` (the default for a single world) makes the SAME draws from Python's `random`,
+`np.random` and torch's global generator, in the same order and with the same arguments, as the reference's
+reset() / step() / update_env() (environment.py:133-158, 488-547, 741-776; grid.py:69-83): seed the three generators as
+you would for the reference and the world follows the reference's trajectory bit for bit (tests/test_hip_seed_compat.py
+replays the golden traces from their seeds alone).  The draws of _add_food depend on the grid after movement, so a step
+is two launches (rl_step_split -> host draws -> rl_step_food).  `rng="philox"` (the default and only choice for
+n_worlds > 1) draws inside the kernels from counter-based Philox streams keyed by `seed`.  The Tracker's statistics are accumulated in the step kernel (Helpers/tracker.py); Saver / renderer are out of scope.
 """
 import numpy as np
 import torch
@@ -87,7 +90,7 @@ class Environment:
     def __init__(self, width=30, height=30, brains=None, grid_size=16, max_agents=50, update_interval=500, print_results=True,
                  static_families=True, interactive_results=False, google_colab=False, training=True, save=False,
                  pastel_colors=False, limit_reproduction=False, incentivize_killing=True, *, n_worlds=1, device="cuda:0",
-                 seed=0):
+                 seed=0, rng=None):
         if not brains:
             raise ValueError("Environment needs a non-empty list of brains")
         self.width, self.height = width, height
@@ -105,6 +108,9 @@ class Environment:
         self.observation_space = 153
         self.n_worlds = n_worlds
         self.device = device
+        self.rng = rng or ("reference" if n_worlds == 1 else "philox")
+        if self.rng not in ("reference", "philox") or (self.rng == "reference" and n_worlds != 1):
+            raise ValueError("rng must be 'reference' (single world only) or 'philox'")
         self.best_agents = []
         self.worlds = DeviceWorlds(n_worlds=n_worlds, width=width, height=height, max_agents=max_agents,
                                    n_brains=len(brains), static_families=static_families,
@@ -154,15 +160,84 @@ class Environment:
             full[0] = self._actions_host
             self.worlds.set_actions(full)
             self._actions_dirty = False
-        self.worlds.step()
+        if self.rng == "reference":
+            nf, npo, ns, ne = self.worlds.step_split()[0].tolist()
+            self.worlds.step_food(self.worlds.make_tape([self._draw_add_food(nf, npo, ns, ne)]))
+        else:
+            self.worlds.step()
         self._refresh(after="step")
 
     def update_env(self, n_epi=0):
         """environment.py:188-215"""
         if self.training:
             self.tracker.update_results(self.agents, n_epi)
-        self.worlds.update()
-        self._refresh(after="update")
+        if self.rng == "reference":
+            tape, produced = self._draw_update()
+            self.worlds.update(self.worlds.make_tape([tape]))
+            self._refresh(after="update")
+            if produced and not self.static_families:  # Agent.mutate_brain (entities.py:210-213) draws torch.randn
+                new = np.nonzero(self._host["a_gene"] == self.max_gene)[0]
+                if len(new) and self.brains[int(self._host["a_brain"][new[0]])].method == "PERD3QN":
+                    torch.randn((128, 153))  # PERD3QN.py:127-130; brains are shared by index here, only the stream advances
+        else:
+            self.worlds.update()
+            self._refresh(after="update")
+
+    # -- the reference's random draws, made on the host from the global generators (rng="reference") -----------
+    def _draw_add_food(self, n_food, n_poison, n_super, n_empty):
+        """_add_food (environment.py:763-776) -> Grid.set_random (grid.py:69-83): randint(0, #empty) then random(), nothing
+        when the grid is full (randint raises before drawing)."""
+        C = self.width * self.height
+        k = np.zeros(_lib.FOOD_TRIES, np.int32)
+        u = np.full(_lib.FOOD_TRIES, 2.0)
+        for tries, enabled, p in (((0, 1, 2), n_food <= C / 10, 0.2), ((3, 4, 5), n_poison <= C / 20, 0.2), ((6,), n_super == 0, 1.0)):
+            if not enabled:
+                continue
+            for t in tries:
+                if n_empty == 0:
+                    continue
+                k[t] = np.random.randint(0, n_empty)
+                u[t] = np.random.random()
+                n_empty -= u[t] < p
+        return {"food_k": k, "food_u": u, "repro_u": [], "birth_k": [], "produce_u": 0.0, "produce_choice": 0}
+
+    def _draw_update(self):
+        """_reproduce / _produce (environment.py:488-547) over the post-step agent list (host mirror)."""
+        import random
+        h = self._host
+        n1 = len(h["a_age"])
+        n_empty = int((self.grid == _lib.EMPTY).sum())
+        repro_u, birth_k = [], []
+        produce_u, choice, produced = 0.0, 0, False
+
+        def place():
+            nonlocal n_empty
+            if n_empty == 0:
+                return False
+            birth_k.append(np.random.randint(0, n_empty))
+            np.random.random()  # the p=1 coin
+            n_empty -= 1
+            return True
+
+        if n1 <= self.max_agents:
+            for a in range(n1):
+                if (h["a_flags"][a] & (_lib.F_DEAD | _lib.F_REPRODUCED)) or h["a_age"][a] <= 5:
+                    continue
+                r = random.random()
+                repro_u.append(r)
+                if r > 0.95:
+                    place()
+            produce_u = random.random()
+            if produce_u > 0.95:
+                if self.static_families:
+                    genes = set([int(g) for g in h["a_gene"]])
+                    not_alive = list(set(range(len(self.brains))).difference(genes))
+                    choice = random.choice(not_alive) if not_alive else random.choice([x for x in range(len(self.brains))])
+                else:
+                    choice = random.choice(range(_lib.N_BEST))
+                produced = place()
+        return ({"food_k": np.zeros(_lib.FOOD_TRIES, np.int32), "food_u": np.zeros(_lib.FOOD_TRIES), "repro_u": repro_u,
+                 "birth_k": birth_k, "produce_u": produce_u, "produce_choice": choice}, produced)
 
     def render(self, fps=10):
         return False  # renderer out of scope

@@ -71,6 +71,8 @@ ABI = [
     ("rl_refill", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
     ("rl_observe", C.c_int, [_P, _P, _P]),
     ("rl_step", C.c_int, [_P, _P, C.POINTER(Tape), C.POINTER(StepOut), _P]),
+    ("rl_step_split", C.c_int, [_P, _P, C.POINTER(StepOut), _P, _P]),
+    ("rl_step_food", C.c_int, [_P, C.POINTER(Tape), _P, _P]),
     ("rl_update", C.c_int, [_P, C.POINTER(Tape), C.POINTER(UpdateOut), _P]),
     ("rl_tick", C.c_int, [_P, _P, C.POINTER(Tape), C.POINTER(StepOut), C.POINTER(UpdateOut), _P]),
     ("rl_tick_refill", C.c_int, [_P, _P, C.POINTER(StepOut), C.POINTER(UpdateOut), C.c_int, C.c_int, _P, _P]),

@@ -11,6 +11,8 @@
 size_t rl_world_smem_bytes(int cpad, int cap, int hash);
 int rl_world_block();
 int rl_world_launch_step(rl_world*, const int8_t*, const rl_tape*, const rl_step_out*, hipStream_t);
+int rl_world_launch_step_split(rl_world*, const int8_t*, const rl_step_out*, int32_t*, hipStream_t);
+int rl_world_launch_step_food(rl_world*, const rl_tape*, float*, hipStream_t);
 int rl_world_launch_update(rl_world*, const rl_tape*, const rl_update_out*, hipStream_t);
 int rl_world_launch_tick(rl_world*, const int8_t*, const rl_tape*, const rl_step_out*, const rl_update_out*, int, int, int32_t*, hipStream_t);
 int rl_world_launch_observe(const rl_world*, float*, hipStream_t);
@@ -159,6 +161,21 @@ int rl_step(rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_st
     if (!actions) { rl_set_error("rl_step: null actions"); return RL_E_INVALID; }
     if (int rc = check_tape(tape, "rl_step")) return rc;
     return rl_world_launch_step(h, actions, tape, out, (hipStream_t)stream);
+}
+
+int rl_step_split(rl_world* h, const int8_t* actions, const rl_step_out* out, int32_t* pre_counts, void* stream)
+{
+    RL_CHECK_BOUND("rl_step_split")
+    if (!actions || !pre_counts) { rl_set_error("rl_step_split: null argument"); return RL_E_INVALID; }
+    if (int rc = check_step_out(out, "rl_step_split")) return rc;
+    return rl_world_launch_step_split(h, actions, out, pre_counts, (hipStream_t)stream);
+}
+
+int rl_step_food(rl_world* h, const rl_tape* tape, float* obs, void* stream)
+{
+    RL_CHECK_BOUND("rl_step_food")
+    if (!tape || !tape->food_k || !tape->food_u) { rl_set_error("rl_step_food: a tape with food_k / food_u is required"); return RL_E_INVALID; }
+    return rl_world_launch_step_food(h, tape, obs, (hipStream_t)stream);
 }
 
 int rl_update(rl_world* h, const rl_tape* tape, const rl_update_out* out, void* stream)

@@ -49,6 +49,8 @@ struct KParams {
     int32_t* err;
     int reset_n_agents, refill_threshold;
     int32_t* refill_count;
+    int split_food;        // MODE_STEP only: stop before _add_food and report the cell counts its draws depend on
+    int32_t* pre_counts;   // [R][4] food, poison, super food, empty cells after movement (split_food)
     int* lists_counts;       // optional: per-brain row-list counters of this launch's parity (policy work buffer)
     int* lists_counts_zero;  //           the other parity, cleared by block 0 for the next producer
     int* lists;              //           row ids (world*cap + k), [n_brains][list_stride]
@@ -591,6 +593,18 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
     if (ns) atomicAdd(&s.scal[S_NSUPER], ns);
     lds_barrier();
     RL_MARK(6);
+    if (!LEAN && p.split_food) {  // seed-compatible stepping: the host needs these counts to draw exactly like _add_food
+        if (tid < 64) {
+            int ne = tid < p.nW ? __popcll(~s.occbits[tid]) : 0;
+            ne = __builtin_amdgcn_readlane(wave_incl_scan(ne), 63);
+            if (tid == 0 && p.pre_counts) {
+                int32_t* o = p.pre_counts + (size_t)w * 4;
+                o[0] = s.scal[S_NFOOD]; o[1] = s.scal[S_NPOISON]; o[2] = s.scal[S_NSUPER]; o[3] = ne;
+            }
+        }
+        lds_barrier();
+        return;
+    }
     if (tid < 64 && !RL_ABL(4)) {
         Placer P;
         placer_init(P, tid < p.nW ? s.occbits[tid] : ~0ull);
@@ -1001,7 +1015,7 @@ __device__ void store_world(const KParams& p, Smem& s, int w, int n)
 template <int T>
 __device__ int reset_world_lds(const KParams& p, Smem& s, int w, uint32_t epoch);
 
-enum { MODE_STEP = 0, MODE_UPDATE = 1, MODE_TICK = 2, MODE_OBSERVE = 3 };
+enum { MODE_STEP = 0, MODE_UPDATE = 1, MODE_TICK = 2, MODE_OBSERVE = 3, MODE_FOOD = 4 };
 
 // LEAN = performance path: no recorded tape, no tracker, no capture outputs (their pointers are known to be null), which
 // lets the compiler drop those parameters and branches (SGPR pressure: the full kernel keeps ~45 pointers alive)
@@ -1022,6 +1036,45 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
     int nslots = n0;
     int n_cur = n0;  // length of order[]
 
+    if (MODE == MODE_FOOD) {
+        // second half of a split step (_add_food with a host-drawn tape, then the observation pass, environment.py:185-186)
+        int nf = 0, np_ = 0, ns = 0;
+        for (int c = tid; c < p.Cp; c += T) {
+            const int t = s.type[c];
+            nf += t == RL_FOOD; np_ += t == RL_POISON; ns += t == kSuper;
+            const unsigned long long m = __ballot(t != RL_EMPTY);
+            if (lane_id() == 0) s.occbits[c >> 6] = m;
+        }
+        if (nf) atomicAdd(&s.scal[S_NFOOD], nf);
+        if (np_) atomicAdd(&s.scal[S_NPOISON], np_);
+        if (ns) atomicAdd(&s.scal[S_NSUPER], ns);
+        lds_barrier();
+        if (tid < 64) {
+            Placer P;
+            placer_init(P, tid < p.nW ? s.occbits[tid] : ~0ull);
+            int xk = 0; double u = 2.0;
+            if (tid < RL_FOOD_TRIES && p.tape.food_k) { xk = p.tape.food_k[(size_t)w * RL_FOOD_TRIES + tid]; u = p.tape.food_u[(size_t)w * RL_FOOD_TRIES + tid]; }
+            const bool en = tid < 3 ? (double)s.scal[S_NFOOD] <= (double)p.C / 10.0 : (tid < 6 ? (double)s.scal[S_NPOISON] <= (double)p.C / 20.0 : s.scal[S_NSUPER] == 0);
+            unsigned long long todo = __ballot(tid < RL_FOOD_TRIES && en && u < (tid < 6 ? 0.2 : 1.0));
+            while (todo) {
+                const int t = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                if (P.n_empty <= 0) break;
+                const int k = read_lane(xk, t);
+                if (k < 0 || k >= P.n_empty) { if (tid == 0) flag_error(p, s, 1, w, t, k); continue; }
+                const int cell = placer_take(P, k);
+                if (tid == 0) s.type[cell] = (uint8_t)(t < 3 ? RL_FOOD : (t < 6 ? RL_POISON : kSuper));
+            }
+        }
+        lds_barrier();
+        rebuild_gene_counts<T>(p, s, n0);
+        build_planes<T>(p, s);
+        lds_barrier();
+        write_observations<T>(p, s, w, n0, p.so.obs);
+        uint8_t* gt = p.st.cell_type + (size_t)w * p.C;
+        for (int c = tid; c < p.C; c += T) gt[c] = s.type[c];
+        return;
+    }
     if (MODE == MODE_OBSERVE) {
         rebuild_gene_counts<T>(p, s, n0);
         build_planes<T>(p, s);
@@ -1035,10 +1088,11 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
         build_order<T>(p, s, nslots, S_N1);
         RL_MARK(9);
         const int n1 = s.scal[S_N1];
-        build_planes<T>(p, s);
+        const bool split = !LEAN && MODE == MODE_STEP && p.split_food;  // observation pass comes with the food half
+        if (!split) build_planes<T>(p, s);
         lds_barrier();
         RL_MARK(10);
-        write_observations<T>(p, s, w, n1, p.so.obs);
+        if (!split) write_observations<T>(p, s, w, n1, p.so.obs);
         RL_MARK(11);
         const size_t b = (size_t)w * p.cap;
         for (int k = tid; k < n1; k += T) {
@@ -1371,7 +1425,7 @@ int rl_world_prepare_bytes(size_t bytes)
     hipError_t e = hipSuccess;
 #define RL_ATTR(K) e = e != hipSuccess ? e : hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 #define RL_ATTR_T(T) RL_ATTR((k_world<T, MODE_STEP, false>)) RL_ATTR((k_world<T, MODE_UPDATE, false>)) RL_ATTR((k_world<T, MODE_TICK, false>)) \
-    RL_ATTR((k_world<T, MODE_TICK, true>)) RL_ATTR((k_world<T, MODE_OBSERVE, false>)) RL_ATTR((k_reset<T>))
+    RL_ATTR((k_world<T, MODE_TICK, true>)) RL_ATTR((k_world<T, MODE_OBSERVE, false>)) RL_ATTR((k_world<T, MODE_FOOD, false>)) RL_ATTR((k_reset<T>))
     RL_ATTR_T(256) RL_ATTR_T(512) RL_ATTR_T(1024)
 #undef RL_ATTR_T
 #undef RL_ATTR
@@ -1388,6 +1442,23 @@ int rl_world_launch_step(rl_world* h, const int8_t* actions, const rl_tape* tape
     if (tape) p.tape = *tape;
     if (out) p.so = *out;
     return launch_world<MODE_STEP>(h, p, st);
+}
+int rl_world_launch_step_split(rl_world* h, const int8_t* actions, const rl_step_out* out, int32_t* pre_counts, hipStream_t st)
+{
+    KParams p = make_params(h);
+    set_list_production(h, p, false);
+    p.actions = actions;
+    if (out) p.so = *out;
+    p.split_food = 1; p.pre_counts = pre_counts;
+    return launch_world<MODE_STEP>(h, p, st);
+}
+int rl_world_launch_step_food(rl_world* h, const rl_tape* tape, float* obs, hipStream_t st)
+{
+    KParams p = make_params(h);
+    set_list_production(h, p, false);
+    if (tape) p.tape = *tape;
+    p.so.obs = obs;
+    return launch_world<MODE_FOOD>(h, p, st);
 }
 int rl_world_launch_update(rl_world* h, const rl_tape* tape, const rl_update_out* out, hipStream_t st)
 {

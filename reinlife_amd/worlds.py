@@ -220,6 +220,20 @@ class DeviceWorlds:
                                     C.byref(self._step_out), self._stream()), "rl_step")
         self._ticked = False  # Agent.state of this tick is still the current buffer
 
+    def step_split(self, actions=None):
+        """First half of a split step; returns the device tensor [R,4] (food, poison, super food, empty cells after movement)."""
+        if actions is not None:
+            self.set_actions(actions)
+        if not hasattr(self, "pre_counts"):
+            self.pre_counts = torch.zeros((self.R, 4), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.rl_step_split(self.handle, _ptr(self.actions), C.byref(self._step_out), _ptr(self.pre_counts),
+                                          self._stream()), "rl_step_split")
+        self._ticked = False
+        return self.pre_counts
+
+    def step_food(self, tape):
+        _lib.check(self.lib.rl_step_food(self.handle, C.byref(tape), _ptr(self.obs1), self._stream()), "rl_step_food")
+
     def update(self, tape=None):
         uo = self._next_upd_out()
         _lib.check(self.lib.rl_update(self.handle, C.byref(tape) if tape is not None else None, C.byref(uo), self._stream()),

@@ -11,7 +11,8 @@ def test_environment_protocol_matches_oracle_with_per_agent_actions():
     from reinlife_amd import Environment, Models
     from reinlife_amd.World.environment import host_reset
     brains = [Models.PERD3QN(training=False), Models.DQN(training=False), Models.PPO()]
-    env = Environment(width=30, height=30, brains=brains, max_agents=100, static_families=True, training=False, seed=5)
+    env = Environment(width=30, height=30, brains=brains, max_agents=100, static_families=True, training=False, seed=5,
+                      rng="philox")
     assert env.action_space == 8 and env.observation_space == 153
     np.random.seed(11)
     env.reset()
