@@ -4,18 +4,14 @@ from ..World.environment import Environment
 
 
 def tester(brains, width=30, height=30, max_agents=100, pastel_colors=False, static_families=True, limit_reproduction=False,
-           fps=10, *, n_steps=None, n_worlds=1, device="cuda:0", seed=0):
-    for b in brains:  # tester runs brains greedily (tester.py:57-68 passes n_epi=0 to training=False brains)
-        if hasattr(b, "training"):
-            b.training = False
-            b.epsilon = 0
+           fps=10, *, n_steps=None, n_worlds=1, device="cuda:0", seed=0, rng=None):
     env = Environment(width=width, height=height, grid_size=24, max_agents=max_agents, pastel_colors=pastel_colors,
                       brains=brains, training=False, static_families=static_families, limit_reproduction=limit_reproduction,
-                      n_worlds=n_worlds, device=device, seed=seed)
+                      n_worlds=n_worlds, device=device, seed=seed, rng=rng)
     env.reset()
     step = 0
     while n_steps is None or step < n_steps:
-        env.act(0)
+        env.act(0)  # tester.py:57-68: every brain is asked with n_epi = 0
         env.step()
         env.update_env()
         step += 1

@@ -1,18 +1,19 @@
 """trainer(): same signature, defaults and return value as ReinLife/Helpers/trainer.py:7-107.
 
 The loop is the reference's (get_action -> step -> learn -> update_env, trainer.py:85-99) with get_action batched on the
-GPU through env.act(); learn() is accepted but inference-only brains ignore it (training is outside this build's scope)."""
+GPU through env.act().  A single world (rng="reference", the default for n_worlds == 1) makes every random draw of the
+loop exactly as the reference does, so the same seeds give the same run; replicated worlds draw in-kernel.  learn() is accepted but inference-only brains ignore it (training is outside this build's scope)."""
 from ..World.environment import Environment
 
 
 def trainer(brains, n_episodes=10_000, width=30, height=30, visualize_results=False, google_colab=False, update_interval=500,
             print_results=True, max_agents=100, render=False, static_families=True, training=True, save=True,
-            limit_reproduction=False, incentivize_killing=True, *, n_worlds=1, device="cuda:0", seed=0, per_agent_api=False):
+            limit_reproduction=False, incentivize_killing=True, *, n_worlds=1, device="cuda:0", seed=0, rng=None, per_agent_api=False):
     env = Environment(width=width, height=height, max_agents=max_agents, brains=brains, grid_size=24,
                       static_families=static_families, update_interval=update_interval, print_results=print_results,
                       interactive_results=visualize_results, google_colab=google_colab, training=training,
                       limit_reproduction=limit_reproduction, incentivize_killing=incentivize_killing, n_worlds=n_worlds,
-                      device=device, seed=seed)
+                      device=device, seed=seed, rng=rng)
     env.reset()
     for n_epi in range(n_episodes + 1):
         if per_agent_api:  # the reference's literal per-agent calls (slow; API compatibility)

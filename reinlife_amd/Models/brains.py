@@ -104,9 +104,11 @@ class DQNAgent(_HipBrain):
         if self.training and n_epi % 30 == 0:
             self.epsilon = max(0.01, 0.20 - 0.20 * (n_epi / self.max_epi))
 
-    def get_action(self, state, n_epi):
+    def get_action(self, state, n_epi, out=None):
+        """`out`: this state's Q values when the caller already ran the forward pass in a batch (Environment.act)."""
         self.update_epsilon(n_epi)
-        out = self.forward_batch(np.asarray(state)[None])[0]
+        if out is None:
+            out = self.forward_batch(np.asarray(state)[None])[0]
         coin = random.random()  # forward first, then the coin (DQN.py:134-139)
         if coin < self.epsilon:
             return random.randint(0, 7)
@@ -140,10 +142,10 @@ class _DuelingAgent(_HipBrain):
                 self.epsilon = self.epsilon * self.decay
             self.n_epi = n_epi
 
-    def get_action(self, state, n_epi):
+    def get_action(self, state, n_epi, out=None):
         self.update_epsilon(n_epi)
         if random.random() > self.epsilon:  # D3QN.py:168-172 / PERD3QN.py:205-209
-            q = self.forward_batch(np.asarray(state)[None])[0]
+            q = self.forward_batch(np.asarray(state)[None])[0] if out is None else out
             return int(q.argmax().item())
         return random.choice(list(range(self.output_dim)))
 
@@ -189,7 +191,7 @@ class PPOAgent(_HipBrain):
     def update_epsilon(self, n_epi):
         pass
 
-    def get_action(self, s):
-        prob = self.forward_batch(np.asarray(s)[None])[0].cpu()
+    def get_action(self, s, out=None):
+        prob = (self.forward_batch(np.asarray(s)[None])[0] if out is None else out).cpu()
         a = int(torch.distributions.Categorical(prob).sample().item())  # PPO.py:164-169
         return a if self.load_model else (a, prob)

@@ -73,13 +73,13 @@ class AgentView:
     def done(self):
         return bool(self._env._done_host[self._k]) if self._env._done_host is not None else False
 
-    def get_action(self, n_epi):  # entities.py:215-222
+    def get_action(self, n_epi, out=None):  # entities.py:215-222
         b = self.brain
         if b.method == "PPO":
-            r = b.get_action(self.state)
+            r = b.get_action(self.state, out=out)
             self.action, self.prob = r if isinstance(r, tuple) else (r, None)
         else:
-            self.action = b.get_action(self.state, n_epi)
+            self.action = b.get_action(self.state, n_epi, out=out)
 
     def learn(self, **kwargs):  # entities.py:194-208: training is outside this build's scope
         if self.age > 1:
@@ -145,7 +145,23 @@ class Environment:
         self._refresh(after="update")
 
     def act(self, n_epi=0):
-        """Agent.get_action for every agent of every world, batched on the GPU (trainer.py:88-89)."""
+        """Agent.get_action for every agent of every world, batched on the GPU (trainer.py:88-89).
+
+        rng="reference": one batched forward pass per brain, then the brains' own get_action rules agent by agent in
+        list order, so the epsilon-greedy coins / categorical samples are the reference's generator calls in the
+        reference's order (the forward pass draws nothing, so batching it changes no draw).
+        rng="philox": forward pass, epsilon-greedy / categorical selection and the draws all happen in the kernel."""
+        if self.rng == "reference":
+            idx = self._host["a_brain"].astype(np.int64)
+            outs = [None] * len(self.agents)
+            for b in np.unique(idx):
+                rows = np.nonzero(idx == b)[0]
+                res = self.brains[int(b)].forward_batch(self._state_host[rows], self.device).cpu()
+                for r, o in zip(rows, res):
+                    outs[r] = o
+            for agent, o in zip(self.agents, outs):
+                agent.get_action(n_epi, out=o)
+            return
         for b in self.brains:
             b.update_epsilon(n_epi)
         self._bind_brains()
