@@ -66,11 +66,11 @@ WORKLOADS = {
 }
 
 
-def make_worlds(args, rank, device):
+def make_worlds(args, rank, device, n_worlds=None, world_base=None):
     wl = WORKLOADS[args.workload]
-    dw = DeviceWorlds(n_worlds=args.worlds, width=30, height=30, max_agents=100, n_brains=len(wl["brains"]),
+    dw = DeviceWorlds(n_worlds=n_worlds or args.worlds, width=30, height=30, max_agents=100, n_brains=len(wl["brains"]),
                       static_families=wl["static_families"], seed=args.seed, device=device,
-                      world_base=rank * args.worlds)
+                      world_base=rank * args.worlds if world_base is None else world_base)
     dw.set_brains([(_lib.KIND_BY_METHOD[n], 0.0, pack_brain_weights(_lib.KIND_BY_METHOD[n], brain_weights(n, 100 + k), device))
                    for k, n in enumerate(wl["brains"])])
     dw.reset_synthetic(100)
@@ -80,6 +80,42 @@ def make_worlds(args, rank, device):
 def one_step(dw):
     dw.act()                    # k_bucket + k_policy: Agent.get_action for every agent of every world
     dw.tick_refill(70, 100)     # k_world<TICK>: step + update_env (+ re-generation of worlds below 70 agents)
+
+
+class StreamGroups:
+    """--groups G > 1: the GPU's worlds as G independent DeviceWorlds, each on its own HIP stream, so that one group's
+    policy launch can overlap another group's tick (both kernels are latency-bound at 256 worlds and leave issue slots
+    and HBM idle).  Worlds keep their global ids (world_base), so results do not depend on G."""
+
+    def __init__(self, args, rank, device):
+        G = args.groups
+        if args.worlds % G:
+            raise SystemExit("bench.py: --worlds must be a multiple of --groups")
+        per = args.worlds // G
+        self.streams = [torch.cuda.Stream(device) for _ in range(G)]
+        self.parts = []
+        for g, st in enumerate(self.streams):
+            with torch.cuda.stream(st):
+                self.parts.append(make_worlds(args, rank, device, per, rank * args.worlds + g * per))
+        torch.cuda.synchronize()
+
+    def step(self):
+        for dw, st in zip(self.parts, self.streams):
+            with torch.cuda.stream(st):
+                one_step(dw)
+
+    def counters(self):
+        return (sum(float(dw.acted_total.item()) for dw in self.parts), sum(float(dw.refill_count.item()) for dw in self.parts))
+
+    def zero_counters(self):
+        for dw, st in zip(self.parts, self.streams):
+            with torch.cuda.stream(st):
+                dw.acted_total.zero_()
+                dw.refill_count.zero_()
+
+    def check_error_flag(self):
+        for dw in self.parts:
+            dw.check_error_flag()
 
 
 def cpu_baseline(args, seconds_target=12.0):
@@ -137,6 +173,7 @@ def main():
     ap.add_argument("--worlds", type=int, default=256, help="worlds per GPU")
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=20260928)
+    ap.add_argument("--groups", type=int, default=1, help="split the GPU's worlds into this many stream groups (overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -158,14 +195,24 @@ def main():
     device = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)
 
-    dw = make_worlds(args, rank, device)
+    if args.groups > 1:
+        grp = StreamGroups(args, rank, device)
+        dw = grp.parts[0]
+        step_all = grp.step
+    else:
+        grp = None
+        dw = make_worlds(args, rank, device)
+        step_all = lambda: one_step(dw)  # noqa: E731
     for _ in range(args.warmup):
-        one_step(dw)
+        step_all()
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps, inputs resident in HBM ------------------------------------------------------
-    dw.acted_total.zero_()
-    dw.refill_count.zero_()
+    if grp:
+        grp.zero_counters()
+    else:
+        dw.acted_total.zero_()
+        dw.refill_count.zero_()
     if dist is not None:
         dist.barrier()
         try:  # RCCL prints its banner through C stdio: push it out now so that the JSON line is the LAST line
@@ -176,22 +223,24 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_step(dw)
+        step_all()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    dw.check_error_flag()
+    (grp or dw).check_error_flag()
 
     # the only collective of the job: one RCCL all-reduce of the metric counters over xGMI (reinlife_amd/distributed.py)
-    stats = torch.tensor([float(dw.acted_total.item()), float(dw.refill_count.item())], dtype=torch.float64, device=device)
+    counted = grp.counters() if grp else (float(dw.acted_total.item()), float(dw.refill_count.item()))
+    stats = torch.tensor(counted, dtype=torch.float64, device=device)
     stats, elapsed = reduce_counters(stats, elapsed, dist)
     total_agent_steps, refills = stats.tolist()
 
     # ---- per-kernel durations with HIP events on the launch stream (untimed extra steps) ------------------------------
     roofline, extra = None, {}
     if rank == 0 and not args.no_kernel_timing:
+        # (with --groups G the probe runs group 0 alone: its launches cover worlds/G worlds each)
         # back-to-back launches, no host sync inside the probe (a launch from an idle stream costs ~8 us extra): the event
         # pairs then agree with rocprofv3's per-kernel average (profiles/r01c_kernel_stats.txt)
         n_probe = 60
@@ -213,7 +262,7 @@ def main():
         pol_tflops = per_launch * flop / t_act / 1e12
         traffic = pol_traffic = None  # PMC HBM bytes per launch, measured separately (tools/pmc_traffic.sh, 256 worlds/GPU)
         tpath = os.path.join(ROOT, "profiles", "tick_traffic.json")
-        if os.path.exists(tpath) and args.worlds == 256 and args.workload == "c4":
+        if os.path.exists(tpath) and args.worlds == 256 and args.workload == "c4" and args.groups == 1:
             try:
                 tj = json.load(open(tpath))
                 traffic, pol_traffic = tj.get("hbm_bytes_per_launch"), tj.get("policy_hbm_bytes_per_launch")
@@ -250,7 +299,7 @@ def main():
             "dtype": "f32 policy (v_mfma_f32_32x32x2_f32) / int32+u8 world state / f64 rewards",
             "data": "synthetic",
             "config": {"workload": wl["name"], "worlds_per_gpu": args.worlds, "worlds_total": args.worlds * max(1, world_size),
-                       "grid": "30x30", "max_agents": 100, "brains": wl["brains"], "static_families": wl["static_families"],
+                       "stream_groups": args.groups, "grid": "30x30", "max_agents": 100, "brains": wl["brains"], "static_families": wl["static_families"],
                        "refill_below": 70, "includes_update_env": True,
                        "mean_agents_per_world": round(total_agent_steps / (args.steps * args.worlds * max(1, world_size)), 2),
                        "world_refills": int(refills), "parallelism": "replica-sharded x%d, no data-path collective" % max(1, world_size)},

@@ -331,9 +331,8 @@ __device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
 // share a gene are aggregated first (one CAS + one add per distinct gene per wave instead of per agent): with a
 // handful of families every agent would otherwise hammer the same two LDS words.
 // Must be called by all 64 lanes of the wave; `active` lanes contribute.
-__device__ inline void hash_insert_wave(Smem& s, int mask, bool active, int a, int gene, unsigned add, int agg)
+__device__ inline void hash_insert_wave(Smem& s, int mask, bool active, int a, int gene, unsigned add)
 {
-    (void)agg;
     unsigned long long pending = __ballot(active);
     while (pending) {
         const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)pending) - 1);
@@ -543,7 +542,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
     int alive_local = 0;
     const int n0p = (n0 + 63) & ~63;  // whole waves take part in the gene aggregation
     for (int a = tid; a < n0p; a += T) {
-        if (a >= n0) { hash_insert_wave(s, p.hash_mask, false, 0, 0, 0u, 0); continue; }
+        if (a >= n0) { hash_insert_wave(s, p.hash_mask, false, 0, 0, 0u); continue; }
         const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
         const int tg = s.tgt[a];
         if (tg != cx) {
@@ -558,7 +557,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
         const unsigned alive = (fl & RL_F_DEAD) ? 0u : 1u;
         const unsigned ongrid = (s.aux[a] & AUX_VANISH) ? 0u : 1u;
         alive_local += (int)alive;
-        hash_insert_wave(s, p.hash_mask, true, a, s.gene[a], alive | (ongrid << 16), 0);
+        hash_insert_wave(s, p.hash_mask, true, a, s.gene[a], alive | (ongrid << 16));
     }
     RL_MARK(37);
     if (alive_local) atomicAdd(&s.scal[S_ALIVE], alive_local);
@@ -820,7 +819,7 @@ __device__ void rebuild_gene_counts(const KParams& p, Smem& s, int n)
     for (int k = threadIdx.x; k < np2; k += T) {
         const bool act = k < n;
         const int a = act ? s.order[k] : 0;
-        hash_insert_wave(s, p.hash_mask, act, a, act ? s.gene[a] : 0, 1u << 16, 0);
+        hash_insert_wave(s, p.hash_mask, act, a, act ? s.gene[a] : 0, 1u << 16);
     }
     lds_barrier();
 }
@@ -1335,7 +1334,6 @@ struct CaptureArgs {
 __global__ __launch_bounds__(256) void k_capture(const CaptureArgs A)
 {
     __shared__ int slot[4096];
-    __shared__ int n_tx;
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int n1 = A.so.n_post[w];
     const size_t b = (size_t)w * A.cap;
@@ -1349,7 +1347,6 @@ __global__ __launch_bounds__(256) void k_capture(const CaptureArgs A)
         }
         unsigned long long pos = 0;
         if (lane < A.n_brains && cnt) pos = atomicAdd(A.rp[lane].count, (unsigned long long)cnt);
-        int ntx = 0;
         for (int base = 0; base < n1; base += 64) {
             const int k = base + lane;
             const bool act = k < n1 && A.so.age[b + k] > 1;
@@ -1362,9 +1359,7 @@ __global__ __launch_bounds__(256) void k_capture(const CaptureArgs A)
                 if (lane == bb) pos += (unsigned long long)__popcll(m);
             }
             if (k < n1) slot[k] = myslot;
-            ntx += __popcll(__ballot(act));
         }
-        if (lane == 0) n_tx = ntx;
     }
     lds_barrier();
     for (int k = tid >> 6; k < n1; k += 4) {  // one wave per transition
