@@ -80,17 +80,35 @@ __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_b
 
 __device__ inline f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
-// x quad q of this lane: row j = lane&31, half h = lane>>5 covers k = 80h + 4q + e; k == 153 is the bias input.
-// q is a constant after unrolling, so the two ragged quads cost nothing elsewhere.
-__device__ inline f32x4 load_xq(const float* __restrict__ row, int h, int q)
+// Observation tile in LDS, already in B-operand order: xs[q * kXS + lane] = quad q of lane (row j = lane&31, half
+// h = lane>>5): features k = 80h + 4q + e, with x[153] := 1 (bias input) and x[154..159] := 0.  kXS = 65 (not 64) quads
+// per step so that the staging writes of one row (20 quads, one per step) fall into different banks.
+constexpr int kXS = 65;
+constexpr int kXsQuads = kInQuads * kXS;
+
+// Stage the 32 rows of a tile: wave v loads rows 8v..8v+7, ONE coalesced 612-byte read per row (lane m reads floats
+// 4m..4m+3), instead of every wave gathering 16 bytes per lane from 32 different rows for each of the 20 K-steps
+// (64 cache lines per load instruction, four times over): the input layer was request-bound on the vector L1.
+// `row_of_lane`: observation row id of tile row (lane & 31).
+__device__ inline void stage_x(f32x4* __restrict__ xs, const float* __restrict__ obs, int64_t row_of_lane, int lane, int v)
 {
-    if (q < 18) return *(const f32x4u*)(row + h * kHalfK + 4 * q);
-    if (q == 18) {  // half 0 -> k 72..75; half 1 -> k 152, bias, 0, 0 (reads k 149..152 to stay inside the row)
-        const f32x4 v = *(const f32x4u*)(row + (h ? 149 : 72));
-        return h ? f32x4{v.w, 1.0f, 0.0f, 0.0f} : v;
+    f32x4 val[8];
+    const int lo = (int)(row_of_lane & 0xffffffff), hi = (int)(row_of_lane >> 32);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int jj = 8 * v + rr;
+        const int64_t r = ((int64_t)__builtin_amdgcn_readlane(hi, jj) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, jj);
+        const float* xr = obs + r * RL_OBS_DIM;
+        f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (lane < 38) t = *(const f32x4u*)(xr + 4 * lane);
+        else if (lane == 38) t = f32x4{xr[152], 1.0f, 0.0f, 0.0f};  // k = 152, the bias input, padding
+        val[rr] = t;
     }
-    const f32x4 w = *(const f32x4u*)(row + 76);  // q == 19: half 0 -> k 76..79; half 1 -> padding
-    return h ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : w;
+    if (lane < 40) {
+        const int q = lane < 20 ? lane : lane - 20, hh = lane < 20 ? 0 : 32;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) xs[q * kXS + hh + 8 * v + rr] = val[rr];
+    }
 }
 
 // The packed weights are STEP-major: [K-quad step][output tile][lane][4 floats], so the fragments of one step are
@@ -98,29 +116,35 @@ __device__ inline f32x4 load_xq(const float* __restrict__ row, int h, int q)
 // compiler neither precomputes nor hoists hundreds of 64-bit addresses, and a sched_barrier per step bounds the
 // prefetch distance to exactly one step.
 //
-// layer_in: this wave computes output tiles {t0, t0 + TSTRIDE, ...} (NT of them) of a layer with TOUT tiles.
+// layer_in: this wave computes output tiles {t0, t0 + TSTRIDE, ...} (NT of them) of a layer with TOUT tiles; the
+// B operand comes from the staged observation tile.
 // D = prefetch ring depth in K-quad steps: a step is only 4*NT MFMAs (256*NT cycles), an L2 round trip under load is
 // 2-3x that, so D steps of operands are kept in flight.
 template <int TOUT, int NT, int TSTRIDE, int D>
-__device__ inline void layer_in(gfloat* __restrict__ pw, int lane, int t0, const float* __restrict__ row, f32x16 (&acc)[NT])
+__device__ inline void layer_in(gfloat* __restrict__ pw, int lane, int t0, const f32x4* __restrict__ xs, f32x16 (&acc)[NT])
 {
     gf32x4* p = (gf32x4*)pw + t0 * 64 + lane;
-    const int h = lane >> 5;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    f32x4 a[D][NT], x[D];
+    // two independent accumulator chains per tile (even / odd k of every quad), summed at the end: consecutive MFMAs of
+    // one wave never wait for each other's result
+    f32x16 acc2[NT];
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[t][r] = 0.0f;
+    f32x4 a[D][NT], x[2];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
 #pragma unroll
         for (int t = 0; t < NT; ++t) a[d][t] = p[(d * TOUT + t * TSTRIDE) * 64];
-        x[d] = load_xq(row, h, d);
-    }
+    x[0] = xs[lane];
 #pragma unroll
     for (int q = 0; q < kInQuads; ++q) {
         const int cur = q % D;
-        f32x4 ac[NT], xc = x[cur];
+        f32x4 ac[NT], xc = x[q & 1];
 #pragma unroll
         for (int t = 0; t < NT; ++t) ac[t] = a[cur][t];
         p += TOUT * 64;
@@ -128,14 +152,21 @@ __device__ inline void layer_in(gfloat* __restrict__ pw, int lane, int t0, const
         if (q + D < kInQuads) {  // refill this ring slot with step q + D
 #pragma unroll
             for (int t = 0; t < NT; ++t) a[cur][t] = p[((D - 1) * TOUT + t * TSTRIDE) * 64];
-            x[cur] = load_xq(row, h, q + D);
         }
+        if (q + 1 < kInQuads) x[(q + 1) & 1] = xs[(q + 1) * kXS + lane];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = mfma(ac[t][e], xc[e], acc[t]);
+            for (int t = 0; t < NT; ++t) {
+                if (e & 1) acc2[t] = mfma(ac[t][e], xc[e], acc2[t]);
+                else acc[t] = mfma(ac[t][e], xc[e], acc[t]);
+            }
         __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] += acc2[t][r];
 }
 
 template <int NT>
@@ -164,6 +195,11 @@ __device__ inline void layer_hidden(gfloat* __restrict__ pw, int lane, int t0, c
     gfloat* bias = pw + (int64_t)NS * TOUT * 64 * 4 + t0 * 64 + lane;
     const float one = lane < 32 ? 1.0f : 0.0f;
     f32x4 a[D][NT], b[2];
+    f32x16 acc2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[t][r] = 0.0f;
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
@@ -192,9 +228,16 @@ __device__ inline void layer_hidden(gfloat* __restrict__ pw, int lane, int t0, c
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = mfma(ac[t][e], bc[e], acc[t]);
+            for (int t = 0; t < NT; ++t) {
+                if (e & 1) acc2[t] = mfma(ac[t][e], bc[e], acc2[t]);
+                else acc[t] = mfma(ac[t][e], bc[e], acc[t]);
+            }
         __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] += acc2[t][r];
 }
 
 // narrow head on the VALU, partial over this wave's NT tiles {t0, t0+TSTRIDE, ..}: out[i] = sum_f W[i][f] h[f]
@@ -251,7 +294,17 @@ struct PolicyArgs {
     int cap, world_base;
     const int32_t* tick;      // per world
     const int32_t* epoch;
+#ifdef RL_PHASE_PROFILE
+    long long* prof;          // tuning build: shader-clock stamps of workgroup prof_block, wave 0 (slots 48..)
+    int prof_block;
+#endif
 };
+
+#ifdef RL_PHASE_PROFILE
+#define RL_PMARK(i) do { if (A.prof && (int)blockIdx.x == A.prof_block && threadIdx.x == 0) A.prof[48 + (i)] = (long long)clock64(); } while (0)
+#else
+#define RL_PMARK(i) do { } while (0)
+#endif
 
 // One launch serves every brain of one kind: the tile space is the concatenation of the brains' 32-row tiles; one
 // 4-wave workgroup per tile.
@@ -259,10 +312,12 @@ template <int KIND>
 __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const PolicyArgs A)
 {
     constexpr int HID_TILES = KIND == RL_PPO ? 8 : 4;          // tiles of the first hidden layer
-    __shared__ __attribute__((aligned(16))) f32x4 lds_h[HID_TILES * 4 * 64];  // published activations (16 / 32 KiB)
+    // observation tile (20.3 KiB), then -- after the input layer -- the published activations (16 / 32 KiB)
+    __shared__ __attribute__((aligned(16))) f32x4 lds_h[HID_TILES * 4 * 64 > kXsQuads ? HID_TILES * 4 * 64 : kXsQuads];
     __shared__ float lds_part[4][32][9];                        // per-wave head partials
 
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, v = threadIdx.x >> 6;
+    RL_PMARK(0);
     int ntiles = 0;
     for (int i = 0; i < A.nb; ++i) ntiles += ((A.b[i].count_ptr ? *A.b[i].count_ptr : (int)A.n_rows) + 31) / 32;
     const Layout L = layout_of(KIND);
@@ -280,14 +335,18 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const 
         const int li = tile * 32 + j;
         const bool valid = li < n;
         const int64_t row = valid ? (B.rowlist ? (int64_t)B.rowlist[li] : (int64_t)li) : (B.rowlist ? (int64_t)B.rowlist[tile * 32] : (int64_t)tile * 32);
-        const float* xrow = A.obs + row * RL_OBS_DIM;
+        RL_PMARK(1);
+        stage_x(lds_h, A.obs, row, lane, v);
+        lds_barrier();
+        RL_PMARK(10);
         float part[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) part[i] = 0.0f;
         if (KIND == RL_DQN) {
             f32x16 h1[1], h2[1];
-            layer_in<4, 1, 1, 4>(packed + L.l1, lane, v, xrow, h1);
+            layer_in<4, 1, 1, 4>(packed + L.l1, lane, v, lds_h, h1);
             relu_inplace<1>(h1);
+            lds_barrier();  // every wave is done with the observation tile: its LDS becomes the activation exchange
             publish_tile(lds_h, v, lane, h1[0]);
             lds_barrier();
             if (v < 2) {  // the second hidden layer has 2 output tiles: waves 0 and 1
@@ -301,24 +360,32 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const 
         } else if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
             f32x16 h1[1], h2[1];
             float adv[8], val[1];
-            layer_in<4, 1, 1, 4>(packed + L.l1, lane, v, xrow, h1);
+            layer_in<4, 1, 1, 4>(packed + L.l1, lane, v, lds_h, h1);
+            RL_PMARK(2);
             relu_inplace<1>(h1);  // relu(feature) feeds both branches (PERD3QN.py:200-201)
+            lds_barrier();
             publish_tile(lds_h, v, lane, h1[0]);
             lds_barrier();
+            RL_PMARK(3);
             layer_hidden<4, 4, 1, 1, 4>(packed + L.l2a, lane, v, lds_h, h2);
+            RL_PMARK(4);
             relu_inplace<1>(h2);
             head_partial<1, 1, 8>(packed + L.ha, h, v, h2, adv);
+            RL_PMARK(5);
             layer_hidden<4, 4, 1, 1, 4>(packed + L.l2b, lane, v, lds_h, h2);
+            RL_PMARK(6);
             relu_inplace<1>(h2);
             head_partial<1, 1, 1>(packed + L.hb, h, v, h2, val);
+            RL_PMARK(7);
 #pragma unroll
             for (int i = 0; i < 8; ++i) part[i] = adv[i];
             part[8] = val[0];
         } else {
             f32x16 h1[2], h2[2];
             float q8[8];
-            layer_in<8, 2, 4, 3>(packed + L.l1, lane, v, xrow, h1);   // tiles v and v+4
+            layer_in<8, 2, 4, 3>(packed + L.l1, lane, v, lds_h, h1);   // tiles v and v+4
             relu_inplace<2>(h1);
+            lds_barrier();
             publish_tile(lds_h, v, lane, h1[0]);
             publish_tile(lds_h, v + 4, lane, h1[1]);
             lds_barrier();
@@ -333,6 +400,7 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const 
             for (int i = 0; i < 9; ++i) lds_part[v][j][i] = part[i];
         }
         lds_barrier();
+        RL_PMARK(8);
         if (v == 0 && h == 0) {
             float q[8];
             float sum9[9];
@@ -386,6 +454,7 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const 
                 }
             }
         }
+        RL_PMARK(9);
         lds_barrier();  // lds_h / lds_part are reused by the next tile
     }
 }
@@ -571,6 +640,9 @@ int rl_policy_act_impl(rl_world* h, const rl_brain* brains, int n_brains, const 
         PolicyArgs a{};
         a.obs = obs; a.out = out_q; a.actions = actions; a.seed = h->cfg.seed; a.cap = cap; a.world_base = h->cfg.world_base;
         a.tick = h->st.tick; a.epoch = h->st.epoch;
+#ifdef RL_PHASE_PROFILE
+        a.prof = h->prof; a.prof_block = h->prof_world;
+#endif
         for (int b = 0; b < n_brains; ++b) {
             if (brains[b].kind != kind) continue;
             BrainSlot& s = a.b[a.nb++];
