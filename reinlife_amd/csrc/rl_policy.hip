@@ -11,16 +11,24 @@
 // chain per tile and 4x more waves than one-wave-per-tile, which is what matters at 256 worlds = ~700 tiles on
 // 1024 SIMDs), activations cross waves through LDS once per layer:
 //
-//   * fp32 everywhere (v_mfma_f32_32x32x2_f32: exact f32 fma chains, the 157 TFLOP/s matrix rate of gfx950).
+//   * fp32 results from the bf16 matrix pipe ("3 x bf16"): every f32 operand is split into three bf16 parts
+//     x = hi + mid + lo (8 + 8 + 8 mantissa bits, each part the round-to-nearest bf16 of the remaining residual, so the
+//     three parts carry the whole 24-bit f32 mantissa) and a product is the sum of the six partial products of weight
+//     2^-16 or more (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi), each EXACT in the f32 accumulator of
+//     v_mfma_f32_32x32x16_bf16.  The dropped terms are below 2^-23 relative -- the size of f32's own rounding -- so the
+//     result is f32-grade (measured error vs torch ~1e-6, the bar is 1e-5) at 6 x 32 cycles per 16 k instead of
+//     8 x 64 with v_mfma_f32_32x32x2_f32: 2.7x the f32 matrix rate.  Weights are split once when packed, activations
+//     once where they are produced (observation staging / layer output), so the split costs a few VALU ops per value.
 //   * transposed formulation  H_out[feature][row] = W[feature][k] . H_in[k][row]: the WEIGHTS are the MFMA A operand
 //     and the ACTIVATIONS the B operand.  The 32x32 f32 accumulator layout (lane = row, register r of half h =
-//     feature (r&3) + 8(r>>2) + 4h) is then exactly a B operand of the next layer if K-step (t, r) pairs feature
-//     32t + (r&3) + 8(r>>2) (lanes 0-31) with the same + 4 (lanes 32-63): activations never move, ReLU and bias are
-//     per-register VALU ops / one extra K-step, and the weights are pre-packed so every A fragment is one coalesced
+//     feature (r&3) + 8(r>>2) + 4h) is dtype-independent, so a lane's registers 8c..8c+7 are exactly its 8 B-operand
+//     values of K-chunk (tile, c) of the next layer when the next layer's weights are packed in that k order:
+//     activations are never transposed; the weights are pre-packed so every A fragment is one coalesced
 //     16-byte-per-lane load (rl_policy_pack_weights).
 //   * the narrow heads (8 / 1 outputs) run on the VALU (an MFMA tile would be 75-97 % padding), followed by the
 //     dueling combine / softmax and the epsilon-greedy / categorical draw (Philox) in the same kernel.
 #include "rl_common.h"
+#include <string.h>
 
 namespace {
 
@@ -32,13 +40,16 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef const float __attribute__((address_space(1))) gfloat;
 typedef const f32x4 __attribute__((address_space(1))) gf32x4;
 
-constexpr int kInQuads = 20;     // input layer: K padded to 160 = 2 halves x 20 quads x 4
-constexpr int kHalfK = 80;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kInChunks = 10;    // input layer: K padded to 160 = 10 chunks of 16 (lanes 0-31: k 16c..16c+7, lanes 32-63: +8)
 constexpr int kBiasK = 153;      // x[153] := 1, W[:,153] := bias
 
-// packed sizes (floats)
-__host__ __device__ constexpr int64_t in_layer_floats(int tiles) { return (int64_t)tiles * kInQuads * 64 * 4; }
-__host__ __device__ constexpr int64_t hid_layer_floats(int tin, int tout) { return (int64_t)tout * tin * 4 * 64 * 4 + (int64_t)tout * 64; }
+// packed sizes in 4-byte units: a fragment is 8 bf16 = 16 bytes per lane, three planes (hi, mid, lo) per fragment
+__host__ __device__ constexpr int64_t in_layer_floats(int tiles) { return (int64_t)kInChunks * tiles * 3 * 64 * 4; }
+__host__ __device__ constexpr int64_t hid_layer_floats(int tin, int tout) { return (int64_t)(2 * tin) * tout * 3 * 64 * 4 + (int64_t)tout * 32; }
 __host__ __device__ constexpr int64_t head_floats(int tin, int nout) { return (int64_t)tin * 16 * 2 * nout + nout; }
 
 struct Layout {  // offsets (floats) into a brain's packed buffer
@@ -78,17 +89,42 @@ __device__ inline void lds_barrier() { __syncthreads(); }
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
 
-__device__ inline f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ inline f32x16 mfma(const f32x4& a, const f32x4& b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
-// Observation tile in LDS, already in B-operand order: xs[q * kXS + lane] = quad q of lane (row j = lane&31, half
-// h = lane>>5): features k = 80h + 4q + e, with x[153] := 1 (bias input) and x[154..159] := 0.  kXS = 65 (not 64) quads
-// per step so that the staging writes of one row (20 quads, one per step) fall into different banks.
-constexpr int kXS = 65;
-constexpr int kXsQuads = kInQuads * kXS;
+// x = hi + mid + lo, each the bf16 nearest to what is left (the subtractions are exact in f32)
+__device__ inline void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo)
+{
+    hi = (__bf16)x;
+    const float r1 = x - (float)hi;
+    mid = (__bf16)r1;
+    lo = (__bf16)(r1 - (float)mid);
+}
+
+// the six partial products of one K-chunk, three per accumulator chain (a / b: planes hi, mid, lo)
+__device__ inline void mfma6(const f32x4 (&a)[3], const f32x4 (&b)[3], f32x16& acc, f32x16& acc2)
+{
+    acc2 = mfma(a[0], b[2], acc2);  // hi.lo
+    acc = mfma(a[2], b[0], acc);    // lo.hi
+    acc2 = mfma(a[1], b[1], acc2);  // mid.mid
+    acc = mfma(a[1], b[0], acc);    // mid.hi
+    acc2 = mfma(a[0], b[1], acc2);  // hi.mid
+    acc = mfma(a[0], b[0], acc);    // hi.hi
+}
+
+// Observation tile in LDS, split and already in B-operand order: plane p (hi, mid, lo) holds, for K-chunk c and lane
+// (row j = lane&31, half kh = lane>>5), the 8 bf16 x[j][16c + 8kh + 0..7] as one 16-byte unit at
+// p*kXPlane + (2c + kh)*33 + j, with x[153] := 1 (bias input) and x[154..159] := 0.  Groups are 33 (not 32) units
+// apart so that the staging writes of one row (40 lanes, one 8-byte half unit each) spread over the banks.
+constexpr int kXGroup = 33;
+constexpr int kXPlane = 2 * kInChunks * kXGroup;
+constexpr int kXsUnits = 3 * kXPlane;
 
 // Stage the 32 rows of a tile: wave v loads rows 8v..8v+7, ONE coalesced 612-byte read per row (lane m reads floats
-// 4m..4m+3), instead of every wave gathering 16 bytes per lane from 32 different rows for each of the 20 K-steps
-// (64 cache lines per load instruction, four times over): the input layer was request-bound on the vector L1.
+// 4m..4m+3), instead of every wave gathering 16 bytes per lane from 32 different rows for each K-step (64 cache lines
+// per load instruction, four times over): the input layer was request-bound on the vector L1.
 // `row_of_lane`: observation row id of tile row (lane & 31).
 __device__ inline void stage_x(f32x4* __restrict__ xs, const float* __restrict__ obs, int64_t row_of_lane, int lane, int v)
 {
@@ -104,63 +140,73 @@ __device__ inline void stage_x(f32x4* __restrict__ xs, const float* __restrict__
         else if (lane == 38) t = f32x4{xr[152], 1.0f, 0.0f, 0.0f};  // k = 152, the bias input, padding
         val[rr] = t;
     }
-    if (lane < 40) {
-        const int q = lane < 20 ? lane : lane - 20, hh = lane < 20 ? 0 : 32;
+    if (lane < 40) {  // floats 4m..4m+3 of a row = half (m&1) of the unit of chunk m>>2, k-half (m>>1)&1
+        f32x2* x2 = (f32x2*)xs;
+        const int unit0 = (lane >> 1) * kXGroup + 8 * v, half = lane & 1;
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) xs[q * kXS + hh + 8 * v + rr] = val[rr];
+        for (int rr = 0; rr < 8; ++rr) {
+            bf16x4 ph, pm, pl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { __bf16 a, b, c; split3(val[rr][e], a, b, c); ph[e] = a; pm[e] = b; pl[e] = c; }
+            const int u = (unit0 + rr) * 2 + half;
+            x2[u] = __builtin_bit_cast(f32x2, ph);
+            x2[kXPlane * 2 + u] = __builtin_bit_cast(f32x2, pm);
+            x2[kXPlane * 4 + u] = __builtin_bit_cast(f32x2, pl);
+        }
     }
 }
 
-// The packed weights are STEP-major: [K-quad step][output tile][lane][4 floats], so the fragments of one step are
+// The packed weights are STEP-major: [K-chunk][output tile][plane][lane][8 bf16], so the fragments of one chunk are
 // 1 KiB apart (immediate offsets of one running pointer).  The pointer is made opaque at every step so that the
 // compiler neither precomputes nor hoists hundreds of 64-bit addresses, and a sched_barrier per step bounds the
 // prefetch distance to exactly one step.
 //
 // layer_in: this wave computes output tiles {t0, t0 + TSTRIDE, ...} (NT of them) of a layer with TOUT tiles; the
-// B operand comes from the staged observation tile.
-// D = prefetch ring depth in K-quad steps: a step is only 4*NT MFMAs (256*NT cycles), an L2 round trip under load is
-// 2-3x that, so D steps of operands are kept in flight.
+// B operand comes from the staged observation tile.  D = prefetch ring depth in K-chunks: a chunk is only 6*NT MFMAs
+// (192*NT cycles), an L2 round trip under load is several times that, so D chunks of weights are kept in flight.
 template <int TOUT, int NT, int TSTRIDE, int D>
 __device__ inline void layer_in(gfloat* __restrict__ pw, int lane, int t0, const f32x4* __restrict__ xs, f32x16 (&acc)[NT])
 {
-    gf32x4* p = (gf32x4*)pw + t0 * 64 + lane;
+    gf32x4* p = (gf32x4*)pw + t0 * 3 * 64 + lane;
+    f32x16 acc2[NT];  // second accumulator chain: consecutive MFMAs of one wave do not wait for each other's result
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    // two independent accumulator chains per tile (even / odd k of every quad), summed at the end: consecutive MFMAs of
-    // one wave never wait for each other's result
-    f32x16 acc2[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[t][r] = 0.0f;
-    f32x4 a[D][NT], x[2];
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; acc2[t][r] = 0.0f; }
+    f32x4 a[D][NT][3], x[2][3];
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) a[d][t] = p[(d * TOUT + t * TSTRIDE) * 64];
-    x[0] = xs[lane];
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int q = 0; q < kInQuads; ++q) {
-        const int cur = q % D;
-        f32x4 ac[NT], xc = x[q & 1];
+            for (int pl = 0; pl < 3; ++pl) a[d][t][pl] = p[((d * TOUT + t * TSTRIDE) * 3 + pl) * 64];
+    const int xb = (lane >> 5) * kXGroup + (lane & 31);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) ac[t] = a[cur][t];
-        p += TOUT * 64;
-        asm volatile("" : "+v"(p));
-        if (q + D < kInQuads) {  // refill this ring slot with step q + D
+    for (int pl = 0; pl < 3; ++pl) x[0][pl] = xs[pl * kXPlane + xb];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) a[cur][t] = p[((D - 1) * TOUT + t * TSTRIDE) * 64];
+    for (int c = 0; c < kInChunks; ++c) {
+        const int cur = c % D;
+        f32x4 ac[NT][3], xc[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            xc[pl] = x[c & 1][pl];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ac[t][pl] = a[cur][t][pl];
         }
-        if (q + 1 < kInQuads) x[(q + 1) & 1] = xs[(q + 1) * kXS + lane];
+        p += TOUT * 3 * 64;
+        asm volatile("" : "+v"(p));
+        if (c + D < kInChunks) {  // refill this ring slot with chunk c + D
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (e & 1) acc2[t] = mfma(ac[t][e], xc[e], acc2[t]);
-                else acc[t] = mfma(ac[t][e], xc[e], acc[t]);
-            }
+                for (int pl = 0; pl < 3; ++pl) a[cur][t][pl] = p[(((D - 1) * TOUT + t * TSTRIDE) * 3 + pl) * 64];
+        }
+        if (c + 1 < kInChunks) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) x[(c + 1) & 1][pl] = xs[pl * kXPlane + xb + (c + 1) * 2 * kXGroup];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mfma6(ac[t], xc, acc[t], acc2[t]);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -178,60 +224,74 @@ __device__ inline void relu_inplace(f32x16 (&h)[NT])
         for (int r = 0; r < 16; ++r) h[t][r] = fmaxf(h[t][r], 0.0f);
 }
 
-// Publish this wave's activation tile `t` to the workgroup: lds[(t*4 + q)*64 + lane] = registers 4q..4q+3, i.e.
-// exactly the B-operand quad of K-step (t, q) of the next layer for this lane.
-__device__ inline void publish_tile(f32x4* lds, int t, int lane, const f32x16& h)
+// Publish this wave's activation tile `t` to the workgroup, split: plane p unit (t*2 + c)*64 + lane = registers
+// 8c..8c+7, i.e. exactly the B-operand fragment of K-chunk (t, c) of the next layer for this lane.
+__device__ inline void publish_tile(f32x4* lds, int plane_units, int t, int lane, const f32x16& h)
 {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) lds[(t * 4 + q) * 64 + lane] = f32x4{h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]};
+    for (int c = 0; c < 2; ++c) {
+        bf16x8 ph, pm, pl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { __bf16 x, y, z; split3(h[8 * c + e], x, y, z); ph[e] = x; pm[e] = y; pl[e] = z; }
+        const int u = (t * 2 + c) * 64 + lane;
+        lds[u] = __builtin_bit_cast(f32x4, ph);
+        lds[plane_units + u] = __builtin_bit_cast(f32x4, pm);
+        lds[2 * plane_units + u] = __builtin_bit_cast(f32x4, pl);
+    }
 }
 
-// layer_hidden: input = TIN published tiles in LDS; this wave computes output tiles {t0, t0 + TSTRIDE, ...}.
+// layer_hidden: input = TIN published tiles in LDS (three planes of TIN*128 units); this wave computes output tiles
+// {t0, t0 + TSTRIDE, ...}.  The accumulators start from the bias (packed in accumulator order).
 template <int TIN, int TOUT, int NT, int TSTRIDE, int D>
 __device__ inline void layer_hidden(gfloat* __restrict__ pw, int lane, int t0, const f32x4* __restrict__ hin, f32x16 (&acc)[NT])
 {
-    constexpr int NS = TIN * 4;  // step s = t*4 + q covers input features 32t + 8q + 4h + e
-    gf32x4* p = (gf32x4*)pw + t0 * 64 + lane;
-    gfloat* bias = pw + (int64_t)NS * TOUT * 64 * 4 + t0 * 64 + lane;
-    const float one = lane < 32 ? 1.0f : 0.0f;
-    f32x4 a[D][NT], b[2];
+    constexpr int NS = TIN * 2;        // chunk s = t*2 + c covers input features 32t + (r&3) + 8(r>>2) + 4h, r = 8c..8c+7
+    constexpr int PS = TIN * 2 * 64;   // units per plane
+    gf32x4* p = (gf32x4*)pw + t0 * 3 * 64 + lane;
+    gf32x4* bias = (gf32x4*)(pw + (int64_t)NS * TOUT * 3 * 64 * 4) + (t0 * 2 + (lane >> 5)) * 4;
+    f32x4 a[D][NT][3], b[2][3];
     f32x16 acc2[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[t][r] = 0.0f;
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) a[d][t] = p[(d * TOUT + t * TSTRIDE) * 64];
-    b[0] = hin[lane];
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[d][t][pl] = p[((d * TOUT + t * TSTRIDE) * 3 + pl) * 64];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) b[0][pl] = hin[pl * PS + lane];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-        acc[t] = mfma(bias[t * TSTRIDE * 64], one, acc[t]);  // bias as one extra K-step against a constant-1 input
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bq = bias[t * TSTRIDE * 8 + q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[t][4 * q + e] = bq[e]; acc2[t][4 * q + e] = 0.0f; }
+        }
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int cur = s % D;
-        f32x4 ac[NT];
+        f32x4 ac[NT][3], bc[3];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) ac[t] = a[cur][t];
-        const f32x4 bc = b[s & 1];
-        p += TOUT * 64;
+        for (int pl = 0; pl < 3; ++pl) {
+            bc[pl] = b[s & 1][pl];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ac[t][pl] = a[cur][t][pl];
+        }
+        p += TOUT * 3 * 64;
         asm volatile("" : "+v"(p));
         if (s + D < NS) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) a[cur][t] = p[((D - 1) * TOUT + t * TSTRIDE) * 64];
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[cur][t][pl] = p[(((D - 1) * TOUT + t * TSTRIDE) * 3 + pl) * 64];
         }
-        if (s + 1 < NS) b[(s + 1) & 1] = hin[(s + 1) * 64 + lane];
+        if (s + 1 < NS) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+            for (int pl = 0; pl < 3; ++pl) b[(s + 1) & 1][pl] = hin[pl * PS + (s + 1) * 64 + lane];
+        }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (e & 1) acc2[t] = mfma(ac[t][e], bc[e], acc2[t]);
-                else acc[t] = mfma(ac[t][e], bc[e], acc[t]);
-            }
+        for (int t = 0; t < NT; ++t) mfma6(ac[t], bc, acc[t], acc2[t]);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -312,8 +372,9 @@ template <int KIND>
 __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const PolicyArgs A)
 {
     constexpr int HID_TILES = KIND == RL_PPO ? 8 : 4;          // tiles of the first hidden layer
-    // observation tile (20.3 KiB), then -- after the input layer -- the published activations (16 / 32 KiB)
-    __shared__ __attribute__((aligned(16))) f32x4 lds_h[HID_TILES * 4 * 64 > kXsQuads ? HID_TILES * 4 * 64 : kXsQuads];
+    // split observation tile (31 KiB), then -- after the input layer -- the split published activations (24 / 48 KiB)
+    constexpr int PS = HID_TILES * 2 * 64;  // units per plane of the published activations
+    __shared__ __attribute__((aligned(16))) f32x4 lds_h[3 * PS > kXsUnits ? 3 * PS : kXsUnits];
     __shared__ float lds_part[4][32][9];                        // per-wave head partials
 
     const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, v = threadIdx.x >> 6;
@@ -344,14 +405,14 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const 
         for (int i = 0; i < 9; ++i) part[i] = 0.0f;
         if (KIND == RL_DQN) {
             f32x16 h1[1], h2[1];
-            layer_in<4, 1, 1, 4>(packed + L.l1, lane, v, lds_h, h1);
+            layer_in<4, 1, 1, 3>(packed + L.l1, lane, v, lds_h, h1);
             relu_inplace<1>(h1);
             lds_barrier();  // every wave is done with the observation tile: its LDS becomes the activation exchange
-            publish_tile(lds_h, v, lane, h1[0]);
+            publish_tile(lds_h, PS, v, lane, h1[0]);
             lds_barrier();
             if (v < 2) {  // the second hidden layer has 2 output tiles: waves 0 and 1
                 float q8[8];
-                layer_hidden<4, 2, 1, 1, 4>(packed + L.l2a, lane, v, lds_h, h2);
+                layer_hidden<4, 2, 1, 1, 3>(packed + L.l2a, lane, v, lds_h, h2);
                 relu_inplace<1>(h2);
                 head_partial<1, 1, 8>(packed + L.ha, h, v, h2, q8);
 #pragma unroll
@@ -360,19 +421,19 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const 
         } else if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
             f32x16 h1[1], h2[1];
             float adv[8], val[1];
-            layer_in<4, 1, 1, 4>(packed + L.l1, lane, v, lds_h, h1);
+            layer_in<4, 1, 1, 3>(packed + L.l1, lane, v, lds_h, h1);
             RL_PMARK(2);
             relu_inplace<1>(h1);  // relu(feature) feeds both branches (PERD3QN.py:200-201)
             lds_barrier();
-            publish_tile(lds_h, v, lane, h1[0]);
+            publish_tile(lds_h, PS, v, lane, h1[0]);
             lds_barrier();
             RL_PMARK(3);
-            layer_hidden<4, 4, 1, 1, 4>(packed + L.l2a, lane, v, lds_h, h2);
+            layer_hidden<4, 4, 1, 1, 3>(packed + L.l2a, lane, v, lds_h, h2);
             RL_PMARK(4);
             relu_inplace<1>(h2);
             head_partial<1, 1, 8>(packed + L.ha, h, v, h2, adv);
             RL_PMARK(5);
-            layer_hidden<4, 4, 1, 1, 4>(packed + L.l2b, lane, v, lds_h, h2);
+            layer_hidden<4, 4, 1, 1, 3>(packed + L.l2b, lane, v, lds_h, h2);
             RL_PMARK(6);
             relu_inplace<1>(h2);
             head_partial<1, 1, 1>(packed + L.hb, h, v, h2, val);
@@ -386,8 +447,8 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const 
             layer_in<8, 2, 4, 3>(packed + L.l1, lane, v, lds_h, h1);   // tiles v and v+4
             relu_inplace<2>(h1);
             lds_barrier();
-            publish_tile(lds_h, v, lane, h1[0]);
-            publish_tile(lds_h, v + 4, lane, h1[1]);
+            publish_tile(lds_h, PS, v, lane, h1[0]);
+            publish_tile(lds_h, PS, v + 4, lane, h1[1]);
             lds_barrier();
             layer_hidden<8, 8, 2, 4, 3>(packed + L.l2a, lane, v, lds_h, h2);
             relu_inplace<2>(h2);
@@ -511,36 +572,69 @@ int64_t rl_policy_packed_floats_impl(int kind)
     return layout_of(kind).total;
 }
 
+static inline uint16_t bf16_rne(float f)  // round to nearest even (finite inputs)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_float(uint16_t h)
+{
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline void split3_host(float x, uint16_t (&out)[3])
+{
+    out[0] = bf16_rne(x);
+    const float r1 = x - bf16_to_float(out[0]);
+    out[1] = bf16_rne(r1);
+    out[2] = bf16_rne(r1 - bf16_to_float(out[1]));
+}
+
 static void pack_in_layer(const float* W, const float* b, int n_out, float* dst)
 {
-    // dst[q][t][lane][e] = Wext[32t + (lane&31)][80*(lane>>5) + 4q + e],  Wext[:,153] = bias, Wext[:,154..159] = 0
+    // dst16[c][t][plane][lane][e] = part_plane(Wext[32t + (lane&31)][16c + 8(lane>>5) + e]),  Wext[:,153] = bias,
+    // Wext[:,154..159] = 0
     const int tout = n_out / 32;
-    for (int q = 0; q < kInQuads; ++q)
+    uint16_t* d16 = (uint16_t*)dst;
+    for (int c = 0; c < kInChunks; ++c)
         for (int t = 0; t < tout; ++t)
             for (int lane = 0; lane < 64; ++lane)
-                for (int e = 0; e < 4; ++e) {
-                    const int o = 32 * t + (lane & 31), k = kHalfK * (lane >> 5) + 4 * q + e;
+                for (int e = 0; e < 8; ++e) {
+                    const int o = 32 * t + (lane & 31), k = 16 * c + 8 * (lane >> 5) + e;
                     float v = 0.0f;
                     if (k < 153) v = W[(size_t)o * 153 + k];
                     else if (k == kBiasK) v = b[o];
-                    dst[(((size_t)q * tout + t) * 64 + lane) * 4 + e] = v;
+                    uint16_t parts[3];
+                    split3_host(v, parts);
+                    for (int pl = 0; pl < 3; ++pl) d16[(((((size_t)c * tout + t) * 3 + pl) * 64 + lane) * 8) + e] = parts[pl];
                 }
 }
 static void pack_hidden_layer(const float* W, const float* b, int n_in, int n_out, float* dst)
 {
-    // dst[s = t*4+q][t2][lane][e] = W[32 t2 + (lane&31)][32 t + 8 q + 4 (lane>>5) + e];  then bias[t2][lane]
+    // dst16[s = t*2+c][t2][plane][lane][e] = part_plane(W[32 t2 + (lane&31)][32 t + (r&3) + 8(r>>2) + 4(lane>>5)]), r = 8c + e;
+    // then f32 bias[t2][h][r] = b[32 t2 + (r&3) + 8(r>>2) + 4h] (accumulator order)
     const int tin = n_in / 32, tout = n_out / 32;
+    uint16_t* d16 = (uint16_t*)dst;
     for (int t = 0; t < tin; ++t)
-        for (int q = 0; q < 4; ++q)
+        for (int c = 0; c < 2; ++c)
             for (int t2 = 0; t2 < tout; ++t2)
                 for (int lane = 0; lane < 64; ++lane)
-                    for (int e = 0; e < 4; ++e) {
-                        const int o = 32 * t2 + (lane & 31), k = 32 * t + 8 * q + 4 * (lane >> 5) + e;
-                        dst[((((size_t)t * 4 + q) * tout + t2) * 64 + lane) * 4 + e] = W[(size_t)o * n_in + k];
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = 8 * c + e;
+                        const int o = 32 * t2 + (lane & 31), k = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        uint16_t parts[3];
+                        split3_host(W[(size_t)o * n_in + k], parts);
+                        const size_t sidx = (size_t)t * 2 + c;
+                        for (int pl = 0; pl < 3; ++pl) d16[((((sidx * tout + t2) * 3 + pl) * 64 + lane) * 8) + e] = parts[pl];
                     }
-    float* bias = dst + (size_t)tout * tin * 4 * 64 * 4;
+    float* bias = dst + (size_t)(2 * tin) * tout * 3 * 64 * 4;
     for (int t2 = 0; t2 < tout; ++t2)
-        for (int lane = 0; lane < 64; ++lane) bias[t2 * 64 + lane] = lane < 32 ? b[32 * t2 + lane] : 0.0f;
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) bias[(t2 * 2 + h) * 16 + r] = b[32 * t2 + (r & 3) + 8 * (r >> 2) + 4 * h];
 }
 static void pack_head(const float* W, const float* b, int n_in, int n_out, float* dst)
 {

@@ -54,19 +54,52 @@ def test_philox_matches_oracle_and_known_answers():
         assert list(out) == orc.philox(a[0] * 7919 + 3, a[1] % 5, a[2], a[3], a[4] % 10, a[5])
 
 
+def _bf16_planes_sum(u16, shape):
+    """[..., 3 planes, 64 lanes, 8] bf16 -> the f32 values the three planes add up to."""
+    parts = (u16.astype(np.uint32) << 16).view(np.float32).reshape(shape).astype(np.float64)
+    return parts.sum(axis=-3)
+
+
 @pytest.mark.parametrize("name", ["DQN", "D3QN", "PERD3QN", "PPO"])
-def test_weight_packing_is_a_permutation_with_bias_folded_in(name):
+def test_weight_packing_keeps_every_weight_exactly(name):
+    """rl_policy_pack_weights: MFMA layers are stored as three bf16 planes (hi + mid + lo == the f32 weight, exactly),
+    permuted into fragment order with the input layer's bias folded in as column 153; hidden-layer biases and the VALU
+    heads stay f32.  Every parameter must be recoverable, none duplicated."""
     from oracle import oracle as orc
     lib = _lib.lib()
     kind = _lib.KIND_BY_METHOD[name]
     n = lib.rl_policy_n_params(kind)
     assert n == orc.lib().rlo_policy_n_params(kind)
-    flat = (np.arange(n, dtype=np.float32) + 1.0)
+    # a 24-bit-mantissa pattern per parameter, all distinct and nonzero
+    flat = ((np.arange(n, dtype=np.float64) + 1.0) * (1.0 + 2.0 ** -23) * 2.0 ** -10).astype(np.float32)
+    assert len(np.unique(flat)) == n
     packed = np.zeros(lib.rl_policy_packed_floats(kind), np.float32)
     assert lib.rl_policy_pack_weights(kind, flat.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)) == 0
-    nz = packed[packed != 0]
+    u16 = packed.view(np.uint16)
+    # (hidden width, [(tin, tout, head outputs)...]) per kind, in packed order
+    h1, branches = {"DQN": (128, [(4, 2, 8)]), "D3QN": (128, [(4, 4, 8), (4, 4, 1)]), "PERD3QN": (128, [(4, 4, 8), (4, 4, 1)]),
+                    "PPO": (256, [(8, 8, 8)])}[name]
+    got = []
+    off = 0  # in 4-byte units
+    t1 = h1 // 32
+    cnt = 10 * t1 * 3 * 64 * 4
+    got.append(_bf16_planes_sum(u16[off * 2:(off + cnt) * 2], (10, t1, 3, 64, 8)).reshape(-1))
+    off += cnt
+    for tin, tout, nout in branches:
+        cnt = 2 * tin * tout * 3 * 64 * 4
+        got.append(_bf16_planes_sum(u16[off * 2:(off + cnt) * 2], (2 * tin, tout, 3, 64, 8)).reshape(-1))
+        off += cnt
+        got.append(packed[off:off + 32 * tout].astype(np.float64))       # hidden bias, accumulator order
+        off += 32 * tout
+        cnt = tout * 16 * 2 * nout + nout
+        got.append(packed[off:off + cnt].astype(np.float64))              # VALU head + its bias
+        off += cnt
+    assert off == len(packed)
+    vals = np.concatenate(got)
+    nz = np.sort(vals[vals != 0])
     used = n - (257 if name == "PPO" else 0)          # PPO's value head is not evaluated when acting (PPO.py:164-169)
-    assert len(nz) == used and len(np.unique(nz)) == used
+    want = np.sort(flat[:used].astype(np.float64))   # state-dict order: PPO's unused fc_v comes last
+    assert len(nz) == used and np.array_equal(nz, want)
     assert lib.rl_policy_pack_weights(9, flat.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)) < 0
 
 

@@ -135,7 +135,8 @@ def test_hip_small_and_rect_grids_match_oracle():
 
 
 def test_hip_policy_forward_matches_reference_and_oracle():
-    """fp32 MFMA MLPs vs the reference's torch networks (golden) and the C oracle: 1e-5 (north_star tolerance)."""
+    """3xbf16 split-precision MFMA MLPs (f32-grade) vs the reference's torch networks (golden) and the C oracle: 1e-5
+    (north_star tolerance; the measured difference is ~1e-7)."""
     import torch
     from oracle import oracle as orc
     from reinlife_amd import _lib
@@ -150,6 +151,29 @@ def test_hip_policy_forward_matches_reference_and_oracle():
             np.testing.assert_allclose(out, m[name + "_out"][:n], rtol=0, atol=1e-5, err_msg="%s n=%d vs reference" % (name, n))
             ora = orc.policy_forward(orc.KIND_BY_NAME[name], m[name + "_weights"], m["obs"][:n])
             np.testing.assert_allclose(out, ora, rtol=0, atol=1e-5, err_msg="%s n=%d vs oracle" % (name, n))
+
+
+def test_hip_policy_split_precision_holds_over_the_f32_range():
+    """The bf16 split keeps f32's exponent range and 24-bit mantissa: weights / observations scaled up or down by
+    large factors (activations up to ~1e6, down to ~1e-12) still match the f32 oracle to 1e-5 RELATIVE to the output
+    scale, for the Q-value brains (PPO's softmax output is scale-free; it is checked unscaled above)."""
+    import torch
+    from oracle import oracle as orc
+    from reinlife_amd import _lib
+    from reinlife_amd.worlds import pack_brain_weights, policy_forward
+    m = np.load(golden_io.GOLDEN_DIR + "/models.npz")
+    rng = np.random.RandomState(5)
+    obs = m["obs"][:200].copy()
+    for name in ("DQN", "D3QN", "PERD3QN"):
+        kind = _lib.KIND_BY_METHOD[name]
+        for wscale, xscale in ((40.0, 25.0), (1e-3, 1e-4), (7.0, 1.0)):
+            w = (m[name + "_weights"] * wscale * rng.uniform(0.5, 1.5, size=m[name + "_weights"].shape)).astype(np.float32)
+            x = (obs * xscale).astype(np.float32)
+            out = policy_forward(kind, pack_brain_weights(kind, w), torch.as_tensor(x, device="cuda:0")).cpu().numpy()
+            ora = orc.policy_forward(orc.KIND_BY_NAME[name], w, x)
+            scale = float(np.abs(ora).max())
+            assert np.isfinite(out).all() and scale > 0
+            np.testing.assert_allclose(out / scale, ora / scale, rtol=0, atol=1e-5, err_msg="%s w*%g x*%g" % (name, wscale, xscale))
 
 
 def test_hip_policy_act_over_worlds_matches_oracle():
