@@ -50,7 +50,8 @@ constexpr int kBiasK = 153;      // x[153] := 1, W[:,153] := bias
 // packed sizes in 4-byte units: a fragment is 8 bf16 = 16 bytes per lane, three planes (hi, mid, lo) per fragment
 __host__ __device__ constexpr int64_t in_layer_floats(int tiles) { return (int64_t)kInChunks * tiles * 3 * 64 * 4; }
 __host__ __device__ constexpr int64_t hid_layer_floats(int tin, int tout) { return (int64_t)(2 * tin) * tout * 3 * 64 * 4 + (int64_t)tout * 32; }
-__host__ __device__ constexpr int64_t head_floats(int tin, int nout) { return (int64_t)tin * 16 * 2 * nout + nout; }
+__host__ __device__ constexpr int64_t head_floats(int tin, int nout) { return (int64_t)tin * 2 * 3 * 64 * 4 + nout; }  // fragments + f32 bias
+__host__ __device__ constexpr int64_t head_bias_off(int tin) { return (int64_t)tin * 2 * 3 * 64 * 4; }
 
 struct Layout {  // offsets (floats) into a brain's packed buffer
     int64_t l1, l2a, l2b, ha, hb, total;
@@ -128,30 +129,33 @@ constexpr int kXsUnits = 3 * kXPlane;
 // `row_of_lane`: observation row id of tile row (lane & 31).
 __device__ inline void stage_x(f32x4* __restrict__ xs, const float* __restrict__ obs, int64_t row_of_lane, int lane, int v)
 {
-    f32x4 val[8];
     const int lo = (int)(row_of_lane & 0xffffffff), hi = (int)(row_of_lane >> 32);
+    f32x2* x2 = (f32x2*)xs;
+    const int unit0 = (lane >> 1) * kXGroup + 8 * v, half = lane & 1;  // lane m: floats 4m..4m+3 = half (m&1) of group m>>1
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        const int jj = 8 * v + rr;
-        const int64_t r = ((int64_t)__builtin_amdgcn_readlane(hi, jj) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, jj);
-        const float* xr = obs + r * RL_OBS_DIM;
-        f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (lane < 38) t = *(const f32x4u*)(xr + 4 * lane);
-        else if (lane == 38) t = f32x4{xr[152], 1.0f, 0.0f, 0.0f};  // k = 152, the bias input, padding
-        val[rr] = t;
-    }
-    if (lane < 40) {  // floats 4m..4m+3 of a row = half (m&1) of the unit of chunk m>>2, k-half (m>>1)&1
-        f32x2* x2 = (f32x2*)xs;
-        const int unit0 = (lane >> 1) * kXGroup + 8 * v, half = lane & 1;
+    for (int r0 = 0; r0 < 8; r0 += 4) {  // four rows in flight at a time (registers are shared with the weight ring)
+        f32x4 val[4];
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            bf16x4 ph, pm, pl;
+        for (int rr = 0; rr < 4; ++rr) {
+            const int jj = 8 * v + r0 + rr;
+            const int64_t r = ((int64_t)__builtin_amdgcn_readlane(hi, jj) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, jj);
+            const float* xr = obs + r * RL_OBS_DIM;
+            f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (lane < 38) t = *(const f32x4u*)(xr + 4 * lane);
+            else if (lane == 38) t = f32x4{xr[152], 1.0f, 0.0f, 0.0f};  // k = 152, the bias input, padding
+            val[rr] = t;
+        }
+        if (lane < 40) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { __bf16 a, b, c; split3(val[rr][e], a, b, c); ph[e] = a; pm[e] = b; pl[e] = c; }
-            const int u = (unit0 + rr) * 2 + half;
-            x2[u] = __builtin_bit_cast(f32x2, ph);
-            x2[kXPlane * 2 + u] = __builtin_bit_cast(f32x2, pm);
-            x2[kXPlane * 4 + u] = __builtin_bit_cast(f32x2, pl);
+            for (int rr = 0; rr < 4; ++rr) {
+                bf16x4 ph, pm, pl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { __bf16 a, b, c; split3(val[rr][e], a, b, c); ph[e] = a; pm[e] = b; pl[e] = c; }
+                const int u = (unit0 + r0 + rr) * 2 + half;
+                x2[u] = __builtin_bit_cast(f32x2, ph);
+                x2[kXPlane * 2 + u] = __builtin_bit_cast(f32x2, pm);
+                x2[kXPlane * 4 + u] = __builtin_bit_cast(f32x2, pl);
+            }
         }
     }
 }
@@ -164,43 +168,61 @@ __device__ inline void stage_x(f32x4* __restrict__ xs, const float* __restrict__
 // layer_in: this wave computes output tiles {t0, t0 + TSTRIDE, ...} (NT of them) of a layer with TOUT tiles; the
 // B operand comes from the staged observation tile.  D = prefetch ring depth in K-chunks: a chunk is only 6*NT MFMAs
 // (192*NT cycles), an L2 round trip under load is several times that, so D chunks of weights are kept in flight.
+// Weight prefetch ring of one layer for one wave: D K-chunks of A fragments (3 planes each) in flight.  start() only
+// needs the packed pointer, so it is issued BEFORE the wait that precedes the layer (observation staging, the LDS
+// exchange of the previous layer, the VALU head): the first L2 round trip of every layer overlaps that wait.
 template <int TOUT, int NT, int TSTRIDE, int D>
-__device__ inline void layer_in(gfloat* __restrict__ pw, int lane, int t0, const f32x4* __restrict__ xs, f32x16 (&acc)[NT])
-{
-    gf32x4* p = (gf32x4*)pw + t0 * 3 * 64 + lane;
-    f32x16 acc2[NT];  // second accumulator chain: consecutive MFMAs of one wave do not wait for each other's result
+struct WRing {
+    f32x4 a[D][NT][3];
+    gf32x4* p;
+    __device__ inline void start(gfloat* __restrict__ pw, int lane, int t0)
+    {
+        p = (gf32x4*)pw + t0 * 3 * 64 + lane;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; acc2[t][r] = 0.0f; }
-    f32x4 a[D][NT][3], x[2][3];
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int d = 0; d < D; ++d)
+                for (int pl = 0; pl < 3; ++pl) a[d][t][pl] = p[((d * TOUT + t * TSTRIDE) * 3 + pl) * 64];
+    }
+    // take chunk s out of the ring and refill its slot with chunk s + D (of NS)
+    template <int NS>
+    __device__ inline void next(int s, f32x4 (&ac)[NT][3])
+    {
+        const int cur = s % D;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) a[d][t][pl] = p[((d * TOUT + t * TSTRIDE) * 3 + pl) * 64];
-    const int xb = (lane >> 5) * kXGroup + (lane & 31);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) x[0][pl] = xs[pl * kXPlane + xb];
-#pragma unroll
-    for (int c = 0; c < kInChunks; ++c) {
-        const int cur = c % D;
-        f32x4 ac[NT][3], xc[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            xc[pl] = x[c & 1][pl];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) ac[t][pl] = a[cur][t][pl];
-        }
+            for (int pl = 0; pl < 3; ++pl) ac[t][pl] = a[cur][t][pl];
         p += TOUT * 3 * 64;
         asm volatile("" : "+v"(p));
-        if (c + D < kInChunks) {  // refill this ring slot with chunk c + D
+        if (s + D < NS) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) a[cur][t][pl] = p[(((D - 1) * TOUT + t * TSTRIDE) * 3 + pl) * 64];
         }
+    }
+};
+
+template <int TOUT, int NT, int TSTRIDE, int D>
+__device__ inline void layer_in(WRing<TOUT, NT, TSTRIDE, D>& w, int lane, const f32x4* __restrict__ xs, f32x16 (&acc)[NT])
+{
+    f32x16 acc2[NT];  // second accumulator chain: consecutive MFMAs of one wave do not wait for each other's result
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; acc2[t][r] = 0.0f; }
+    f32x4 x[2][3];
+    const int xb = (lane >> 5) * kXGroup + (lane & 31);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) x[0][pl] = xs[pl * kXPlane + xb];
+#pragma unroll
+    for (int c = 0; c < kInChunks; ++c) {
+        f32x4 ac[NT][3], xc[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) xc[pl] = x[c & 1][pl];
+        w.template next<kInChunks>(c, ac);
         if (c + 1 < kInChunks) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) x[(c + 1) & 1][pl] = xs[pl * kXPlane + xb + (c + 1) * 2 * kXGroup];
@@ -241,22 +263,16 @@ __device__ inline void publish_tile(f32x4* lds, int plane_units, int t, int lane
 }
 
 // layer_hidden: input = TIN published tiles in LDS (three planes of TIN*128 units); this wave computes output tiles
-// {t0, t0 + TSTRIDE, ...}.  The accumulators start from the bias (packed in accumulator order).
+// {t0, t0 + TSTRIDE, ...}.  The accumulators start from the bias (packed in accumulator order, behind the fragments).
 template <int TIN, int TOUT, int NT, int TSTRIDE, int D>
-__device__ inline void layer_hidden(gfloat* __restrict__ pw, int lane, int t0, const f32x4* __restrict__ hin, f32x16 (&acc)[NT])
+__device__ inline void layer_hidden(WRing<TOUT, NT, TSTRIDE, D>& w, gfloat* __restrict__ pw, int lane, int t0,
+                                    const f32x4* __restrict__ hin, f32x16 (&acc)[NT])
 {
     constexpr int NS = TIN * 2;        // chunk s = t*2 + c covers input features 32t + (r&3) + 8(r>>2) + 4h, r = 8c..8c+7
     constexpr int PS = TIN * 2 * 64;   // units per plane
-    gf32x4* p = (gf32x4*)pw + t0 * 3 * 64 + lane;
     gf32x4* bias = (gf32x4*)(pw + (int64_t)NS * TOUT * 3 * 64 * 4) + (t0 * 2 + (lane >> 5)) * 4;
-    f32x4 a[D][NT][3], b[2][3];
+    f32x4 b[2][3];
     f32x16 acc2[NT];
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) a[d][t][pl] = p[((d * TOUT + t * TSTRIDE) * 3 + pl) * 64];
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) b[0][pl] = hin[pl * PS + lane];
 #pragma unroll
@@ -270,22 +286,10 @@ __device__ inline void layer_hidden(gfloat* __restrict__ pw, int lane, int t0, c
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const int cur = s % D;
         f32x4 ac[NT][3], bc[3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            bc[pl] = b[s & 1][pl];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) ac[t][pl] = a[cur][t][pl];
-        }
-        p += TOUT * 3 * 64;
-        asm volatile("" : "+v"(p));
-        if (s + D < NS) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[cur][t][pl] = p[(((D - 1) * TOUT + t * TSTRIDE) * 3 + pl) * 64];
-        }
+        for (int pl = 0; pl < 3; ++pl) bc[pl] = b[s & 1][pl];
+        w.template next<NS>(s, ac);
         if (s + 1 < NS) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) b[(s + 1) & 1][pl] = hin[pl * PS + (s + 1) * 64 + lane];
@@ -300,37 +304,44 @@ __device__ inline void layer_hidden(gfloat* __restrict__ pw, int lane, int t0, c
         for (int r = 0; r < 16; ++r) acc[t][r] += acc2[t][r];
 }
 
-// narrow head on the VALU, partial over this wave's NT tiles {t0, t0+TSTRIDE, ..}: out[i] = sum_f W[i][f] h[f]
-// (both halves of the wave end with the sum over the wave's features; bias and the cross-wave sum come later)
-template <int NT, int TSTRIDE, int NOUT>
-__device__ inline void head_partial(gfloat* __restrict__ hw, int h, int t0, const f32x16 (&hin)[NT], float (&out)[NOUT])
-{
+// Narrow heads (8 / 1 outputs) also run on the matrix pipe: the head's weight rows are the A operand (outputs padded
+// to 32 rows with zeros), the B operand is this wave's own activation registers (a lane's registers 8c..8c+7 are its
+// B fragment of chunk c -- no exchange needed), 12 MFMAs per 32 input features.  A VALU version (16 FMAs per output
+// and input tile, weights fetched inside the loop) took 2-4 k cycles of mostly load latency per head.
+// Result: out[r], r = 0..3 = this wave's partial sum of output 4*(lane>>5) + r for row lane&31.
+template <int NT, int TSTRIDE>
+struct HeadW {
+    f32x4 a[NT][2][3];
+    __device__ inline void start(gfloat* __restrict__ hw, int lane, int t0)
+    {
+        gf32x4* p = (gf32x4*)hw + lane;
 #pragma unroll
-    for (int i = 0; i < NOUT; ++i) out[i] = 0.0f;
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        gfloat* wp = hw + ((t0 + t * TSTRIDE) * 16 * 2 + h) * NOUT;  // [tile][r][h][NOUT]
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int rg = 0; rg < 16; rg += 4) {
-#pragma unroll
-            for (int r = rg; r < rg + 4; ++r) {
-                gfloat* w = wp + (r - rg) * 2 * NOUT;
-                if (NOUT == 8) {
-                    const f32x4 w0 = *(gf32x4*)w, w1 = *(gf32x4*)(w + 4);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { out[i] = fmaf(hin[t][r], w0[i], out[i]); out[4 + i] = fmaf(hin[t][r], w1[i], out[4 + i]); }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NOUT; ++i) out[i] = fmaf(hin[t][r], w[i], out[i]);
-                }
-            }
-            wp += 4 * 2 * NOUT;
-            asm volatile("" : "+v"(wp));
-            __builtin_amdgcn_sched_barrier(0);
-        }
+                for (int pl = 0; pl < 3; ++pl) a[t][c][pl] = p[(((t0 + t * TSTRIDE) * 2 + c) * 3 + pl) * 64];
     }
+};
+
+template <int NT, int TSTRIDE>
+__device__ inline void head_mfma(const HeadW<NT, TSTRIDE>& w, const f32x16 (&hin)[NT], float (&out)[4])
+{
+    f32x16 acc, acc2;
 #pragma unroll
-    for (int i = 0; i < NOUT; ++i) out[i] = out[i] + __shfl_xor(out[i], 32);
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            bf16x8 ph, pm, pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { __bf16 x, y, z; split3(hin[t][8 * c + e], x, y, z); ph[e] = x; pm[e] = y; pl[e] = z; }
+            const f32x4 b[3] = {__builtin_bit_cast(f32x4, ph), __builtin_bit_cast(f32x4, pm), __builtin_bit_cast(f32x4, pl)};
+            mfma6(w.a[t][c], b, acc, acc2);
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = acc[r] + acc2[r];
 }
 
 constexpr int kMaxBrainsPerLaunch = 8;
@@ -368,8 +379,11 @@ struct PolicyArgs {
 
 // One launch serves every brain of one kind: the tile space is the concatenation of the brains' 32-row tiles; one
 // 4-wave workgroup per tile.
-template <int KIND>
-__global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const PolicyArgs A)
+// EARLY = latency variant for launches of a few tiles per CU (256 worlds): every layer's weight ring and head fragments
+// are requested before the wait that precedes the layer (needs 168 VGPRs: 3 waves per SIMD).  !EARLY = throughput
+// variant for dense launches: rings start at their layer, 128 VGPRs, 4 waves per SIMD.
+template <int KIND, bool EARLY>
+__global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : (EARLY ? 3 : 4))) void k_policy(const PolicyArgs A)
 {
     constexpr int HID_TILES = KIND == RL_PPO ? 8 : 4;          // tiles of the first hidden layer
     // split observation tile (31 KiB), then -- after the input layer -- the split published activations (24 / 48 KiB)
@@ -397,68 +411,93 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const 
         const bool valid = li < n;
         const int64_t row = valid ? (B.rowlist ? (int64_t)B.rowlist[li] : (int64_t)li) : (B.rowlist ? (int64_t)B.rowlist[tile * 32] : (int64_t)tile * 32);
         RL_PMARK(1);
-        stage_x(lds_h, A.obs, row, lane, v);
-        lds_barrier();
-        RL_PMARK(10);
-        float part[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) part[i] = 0.0f;
+        // the draw's Philox key needs the world's tick / epoch: fetch them now, not in the epilogue's dependent chain
+        int key_tick = 0, key_epoch = 0;
+        if (A.actions && v == 0 && h == 0) {
+            const int w = (int)(row / A.cap);
+            key_tick = A.tick[w]; key_epoch = A.epoch[w];
+        }
         if (KIND == RL_DQN) {
             f32x16 h1[1], h2[1];
-            layer_in<4, 1, 1, 3>(packed + L.l1, lane, v, lds_h, h1);
+            WRing<4, 1, 1, 3> w1;
+            WRing<2, 1, 1, 3> w2;
+            if (EARLY) w1.start(packed + L.l1, lane, v);
+            stage_x(lds_h, A.obs, row, lane, v);
+            lds_barrier();
+            if (!EARLY) w1.start(packed + L.l1, lane, v);
+            layer_in(w1, lane, lds_h, h1);
+            HeadW<1, 1> wh;
+            if (EARLY && v < 2) { w2.start(packed + L.l2a, lane, v); wh.start(packed + L.ha, lane, v); }
             relu_inplace<1>(h1);
             lds_barrier();  // every wave is done with the observation tile: its LDS becomes the activation exchange
             publish_tile(lds_h, PS, v, lane, h1[0]);
             lds_barrier();
+            float q4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             if (v < 2) {  // the second hidden layer has 2 output tiles: waves 0 and 1
-                float q8[8];
-                layer_hidden<4, 2, 1, 1, 3>(packed + L.l2a, lane, v, lds_h, h2);
+                if (!EARLY) { w2.start(packed + L.l2a, lane, v); wh.start(packed + L.ha, lane, v); }
+                layer_hidden<4>(w2, packed + L.l2a, lane, v, lds_h, h2);
                 relu_inplace<1>(h2);
-                head_partial<1, 1, 8>(packed + L.ha, h, v, h2, q8);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) part[i] = q8[i];
+                head_mfma(wh, h2, q4);
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds_part[v][j][4 * h + r] = q4[r];
         } else if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
             f32x16 h1[1], h2[1];
-            float adv[8], val[1];
-            layer_in<4, 1, 1, 3>(packed + L.l1, lane, v, lds_h, h1);
+            float adv[4], val[4];
+            WRing<4, 1, 1, EARLY ? 3 : 2> w1, w2;
+            HeadW<1, 1> wh;
+            if (EARLY) w1.start(packed + L.l1, lane, v);
+            stage_x(lds_h, A.obs, row, lane, v);
+            lds_barrier();
+            RL_PMARK(10);
+            if (!EARLY) w1.start(packed + L.l1, lane, v);
+            layer_in(w1, lane, lds_h, h1);
             RL_PMARK(2);
+            if (EARLY) { w2.start(packed + L.l2a, lane, v); wh.start(packed + L.ha, lane, v); }
             relu_inplace<1>(h1);  // relu(feature) feeds both branches (PERD3QN.py:200-201)
             lds_barrier();
             publish_tile(lds_h, PS, v, lane, h1[0]);
             lds_barrier();
             RL_PMARK(3);
-            layer_hidden<4, 4, 1, 1, 3>(packed + L.l2a, lane, v, lds_h, h2);
+            if (!EARLY) w2.start(packed + L.l2a, lane, v);
+            layer_hidden<4>(w2, packed + L.l2a, lane, v, lds_h, h2);
             RL_PMARK(4);
+            if (EARLY) w1.start(packed + L.l2b, lane, v);  // the value branch's first chunks arrive while the advantage head runs
+            else wh.start(packed + L.ha, lane, v);
             relu_inplace<1>(h2);
-            head_partial<1, 1, 8>(packed + L.ha, h, v, h2, adv);
+            head_mfma(wh, h2, adv);
+            wh.start(packed + L.hb, lane, v);
             RL_PMARK(5);
-            layer_hidden<4, 4, 1, 1, 3>(packed + L.l2b, lane, v, lds_h, h2);
+            if (!EARLY) w1.start(packed + L.l2b, lane, v);
+            layer_hidden<4>(w1, packed + L.l2b, lane, v, lds_h, h2);
             RL_PMARK(6);
             relu_inplace<1>(h2);
-            head_partial<1, 1, 1>(packed + L.hb, h, v, h2, val);
+            head_mfma(wh, h2, val);
             RL_PMARK(7);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) part[i] = adv[i];
-            part[8] = val[0];
+            for (int r = 0; r < 4; ++r) lds_part[v][j][4 * h + r] = adv[r];
+            if (h == 0) lds_part[v][j][8] = val[0];
         } else {
             f32x16 h1[2], h2[2];
-            float q8[8];
-            layer_in<8, 2, 4, 3>(packed + L.l1, lane, v, lds_h, h1);   // tiles v and v+4
+            float q4[4];
+            WRing<8, 2, 4, 3> w1, w2;
+            HeadW<2, 4> wh;
+            w1.start(packed + L.l1, lane, v);   // tiles v and v+4
+            stage_x(lds_h, A.obs, row, lane, v);
+            lds_barrier();
+            layer_in(w1, lane, lds_h, h1);
+            w2.start(packed + L.l2a, lane, v);
             relu_inplace<2>(h1);
             lds_barrier();
             publish_tile(lds_h, PS, v, lane, h1[0]);
             publish_tile(lds_h, PS, v + 4, lane, h1[1]);
             lds_barrier();
-            layer_hidden<8, 8, 2, 4, 3>(packed + L.l2a, lane, v, lds_h, h2);
+            wh.start(packed + L.ha, lane, v);
+            layer_hidden<8>(w2, packed + L.l2a, lane, v, lds_h, h2);
             relu_inplace<2>(h2);
-            head_partial<2, 4, 8>(packed + L.ha, h, v, h2, q8);
+            head_mfma(wh, h2, q4);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) part[i] = q8[i];
-        }
-        if (h == 0) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) lds_part[v][j][i] = part[i];
+            for (int r = 0; r < 4; ++r) lds_part[v][j][4 * h + r] = q4[r];
         }
         lds_barrier();
         RL_PMARK(8);
@@ -466,10 +505,12 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const 
             float q[8];
             float sum9[9];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) sum9[i] = ((lds_part[0][j][i] + lds_part[1][j][i]) + lds_part[2][j][i]) + lds_part[3][j][i];
+            for (int i = 0; i < 9; ++i)
+                sum9[i] = (i < 8 || KIND == RL_D3QN || KIND == RL_PERD3QN)
+                              ? ((lds_part[0][j][i] + lds_part[1][j][i]) + lds_part[2][j][i]) + lds_part[3][j][i] : 0.0f;
             if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
-                gfloat* ba = packed + L.ha + 4 * 16 * 2 * 8;
-                const float bv = packed[L.hb + 4 * 16 * 2 * 1];
+                gfloat* ba = packed + L.ha + head_bias_off(4);
+                const float bv = packed[L.hb + head_bias_off(4)];
                 float adv[8], mean = 0.0f;  // advantage.mean() of the [1,8] tensor == per-row mean when batched
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { adv[i] = sum9[i] + ba[i]; mean += adv[i]; }
@@ -478,7 +519,7 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) q[i] = adv[i] + val - mean;
             } else {
-                gfloat* bq = packed + L.ha + (KIND == RL_DQN ? 2 : 8) * 16 * 2 * 8;
+                gfloat* bq = packed + L.ha + head_bias_off(KIND == RL_DQN ? 2 : 8);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) q[i] = sum9[i] + bq[i];
                 if (KIND == RL_PPO) {
@@ -499,7 +540,7 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const 
                 }
                 if (A.actions) {
                     const int w = (int)(row / A.cap), k = (int)(row - (int64_t)w * A.cap);
-                    const rl_u4 r = rl_philox4x32(A.seed, (uint32_t)A.epoch[w], (uint32_t)(A.world_base + w), (uint32_t)A.tick[w], RL_SITE_ACT, (uint32_t)k);
+                    const rl_u4 r = rl_philox4x32(A.seed, (uint32_t)key_epoch, (uint32_t)(A.world_base + w), (uint32_t)key_tick, RL_SITE_ACT, (uint32_t)k);
                     const float u = (float)rl_u24(r.x);
                     int a = 0;
                     if (KIND == RL_PPO) {  // Categorical(prob).sample() as inverse CDF
@@ -638,14 +679,20 @@ static void pack_hidden_layer(const float* W, const float* b, int n_in, int n_ou
 }
 static void pack_head(const float* W, const float* b, int n_in, int n_out, float* dst)
 {
-    // dst[t][r][h][i] = W[i][32 t + (r&3) + 8 (r>>2) + 4 h];  then bias[i]
+    // dst16[t][c][plane][lane][e] = part_plane(W[lane&31][32 t + (r&3) + 8(r>>2) + 4(lane>>5)]), r = 8c + e, rows >= n_out
+    // are zero; then f32 bias[n_out]
     const int tin = n_in / 32;
+    uint16_t* d16 = (uint16_t*)dst;
     for (int t = 0; t < tin; ++t)
-        for (int r = 0; r < 16; ++r)
-            for (int h = 0; h < 2; ++h)
-                for (int i = 0; i < n_out; ++i)
-                    dst[(((size_t)t * 16 + r) * 2 + h) * n_out + i] = W[(size_t)i * n_in + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
-    for (int i = 0; i < n_out; ++i) dst[(size_t)tin * 16 * 2 * n_out + i] = b[i];
+        for (int c = 0; c < 2; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int r = 8 * c + e, o = lane & 31, k = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    uint16_t parts[3];
+                    split3_host(o < n_out ? W[(size_t)o * n_in + k] : 0.0f, parts);
+                    for (int pl = 0; pl < 3; ++pl) d16[(((((size_t)t * 2 + c) * 3 + pl) * 64 + lane) * 8) + e] = parts[pl];
+                }
+    for (int i = 0; i < n_out; ++i) dst[head_bias_off(tin) + i] = b[i];
 }
 
 int rl_policy_pack_impl(int kind, const float* sd, float* packed)
@@ -679,16 +726,21 @@ static int policy_grid(int64_t max_rows)
     return (int)blocks;
 }
 
-static int launch_policy(int kind, const PolicyArgs& a, int64_t max_rows, hipStream_t st)
+// expected_rows: how many rows the launch will really process (max_rows only bounds the grid): picks the variant
+static int launch_policy(int kind, const PolicyArgs& a, int64_t max_rows, int64_t expected_rows, hipStream_t st)
 {
     const dim3 grid(policy_grid(max_rows)), block(256);
+    const bool early = expected_rows / 32 <= 6 * 256;  // fewer than ~6 tiles per CU: latency-bound
+#define RL_LAUNCH(K) do { if (early) hipLaunchKernelGGL((k_policy<K, true>), grid, block, 0, st, a); \
+                          else hipLaunchKernelGGL((k_policy<K, false>), grid, block, 0, st, a); } while (0)
     switch (kind) {
-        case RL_DQN: hipLaunchKernelGGL((k_policy<RL_DQN>), grid, block, 0, st, a); break;
-        case RL_D3QN: hipLaunchKernelGGL((k_policy<RL_D3QN>), grid, block, 0, st, a); break;
-        case RL_PERD3QN: hipLaunchKernelGGL((k_policy<RL_PERD3QN>), grid, block, 0, st, a); break;
-        case RL_PPO: hipLaunchKernelGGL((k_policy<RL_PPO>), grid, block, 0, st, a); break;
+        case RL_DQN: RL_LAUNCH(RL_DQN); break;
+        case RL_D3QN: RL_LAUNCH(RL_D3QN); break;
+        case RL_PERD3QN: RL_LAUNCH(RL_PERD3QN); break;
+        case RL_PPO: RL_LAUNCH(RL_PPO); break;
         default: rl_set_error("unknown brain kind %d", kind); return RL_E_INVALID;
     }
+#undef RL_LAUNCH
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rl_set_error("policy kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
     return RL_OK;
@@ -698,7 +750,7 @@ int rl_policy_forward_impl(int kind, const float* packed, const float* obs, int6
 {
     PolicyArgs a{};
     a.nb = 1; a.b[0].packed = packed; a.obs = obs; a.n_rows = n_rows; a.out = out; a.cap = 1;
-    return launch_policy(kind, a, n_rows, st);
+    return launch_policy(kind, a, n_rows, n_rows, st);
 }
 
 // work layout: int counts[2][64] (parity double buffer, zero-initialised once by the caller), then
@@ -730,6 +782,7 @@ int rl_policy_act_impl(rl_world* h, const rl_brain* brains, int n_brains, const 
     }
     // every live agent: populations are bounded by 2*max_agents+1 (environment.py:501 snapshot rule)
     const int64_t bound = (int64_t)R * (int64_t)(2 * h->cfg.max_agents + 2 < cap ? 2 * h->cfg.max_agents + 2 : cap);
+    const int64_t expected = (int64_t)R * h->cfg.max_agents;  // populations hover around max_agents
     for (int kind = RL_DQN; kind <= RL_PPO; ++kind) {
         PolicyArgs a{};
         a.obs = obs; a.out = out_q; a.actions = actions; a.seed = h->cfg.seed; a.cap = cap; a.world_base = h->cfg.world_base;
@@ -742,11 +795,11 @@ int rl_policy_act_impl(rl_world* h, const rl_brain* brains, int n_brains, const 
             BrainSlot& s = a.b[a.nb++];
             s.packed = brains[b].packed; s.rowlist = lists + b * stride; s.count_ptr = counts + b; s.eps = brains[b].epsilon;
             if (a.nb == kMaxBrainsPerLaunch) {
-                if (int rc = launch_policy(kind, a, bound, st)) return rc;
+                if (int rc = launch_policy(kind, a, bound, expected, st)) return rc;
                 a.nb = 0;
             }
         }
-        if (a.nb) if (int rc = launch_policy(kind, a, bound, st)) return rc;
+        if (a.nb) if (int rc = launch_policy(kind, a, bound, expected, st)) return rc;
     }
     return RL_OK;
 }

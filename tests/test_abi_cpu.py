@@ -63,8 +63,7 @@ def _bf16_planes_sum(u16, shape):
 @pytest.mark.parametrize("name", ["DQN", "D3QN", "PERD3QN", "PPO"])
 def test_weight_packing_keeps_every_weight_exactly(name):
     """rl_policy_pack_weights: MFMA layers are stored as three bf16 planes (hi + mid + lo == the f32 weight, exactly),
-    permuted into fragment order with the input layer's bias folded in as column 153; hidden-layer biases and the VALU
-    heads stay f32.  Every parameter must be recoverable, none duplicated."""
+    permuted into fragment order with the input layer's bias folded in as column 153; the other biases stay f32.  Every parameter must be recoverable, none duplicated."""
     from oracle import oracle as orc
     lib = _lib.lib()
     kind = _lib.KIND_BY_METHOD[name]
@@ -91,9 +90,11 @@ def test_weight_packing_keeps_every_weight_exactly(name):
         off += cnt
         got.append(packed[off:off + 32 * tout].astype(np.float64))       # hidden bias, accumulator order
         off += 32 * tout
-        cnt = tout * 16 * 2 * nout + nout
-        got.append(packed[off:off + cnt].astype(np.float64))              # VALU head + its bias
+        cnt = tout * 2 * 3 * 64 * 4
+        got.append(_bf16_planes_sum(u16[off * 2:(off + cnt) * 2], (tout * 2, 3, 64, 8)).reshape(-1))  # head fragments
         off += cnt
+        got.append(packed[off:off + nout].astype(np.float64))             # head bias
+        off += nout
     assert off == len(packed)
     vals = np.concatenate(got)
     nz = np.sort(vals[vals != 0])
