@@ -9,7 +9,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 PROFILE = bool(os.environ.get("RL_PHASE_PROFILE"))  # tuning build with in-kernel phase stamps
 LIB_PATH = os.path.join(LIB_DIR, "libreinlife_hip_prof.so" if PROFILE else "libreinlife_hip.so")
 SOURCES = ["rl_world.hip", "rl_policy.hip", "rl_capi.hip"]
-HEADERS = ["rl_common.h", os.path.join("..", "..", "include", "reinlife_hip.h")]
+HEADERS = ["rl_common.h", "rl_policy_dev.h", os.path.join("..", "..", "include", "reinlife_hip.h")]
 # -ffp-contract=off: the world kernels' float64 reward / fitness arithmetic must round exactly like the CPU path
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("RL_EXTRA_HIPCC_FLAGS", "").split()

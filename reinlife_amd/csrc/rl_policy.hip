@@ -27,322 +27,10 @@
 //     16-byte-per-lane load (rl_policy_pack_weights).
 //   * the narrow heads (8 / 1 outputs) run on the VALU (an MFMA tile would be 75-97 % padding), followed by the
 //     dueling combine / softmax and the epsilon-greedy / categorical draw (Philox) in the same kernel.
-#include "rl_common.h"
+#include "rl_policy_dev.h"
 #include <string.h>
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-// weight pointers come out of a runtime-indexed brain table, which makes them generic (flat_load, counted on lgkmcnt AND
-// vmcnt); they always point to device global memory, so say so: global_load + a prefetch ring that survives LDS barriers
-typedef const float __attribute__((address_space(1))) gfloat;
-typedef const f32x4 __attribute__((address_space(1))) gf32x4;
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int kInChunks = 10;    // input layer: K padded to 160 = 10 chunks of 16 (lanes 0-31: k 16c..16c+7, lanes 32-63: +8)
-constexpr int kBiasK = 153;      // x[153] := 1, W[:,153] := bias
-
-// packed sizes in 4-byte units: a fragment is 8 bf16 = 16 bytes per lane, three planes (hi, mid, lo) per fragment
-__host__ __device__ constexpr int64_t in_layer_floats(int tiles) { return (int64_t)kInChunks * tiles * 3 * 64 * 4; }
-__host__ __device__ constexpr int64_t hid_layer_floats(int tin, int tout) { return (int64_t)(2 * tin) * tout * 3 * 64 * 4 + (int64_t)tout * 32; }
-__host__ __device__ constexpr int64_t head_floats(int tin, int nout) { return (int64_t)tin * 2 * 3 * 64 * 4 + nout; }  // fragments + f32 bias
-__host__ __device__ constexpr int64_t head_bias_off(int tin) { return (int64_t)tin * 2 * 3 * 64 * 4; }
-
-struct Layout {  // offsets (floats) into a brain's packed buffer
-    int64_t l1, l2a, l2b, ha, hb, total;
-};
-__host__ __device__ inline Layout layout_of(int kind)
-{
-    Layout L{};
-    int64_t o = 0;
-    if (kind == RL_DQN) {
-        L.l1 = o; o += in_layer_floats(4);
-        L.l2a = o; o += hid_layer_floats(4, 2);
-        L.ha = o; o += head_floats(2, 8);
-    } else if (kind == RL_D3QN || kind == RL_PERD3QN) {
-        L.l1 = o; o += in_layer_floats(4);
-        L.l2a = o; o += hid_layer_floats(4, 4);
-        L.ha = o; o += head_floats(4, 8);
-        L.l2b = o; o += hid_layer_floats(4, 4);
-        L.hb = o; o += head_floats(4, 1);
-    } else {
-        L.l1 = o; o += in_layer_floats(8);
-        L.l2a = o; o += hid_layer_floats(8, 8);
-        L.ha = o; o += head_floats(8, 8);
-    }
-    L.total = o;
-    return L;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// device building blocks (everything fully unrolled: accumulators must stay in registers)
-// ---------------------------------------------------------------------------------------------------------------
-// LDS-only workgroup barrier: lds_barrier() would also wait vmcnt(0), i.e. drain the weight-prefetch ring at every
-// layer boundary; waves only exchange activations / partial sums through LDS.
-#ifdef RL_FULL_FENCE
-__device__ inline void lds_barrier() { __syncthreads(); }
-#else
-__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#endif
-
-__device__ inline f32x16 mfma(const f32x4& a, const f32x4& b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// x = hi + mid + lo, each the bf16 nearest to what is left (the subtractions are exact in f32)
-__device__ inline void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo)
-{
-    hi = (__bf16)x;
-    const float r1 = x - (float)hi;
-    mid = (__bf16)r1;
-    lo = (__bf16)(r1 - (float)mid);
-}
-
-// the six partial products of one K-chunk, three per accumulator chain (a / b: planes hi, mid, lo)
-__device__ inline void mfma6(const f32x4 (&a)[3], const f32x4 (&b)[3], f32x16& acc, f32x16& acc2)
-{
-    acc2 = mfma(a[0], b[2], acc2);  // hi.lo
-    acc = mfma(a[2], b[0], acc);    // lo.hi
-    acc2 = mfma(a[1], b[1], acc2);  // mid.mid
-    acc = mfma(a[1], b[0], acc);    // mid.hi
-    acc2 = mfma(a[0], b[1], acc2);  // hi.mid
-    acc = mfma(a[0], b[0], acc);    // hi.hi
-}
-
-// Observation tile in LDS, split and already in B-operand order: plane p (hi, mid, lo) holds, for K-chunk c and lane
-// (row j = lane&31, half kh = lane>>5), the 8 bf16 x[j][16c + 8kh + 0..7] as one 16-byte unit at
-// p*kXPlane + (2c + kh)*33 + j, with x[153] := 1 (bias input) and x[154..159] := 0.  Groups are 33 (not 32) units
-// apart so that the staging writes of one row (40 lanes, one 8-byte half unit each) spread over the banks.
-constexpr int kXGroup = 33;
-constexpr int kXPlane = 2 * kInChunks * kXGroup;
-constexpr int kXsUnits = 3 * kXPlane;
-
-// Stage the 32 rows of a tile: wave v loads rows 8v..8v+7, ONE coalesced 612-byte read per row (lane m reads floats
-// 4m..4m+3), instead of every wave gathering 16 bytes per lane from 32 different rows for each K-step (64 cache lines
-// per load instruction, four times over): the input layer was request-bound on the vector L1.
-// `row_of_lane`: observation row id of tile row (lane & 31).
-__device__ inline void stage_x(f32x4* __restrict__ xs, const float* __restrict__ obs, int64_t row_of_lane, int lane, int v)
-{
-    const int lo = (int)(row_of_lane & 0xffffffff), hi = (int)(row_of_lane >> 32);
-    f32x2* x2 = (f32x2*)xs;
-    const int unit0 = (lane >> 1) * kXGroup + 8 * v, half = lane & 1;  // lane m: floats 4m..4m+3 = half (m&1) of group m>>1
-#pragma unroll
-    for (int r0 = 0; r0 < 8; r0 += 4) {  // four rows in flight at a time (registers are shared with the weight ring)
-        f32x4 val[4];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int jj = 8 * v + r0 + rr;
-            const int64_t r = ((int64_t)__builtin_amdgcn_readlane(hi, jj) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, jj);
-            const float* xr = obs + r * RL_OBS_DIM;
-            f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (lane < 38) t = *(const f32x4u*)(xr + 4 * lane);
-            else if (lane == 38) t = f32x4{xr[152], 1.0f, 0.0f, 0.0f};  // k = 152, the bias input, padding
-            val[rr] = t;
-        }
-        if (lane < 40) {
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                bf16x4 ph, pm, pl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { __bf16 a, b, c; split3(val[rr][e], a, b, c); ph[e] = a; pm[e] = b; pl[e] = c; }
-                const int u = (unit0 + r0 + rr) * 2 + half;
-                x2[u] = __builtin_bit_cast(f32x2, ph);
-                x2[kXPlane * 2 + u] = __builtin_bit_cast(f32x2, pm);
-                x2[kXPlane * 4 + u] = __builtin_bit_cast(f32x2, pl);
-            }
-        }
-    }
-}
-
-// The packed weights are STEP-major: [K-chunk][output tile][plane][lane][8 bf16], so the fragments of one chunk are
-// 1 KiB apart (immediate offsets of one running pointer).  The pointer is made opaque at every step so that the
-// compiler neither precomputes nor hoists hundreds of 64-bit addresses, and a sched_barrier per step bounds the
-// prefetch distance to exactly one step.
-//
-// layer_in: this wave computes output tiles {t0, t0 + TSTRIDE, ...} (NT of them) of a layer with TOUT tiles; the
-// B operand comes from the staged observation tile.  D = prefetch ring depth in K-chunks: a chunk is only 6*NT MFMAs
-// (192*NT cycles), an L2 round trip under load is several times that, so D chunks of weights are kept in flight.
-// Weight prefetch ring of one layer for one wave: D K-chunks of A fragments (3 planes each) in flight.  start() only
-// needs the packed pointer, so it is issued BEFORE the wait that precedes the layer (observation staging, the LDS
-// exchange of the previous layer, the VALU head): the first L2 round trip of every layer overlaps that wait.
-template <int TOUT, int NT, int TSTRIDE, int D>
-struct WRing {
-    f32x4 a[D][NT][3];
-    gf32x4* p;
-    __device__ inline void start(gfloat* __restrict__ pw, int lane, int t0)
-    {
-        p = (gf32x4*)pw + t0 * 3 * 64 + lane;
-#pragma unroll
-        for (int d = 0; d < D; ++d)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[d][t][pl] = p[((d * TOUT + t * TSTRIDE) * 3 + pl) * 64];
-    }
-    // take chunk s out of the ring and refill its slot with chunk s + D (of NS)
-    template <int NS>
-    __device__ inline void next(int s, f32x4 (&ac)[NT][3])
-    {
-        const int cur = s % D;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) ac[t][pl] = a[cur][t][pl];
-        p += TOUT * 3 * 64;
-        asm volatile("" : "+v"(p));
-        if (s + D < NS) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[cur][t][pl] = p[(((D - 1) * TOUT + t * TSTRIDE) * 3 + pl) * 64];
-        }
-    }
-};
-
-template <int TOUT, int NT, int TSTRIDE, int D>
-__device__ inline void layer_in(WRing<TOUT, NT, TSTRIDE, D>& w, int lane, const f32x4* __restrict__ xs, f32x16 (&acc)[NT])
-{
-    f32x16 acc2[NT];  // second accumulator chain: consecutive MFMAs of one wave do not wait for each other's result
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; acc2[t][r] = 0.0f; }
-    f32x4 x[2][3];
-    const int xb = (lane >> 5) * kXGroup + (lane & 31);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) x[0][pl] = xs[pl * kXPlane + xb];
-#pragma unroll
-    for (int c = 0; c < kInChunks; ++c) {
-        f32x4 ac[NT][3], xc[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) xc[pl] = x[c & 1][pl];
-        w.template next<kInChunks>(c, ac);
-        if (c + 1 < kInChunks) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) x[(c + 1) & 1][pl] = xs[pl * kXPlane + xb + (c + 1) * 2 * kXGroup];
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) mfma6(ac[t], xc, acc[t], acc2[t]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] += acc2[t][r];
-}
-
-template <int NT>
-__device__ inline void relu_inplace(f32x16 (&h)[NT])
-{
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h[t][r] = fmaxf(h[t][r], 0.0f);
-}
-
-// Publish this wave's activation tile `t` to the workgroup, split: plane p unit (t*2 + c)*64 + lane = registers
-// 8c..8c+7, i.e. exactly the B-operand fragment of K-chunk (t, c) of the next layer for this lane.
-__device__ inline void publish_tile(f32x4* lds, int plane_units, int t, int lane, const f32x16& h)
-{
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        bf16x8 ph, pm, pl;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { __bf16 x, y, z; split3(h[8 * c + e], x, y, z); ph[e] = x; pm[e] = y; pl[e] = z; }
-        const int u = (t * 2 + c) * 64 + lane;
-        lds[u] = __builtin_bit_cast(f32x4, ph);
-        lds[plane_units + u] = __builtin_bit_cast(f32x4, pm);
-        lds[2 * plane_units + u] = __builtin_bit_cast(f32x4, pl);
-    }
-}
-
-// layer_hidden: input = TIN published tiles in LDS (three planes of TIN*128 units); this wave computes output tiles
-// {t0, t0 + TSTRIDE, ...}.  The accumulators start from the bias (packed in accumulator order, behind the fragments).
-template <int TIN, int TOUT, int NT, int TSTRIDE, int D>
-__device__ inline void layer_hidden(WRing<TOUT, NT, TSTRIDE, D>& w, gfloat* __restrict__ pw, int lane, int t0,
-                                    const f32x4* __restrict__ hin, f32x16 (&acc)[NT])
-{
-    constexpr int NS = TIN * 2;        // chunk s = t*2 + c covers input features 32t + (r&3) + 8(r>>2) + 4h, r = 8c..8c+7
-    constexpr int PS = TIN * 2 * 64;   // units per plane
-    gf32x4* bias = (gf32x4*)(pw + (int64_t)NS * TOUT * 3 * 64 * 4) + (t0 * 2 + (lane >> 5)) * 4;
-    f32x4 b[2][3];
-    f32x16 acc2[NT];
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) b[0][pl] = hin[pl * PS + lane];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 bq = bias[t * TSTRIDE * 8 + q];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { acc[t][4 * q + e] = bq[e]; acc2[t][4 * q + e] = 0.0f; }
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        f32x4 ac[NT][3], bc[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bc[pl] = b[s & 1][pl];
-        w.template next<NS>(s, ac);
-        if (s + 1 < NS) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) b[(s + 1) & 1][pl] = hin[pl * PS + (s + 1) * 64 + lane];
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) mfma6(ac[t], bc, acc[t], acc2[t]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] += acc2[t][r];
-}
-
-// Narrow heads (8 / 1 outputs) also run on the matrix pipe: the head's weight rows are the A operand (outputs padded
-// to 32 rows with zeros), the B operand is this wave's own activation registers (a lane's registers 8c..8c+7 are its
-// B fragment of chunk c -- no exchange needed), 12 MFMAs per 32 input features.  A VALU version (16 FMAs per output
-// and input tile, weights fetched inside the loop) took 2-4 k cycles of mostly load latency per head.
-// Result: out[r], r = 0..3 = this wave's partial sum of output 4*(lane>>5) + r for row lane&31.
-template <int NT, int TSTRIDE>
-struct HeadW {
-    f32x4 a[NT][2][3];
-    __device__ inline void start(gfloat* __restrict__ hw, int lane, int t0)
-    {
-        gf32x4* p = (gf32x4*)hw + lane;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[t][c][pl] = p[(((t0 + t * TSTRIDE) * 2 + c) * 3 + pl) * 64];
-    }
-};
-
-template <int NT, int TSTRIDE>
-__device__ inline void head_mfma(const HeadW<NT, TSTRIDE>& w, const f32x16 (&hin)[NT], float (&out)[4])
-{
-    f32x16 acc, acc2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; }
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            bf16x8 ph, pm, pl;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { __bf16 x, y, z; split3(hin[t][8 * c + e], x, y, z); ph[e] = x; pm[e] = y; pl[e] = z; }
-            const f32x4 b[3] = {__builtin_bit_cast(f32x4, ph), __builtin_bit_cast(f32x4, pm), __builtin_bit_cast(f32x4, pl)};
-            mfma6(w.a[t][c], b, acc, acc2);
-        }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) out[r] = acc[r] + acc2[r];
-}
 
 constexpr int kMaxBrainsPerLaunch = 8;
 
@@ -371,31 +59,19 @@ struct PolicyArgs {
 #endif
 };
 
-#ifdef RL_PHASE_PROFILE
-#define RL_PMARK(i) do { if (A.prof && (int)blockIdx.x == A.prof_block && threadIdx.x == 0) A.prof[48 + (i)] = (long long)clock64(); } while (0)
-#else
-#define RL_PMARK(i) do { } while (0)
-#endif
-
 // One launch serves every brain of one kind: the tile space is the concatenation of the brains' 32-row tiles; one
-// 4-wave workgroup per tile.
-// EARLY = latency variant for launches of a few tiles per CU (256 worlds): every layer's weight ring and head fragments
-// are requested before the wait that precedes the layer (needs 168 VGPRs: 3 waves per SIMD).  !EARLY = throughput
-// variant for dense launches: rings start at their layer, 128 VGPRs, 4 waves per SIMD.
+// 4-wave workgroup per tile (policy_tile, rl_policy_dev.h).
 template <int KIND, bool EARLY>
 __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : (EARLY ? 3 : 4))) void k_policy(const PolicyArgs A)
 {
-    constexpr int HID_TILES = KIND == RL_PPO ? 8 : 4;          // tiles of the first hidden layer
-    // split observation tile (31 KiB), then -- after the input layer -- the split published activations (24 / 48 KiB)
-    constexpr int PS = HID_TILES * 2 * 64;  // units per plane of the published activations
-    __shared__ __attribute__((aligned(16))) f32x4 lds_h[3 * PS > kXsUnits ? 3 * PS : kXsUnits];
+    __shared__ __attribute__((aligned(16))) f32x4 lds_h[policy_lds_units(KIND)];
     __shared__ float lds_part[4][32][9];                        // per-wave head partials
-
-    const int lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31, v = threadIdx.x >> 6;
-    RL_PMARK(0);
+    const int lane = threadIdx.x & 63, j = lane & 31, v = threadIdx.x >> 6;
+#ifdef RL_PHASE_PROFILE
+    if (A.prof && (int)blockIdx.x == A.prof_block && threadIdx.x == 0) A.prof[48] = (long long)clock64();
+#endif
     int ntiles = 0;
     for (int i = 0; i < A.nb; ++i) ntiles += ((A.b[i].count_ptr ? *A.b[i].count_ptr : (int)A.n_rows) + 31) / 32;
-    const Layout L = layout_of(KIND);
     for (int gt = blockIdx.x; gt < ntiles; gt += gridDim.x) {
         int bi = 0, n = 0, tile = gt;
         for (int i = 0; i < A.nb; ++i) {  // which brain does global tile gt belong to
@@ -406,158 +82,25 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : (EARLY ? 3 : 4))) void k
             tile -= nt;
         }
         const BrainSlot B = A.b[bi];
-        gfloat* __restrict__ packed = (gfloat*)B.packed;
         const int li = tile * 32 + j;
-        const bool valid = li < n;
-        const int64_t row = valid ? (B.rowlist ? (int64_t)B.rowlist[li] : (int64_t)li) : (B.rowlist ? (int64_t)B.rowlist[tile * 32] : (int64_t)tile * 32);
-        RL_PMARK(1);
+        TileIO io;
+        io.packed = (gfloat*)B.packed;
+        io.obs = A.obs;
+        io.valid = li < n;
+        io.row = io.valid ? (B.rowlist ? (int64_t)B.rowlist[li] : (int64_t)li) : (B.rowlist ? (int64_t)B.rowlist[tile * 32] : (int64_t)tile * 32);
+        io.eps = B.eps; io.out = A.out; io.actions = A.actions; io.seed = A.seed;
+        io.key_world = io.key_tick = io.key_epoch = io.key_index = 0;
         // the draw's Philox key needs the world's tick / epoch: fetch them now, not in the epilogue's dependent chain
-        int key_tick = 0, key_epoch = 0;
-        if (A.actions && v == 0 && h == 0) {
-            const int w = (int)(row / A.cap);
-            key_tick = A.tick[w]; key_epoch = A.epoch[w];
+        if (A.actions && v == 0 && lane < 32) {
+            const int w = (int)(io.row / A.cap);
+            io.key_world = (uint32_t)(A.world_base + w); io.key_index = (uint32_t)(io.row - (int64_t)w * A.cap);
+            io.key_tick = (uint32_t)A.tick[w]; io.key_epoch = (uint32_t)A.epoch[w];
         }
-        if (KIND == RL_DQN) {
-            f32x16 h1[1], h2[1];
-            WRing<4, 1, 1, 3> w1;
-            WRing<2, 1, 1, 3> w2;
-            if (EARLY) w1.start(packed + L.l1, lane, v);
-            stage_x(lds_h, A.obs, row, lane, v);
-            lds_barrier();
-            if (!EARLY) w1.start(packed + L.l1, lane, v);
-            layer_in(w1, lane, lds_h, h1);
-            HeadW<1, 1> wh;
-            if (EARLY && v < 2) { w2.start(packed + L.l2a, lane, v); wh.start(packed + L.ha, lane, v); }
-            relu_inplace<1>(h1);
-            lds_barrier();  // every wave is done with the observation tile: its LDS becomes the activation exchange
-            publish_tile(lds_h, PS, v, lane, h1[0]);
-            lds_barrier();
-            float q4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (v < 2) {  // the second hidden layer has 2 output tiles: waves 0 and 1
-                if (!EARLY) { w2.start(packed + L.l2a, lane, v); wh.start(packed + L.ha, lane, v); }
-                layer_hidden<4>(w2, packed + L.l2a, lane, v, lds_h, h2);
-                relu_inplace<1>(h2);
-                head_mfma(wh, h2, q4);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) lds_part[v][j][4 * h + r] = q4[r];
-        } else if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
-            f32x16 h1[1], h2[1];
-            float adv[4], val[4];
-            WRing<4, 1, 1, EARLY ? 3 : 2> w1, w2;
-            HeadW<1, 1> wh;
-            if (EARLY) w1.start(packed + L.l1, lane, v);
-            stage_x(lds_h, A.obs, row, lane, v);
-            lds_barrier();
-            RL_PMARK(10);
-            if (!EARLY) w1.start(packed + L.l1, lane, v);
-            layer_in(w1, lane, lds_h, h1);
-            RL_PMARK(2);
-            if (EARLY) { w2.start(packed + L.l2a, lane, v); wh.start(packed + L.ha, lane, v); }
-            relu_inplace<1>(h1);  // relu(feature) feeds both branches (PERD3QN.py:200-201)
-            lds_barrier();
-            publish_tile(lds_h, PS, v, lane, h1[0]);
-            lds_barrier();
-            RL_PMARK(3);
-            if (!EARLY) w2.start(packed + L.l2a, lane, v);
-            layer_hidden<4>(w2, packed + L.l2a, lane, v, lds_h, h2);
-            RL_PMARK(4);
-            if (EARLY) w1.start(packed + L.l2b, lane, v);  // the value branch's first chunks arrive while the advantage head runs
-            else wh.start(packed + L.ha, lane, v);
-            relu_inplace<1>(h2);
-            head_mfma(wh, h2, adv);
-            wh.start(packed + L.hb, lane, v);
-            RL_PMARK(5);
-            if (!EARLY) w1.start(packed + L.l2b, lane, v);
-            layer_hidden<4>(w1, packed + L.l2b, lane, v, lds_h, h2);
-            RL_PMARK(6);
-            relu_inplace<1>(h2);
-            head_mfma(wh, h2, val);
-            RL_PMARK(7);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) lds_part[v][j][4 * h + r] = adv[r];
-            if (h == 0) lds_part[v][j][8] = val[0];
-        } else {
-            f32x16 h1[2], h2[2];
-            float q4[4];
-            WRing<8, 2, 4, 3> w1, w2;
-            HeadW<2, 4> wh;
-            w1.start(packed + L.l1, lane, v);   // tiles v and v+4
-            stage_x(lds_h, A.obs, row, lane, v);
-            lds_barrier();
-            layer_in(w1, lane, lds_h, h1);
-            w2.start(packed + L.l2a, lane, v);
-            relu_inplace<2>(h1);
-            lds_barrier();
-            publish_tile(lds_h, PS, v, lane, h1[0]);
-            publish_tile(lds_h, PS, v + 4, lane, h1[1]);
-            lds_barrier();
-            wh.start(packed + L.ha, lane, v);
-            layer_hidden<8>(w2, packed + L.l2a, lane, v, lds_h, h2);
-            relu_inplace<2>(h2);
-            head_mfma(wh, h2, q4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) lds_part[v][j][4 * h + r] = q4[r];
-        }
-        lds_barrier();
-        RL_PMARK(8);
-        if (v == 0 && h == 0) {
-            float q[8];
-            float sum9[9];
-#pragma unroll
-            for (int i = 0; i < 9; ++i)
-                sum9[i] = (i < 8 || KIND == RL_D3QN || KIND == RL_PERD3QN)
-                              ? ((lds_part[0][j][i] + lds_part[1][j][i]) + lds_part[2][j][i]) + lds_part[3][j][i] : 0.0f;
-            if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
-                gfloat* ba = packed + L.ha + head_bias_off(4);
-                const float bv = packed[L.hb + head_bias_off(4)];
-                float adv[8], mean = 0.0f;  // advantage.mean() of the [1,8] tensor == per-row mean when batched
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { adv[i] = sum9[i] + ba[i]; mean += adv[i]; }
-                mean *= 0.125f;
-                const float val = sum9[8] + bv;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) q[i] = adv[i] + val - mean;
-            } else {
-                gfloat* bq = packed + L.ha + head_bias_off(KIND == RL_DQN ? 2 : 8);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) q[i] = sum9[i] + bq[i];
-                if (KIND == RL_PPO) {
-                    float m = q[0], sm = 0.0f;  // softmax over the 8 logits (PPO.py:105)
-#pragma unroll
-                    for (int i = 1; i < 8; ++i) m = fmaxf(m, q[i]);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { q[i] = expf(q[i] - m); sm += q[i]; }
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) q[i] = q[i] / sm;
-                }
-            }
-            if (valid) {
-                if (A.out) {
-                    f32x4* o = (f32x4*)(A.out + row * 8);
-                    o[0] = f32x4{q[0], q[1], q[2], q[3]};
-                    o[1] = f32x4{q[4], q[5], q[6], q[7]};
-                }
-                if (A.actions) {
-                    const int w = (int)(row / A.cap), k = (int)(row - (int64_t)w * A.cap);
-                    const rl_u4 r = rl_philox4x32(A.seed, (uint32_t)key_epoch, (uint32_t)(A.world_base + w), (uint32_t)key_tick, RL_SITE_ACT, (uint32_t)k);
-                    const float u = (float)rl_u24(r.x);
-                    int a = 0;
-                    if (KIND == RL_PPO) {  // Categorical(prob).sample() as inverse CDF
-                        float cum = 0.0f; a = 7; bool found = false;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) { cum += q[i]; if (!found && u < cum) { a = i; found = true; } }
-                    } else if (u < B.eps) a = (int)(r.y >> 29);
-                    else {
-#pragma unroll
-                        for (int i = 1; i < 8; ++i) if (q[i] > q[a]) a = i;  // first maximum
-                    }
-                    A.actions[row] = (int8_t)a;
-                }
-            }
-        }
-        RL_PMARK(9);
-        lds_barrier();  // lds_h / lds_part are reused by the next tile
+#ifdef RL_PHASE_PROFILE
+        io.prof = (A.prof && (int)blockIdx.x == A.prof_block) ? A.prof : nullptr;
+        if (io.prof && threadIdx.x == 0) io.prof[49] = (long long)clock64();
+#endif
+        policy_tile<KIND, EARLY, false>(io, true, lds_h, lds_part, lane, v);
     }
 }
 
