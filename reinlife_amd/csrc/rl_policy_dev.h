@@ -373,13 +373,14 @@ constexpr __host__ __device__ int policy_lds_units(int kind)  // f32x4 units of 
     return (3 * (kind == RL_PPO ? 8 : 4) * 2 * 64 > kXsUnits) ? 3 * (kind == RL_PPO ? 8 : 4) * 2 * 64 : kXsUnits;
 }
 
-// EARLY = latency variant for launches of a few tiles per CU (256 worlds): every layer's weight ring and head fragments
-// are requested before the wait that precedes the layer (needs ~154 VGPRs: 3 waves per SIMD).  !EARLY = throughput
-// variant for dense launches: rings start at their layer, 128 VGPRs, 4 waves per SIMD.
+// Every layer's weight ring and head fragments are requested BEFORE the wait that precedes the layer (observation
+// staging, the LDS exchange, the previous head): ~154 VGPRs for the 128-wide brains, i.e. 3 waves per SIMD.  A variant
+// that starts the rings at their layer (128 VGPRs, 4 waves per SIMD) and one with 64-row tiles were measured slower at
+// 256 AND at 4096 worlds.
 // GUARD: the tile may be inactive (a world kernel running fewer tiles than it has wave quads): every workgroup barrier
 // is still executed, everything else is skipped.  The barriers are workgroup-wide, so all tiles of a workgroup must run
 // the same KIND.
-template <int KIND, bool EARLY, bool GUARD>
+template <int KIND, bool GUARD>
 __device__ inline void policy_tile(const TileIO& io, bool active, f32x4* __restrict__ lds_h, float (*__restrict__ lds_part)[32][9],
                                    int lane, int v)
 {
@@ -396,14 +397,13 @@ __device__ inline void policy_tile(const TileIO& io, bool active, f32x4* __restr
         HeadW<1, 1> wh;
         float q4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (on) {
-            if (EARLY) w1.start(packed + L.l1, lane, v);
+            w1.start(packed + L.l1, lane, v);
             stage_x(lds_h, io.obs, io.row, lane, v);
         }
         lds_barrier();
         if (on) {
-            if (!EARLY) w1.start(packed + L.l1, lane, v);
             layer_in(w1, lane, lds_h, h1);
-            if (EARLY && v < 2) { w2.start(packed + L.l2a, lane, v); wh.start(packed + L.ha, lane, v); }
+            if (v < 2) { w2.start(packed + L.l2a, lane, v); wh.start(packed + L.ha, lane, v); }
             relu_inplace<1>(h1);
         }
         lds_barrier();  // every wave is done with the observation tile: its LDS becomes the activation exchange
@@ -411,7 +411,6 @@ __device__ inline void policy_tile(const TileIO& io, bool active, f32x4* __restr
         lds_barrier();
         if (on) {
             if (v < 2) {  // the second hidden layer has 2 output tiles: waves 0 and 1
-                if (!EARLY) { w2.start(packed + L.l2a, lane, v); wh.start(packed + L.ha, lane, v); }
                 layer_hidden<4>(w2, packed + L.l2a, lane, v, lds_h, h2);
                 relu_inplace<1>(h2);
                 head_mfma(wh, h2, q4);
@@ -422,19 +421,19 @@ __device__ inline void policy_tile(const TileIO& io, bool active, f32x4* __restr
     } else if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
         f32x16 h1[1], h2[1];
         float adv[4], val[4];
-        WRing<4, 1, 1, EARLY ? 3 : 2> w1, w2;
+        WRing<4, 1, 1, 3> w1, w2;
         HeadW<1, 1> wh;
         if (on) {
-            if (EARLY) w1.start(packed + L.l1, lane, v);
+            w1.start(packed + L.l1, lane, v);
             stage_x(lds_h, io.obs, io.row, lane, v);
         }
         lds_barrier();
         RL_PMARK(10);
         if (on) {
-            if (!EARLY) w1.start(packed + L.l1, lane, v);
             layer_in(w1, lane, lds_h, h1);
             RL_PMARK(2);
-            if (EARLY) { w2.start(packed + L.l2a, lane, v); wh.start(packed + L.ha, lane, v); }
+            w2.start(packed + L.l2a, lane, v);
+            wh.start(packed + L.ha, lane, v);
             relu_inplace<1>(h1);  // relu(feature) feeds both branches (PERD3QN.py:200-201)
         }
         lds_barrier();
@@ -442,16 +441,13 @@ __device__ inline void policy_tile(const TileIO& io, bool active, f32x4* __restr
         lds_barrier();
         RL_PMARK(3);
         if (on) {
-            if (!EARLY) w2.start(packed + L.l2a, lane, v);
             layer_hidden<4>(w2, packed + L.l2a, lane, v, lds_h, h2);
             RL_PMARK(4);
-            if (EARLY) w1.start(packed + L.l2b, lane, v);  // the value branch's first chunks arrive while the advantage head runs
-            else wh.start(packed + L.ha, lane, v);
+            w1.start(packed + L.l2b, lane, v);  // the value branch's first chunks arrive while the advantage head runs
             relu_inplace<1>(h2);
             head_mfma(wh, h2, adv);
             wh.start(packed + L.hb, lane, v);
             RL_PMARK(5);
-            if (!EARLY) w1.start(packed + L.l2b, lane, v);
             layer_hidden<4>(w1, packed + L.l2b, lane, v, lds_h, h2);
             RL_PMARK(6);
             relu_inplace<1>(h2);
