@@ -67,27 +67,34 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 3)) void k_policy(const 
     __shared__ __attribute__((aligned(16))) f32x4 lds_h[policy_lds_units(KIND)];
     __shared__ float lds_part[4][32][9];                        // per-wave head partials
     const int lane = threadIdx.x & 63, j = lane & 31, v = threadIdx.x >> 6;
+    {   // one batch of scalar loads touches every 64-byte line of the argument block (the brain table is read entry by
+        // entry below: each first touch of a line would be a scalar-cache miss on the way to the row list)
+        auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+        int t0, t1, t2, t3, t4, t5;
+        asm volatile("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\t"
+                     "s_load_dword %3, %6, 0xc0\n\ts_load_dword %4, %6, 0x100\n\ts_load_dword %5, %6, 0x140\n\ts_waitcnt lgkmcnt(0)"
+                     : "=s"(t0), "=s"(t1), "=s"(t2), "=s"(t3), "=s"(t4), "=s"(t5) : "s"(ka) : "memory");
+        static_assert(sizeof(PolicyArgs) >= 0x140 + 4 && sizeof(PolicyArgs) <= 0x180, "the warm-up loads must cover the argument block");
+    }
 #ifdef RL_PHASE_PROFILE
     if (A.prof && (int)blockIdx.x == A.prof_block && threadIdx.x == 0) A.prof[48] = (long long)clock64();
 #endif
-    int ntiles = 0;
-    for (int i = 0; i < A.nb; ++i) ntiles += ((A.b[i].count_ptr ? *A.b[i].count_ptr : (int)A.n_rows) + 31) / 32;
-    for (int gt = blockIdx.x; gt < ntiles; gt += gridDim.x) {
-        int bi = 0, n = 0, tile = gt;
-        for (int i = 0; i < A.nb; ++i) {  // which brain does global tile gt belong to
-            n = A.b[i].count_ptr ? *A.b[i].count_ptr : (int)A.n_rows;
-            bi = i;
-            const int nt = (n + 31) / 32;
-            if (tile < nt) break;
-            tile -= nt;
-        }
+    // grid = (tiles a brain can have at most, brains of this launch): the brain and the tile follow from the block index,
+    // so the row-list entry is requested together with the brain's row count instead of after it (one dependent round
+    // trip less at the head of every workgroup).  Entries beyond the count are stale or zero row ids: still valid rows.
+    typedef const int __attribute__((address_space(4))) cint;
+    {
+        const int bi = blockIdx.y, tile = blockIdx.x;
         const BrainSlot B = A.b[bi];
         const int li = tile * 32 + j;
+        const int64_t listed = B.rowlist ? (int64_t)B.rowlist[li] : (int64_t)li;
+        const int n = B.count_ptr ? ((cint*)B.count_ptr)[0] : (int)A.n_rows;
+        if (tile * 32 >= n) return;
         TileIO io;
         io.packed = (gfloat*)B.packed;
         io.obs = A.obs;
         io.valid = li < n;
-        io.row = io.valid ? (B.rowlist ? (int64_t)B.rowlist[li] : (int64_t)li) : (B.rowlist ? (int64_t)B.rowlist[tile * 32] : (int64_t)tile * 32);
+        io.row = (io.valid || B.rowlist) ? listed : (int64_t)tile * 32;  // dense mode: rows past the end do not exist
         io.eps = B.eps; io.out = A.out; io.actions = A.actions; io.seed = A.seed;
         io.key_world = io.key_tick = io.key_epoch = io.key_index = 0;
         // the draw's Philox key needs the world's tick / epoch: fetch them now, not in the epilogue's dependent chain
@@ -261,17 +268,15 @@ int rl_policy_pack_impl(int kind, const float* sd, float* packed)
     return RL_OK;
 }
 
-static int policy_grid(int64_t max_rows)
+static int policy_grid(int64_t max_rows)  // tiles one brain can have: one 4-wave workgroup per 32-row tile
 {
-    int64_t blocks = (max_rows + 31) / 32 + kMaxBrainsPerLaunch;  // one 4-wave workgroup per 32-row tile
-    if (blocks < 1) blocks = 1;
-    if (blocks > 16384) blocks = 16384;
-    return (int)blocks;
+    const int64_t blocks = (max_rows + 31) / 32;
+    return (int)(blocks < 1 ? 1 : blocks);
 }
 
 static int launch_policy(int kind, const PolicyArgs& a, int64_t max_rows, hipStream_t st)
 {
-    const dim3 grid(policy_grid(max_rows)), block(256);
+    const dim3 grid(policy_grid(max_rows), a.nb), block(256);
     switch (kind) {
         case RL_DQN: hipLaunchKernelGGL((k_policy<RL_DQN>), grid, block, 0, st, a); break;
         case RL_D3QN: hipLaunchKernelGGL((k_policy<RL_D3QN>), grid, block, 0, st, a); break;

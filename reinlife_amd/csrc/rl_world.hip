@@ -150,13 +150,20 @@ __device__ inline int lane_id() { return threadIdx.x & 63; }
 // The kernel argument block (KParams is the only kernel parameter, so it starts at offset 0 of the kernarg segment), made
 // opaque so that every use site re-reads the few pointers it needs with s_load instead of keeping all ~45 pointers alive
 // from kernel entry to the final store (which spilled >150 SGPRs into VGPR lanes).
+// The block is read through the CONSTANT address space (scalar loads, also inside divergent code) and the pointers found
+// in it are used through the GLOBAL address space (RL_G): as generic pointers they became flat_load / flat_store, which
+// are counted on lgkmcnt as well -- every LDS wait and every lds_barrier() then also waited for HBM traffic.
 struct KParams;
-__device__ inline const KParams* kernargs()
+typedef const KParams __attribute__((address_space(4))) KParamsC;
+__device__ inline KParamsC* kernargs()
 {
-    const void* q = (const void*)__builtin_amdgcn_kernarg_segment_ptr();
+    KParamsC* q = (KParamsC*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(q));
-    return (const KParams*)q;
+    return q;
 }
+template <typename P> struct rl_global_ptr;
+template <typename E> struct rl_global_ptr<E*> { typedef E __attribute__((address_space(1)))* type; };
+#define RL_G(ptr) ((typename rl_global_ptr<decltype(ptr)>::type)(ptr))
 
 // Workgroup barrier for LDS-only communication.  lds_barrier() is a full workgroup fence: it emits
 // s_waitcnt vmcnt(0), which on gfx950 also waits for every outstanding global STORE (observation rows, outputs) -- an
@@ -268,23 +275,26 @@ template <int T>
 __device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
 {
     const int tid = threadIdx.x;
-    const KParams* q = kernargs();
+    KParamsC* q = kernargs();
     const size_t b = (size_t)w * p.cap;
-    const uint8_t* gt = q->st.cell_type + (size_t)w * p.C;
-    // ---- issue EVERY global load first (one HBM round trip): nothing below depends on n_agents until the LDS writes.
+    // ---- every pointer first, in uniform code (one batch of scalar loads) ...
+    const auto gt = RL_G(q->st.cell_type) + (size_t)w * p.C;
+    const auto g_i = RL_G(q->st.a_i) + b, g_j = RL_G(q->st.a_j) + b, g_fl = RL_G(q->st.a_flags) + b;
+    const auto g_h = RL_G(q->st.a_health) + b, g_age = RL_G(q->st.a_age) + b, g_ma = RL_G(q->st.a_max_age) + b;
+    const auto g_g = RL_G(q->st.a_gene) + b, g_b = RL_G(q->st.a_brain) + b, g_u = RL_G(q->st.a_uid) + b;
+    const auto g_f = RL_G(q->st.a_fitness) + b;
+    const auto g_act = (q->actions ? RL_G(q->actions) : RL_G((const int8_t*)q->st.a_action)) + b;
+    const auto g_bu = RL_G(q->st.best_uid) + (size_t)w * RL_N_BEST, g_bb = RL_G(q->st.best_brain) + (size_t)w * RL_N_BEST;
+    const auto g_bf = RL_G(q->st.best_fit) + (size_t)w * RL_N_BEST;
+    // ---- ... the per-world scalars through the scalar cache (uniform addresses: no lane select of POINTERS, no readfirstlane) ...
+    typedef const int32_t __attribute__((address_space(4))) cint;
+    n0 = ((cint*)q->st.n_agents)[w];
+    const int v_tick = ((cint*)q->st.tick)[w], v_epoch = ((cint*)q->st.epoch)[w];
+    const int v_uid = ((cint*)q->st.next_uid)[w], v_mg = ((cint*)q->st.max_gene)[w];
+    // ---- ... then EVERY vector load (one HBM round trip): nothing below depends on a loaded value until the LDS writes.
     // Slot `tid` of the agent arrays is read unconditionally (inside the allocation; ignored beyond n_agents).
-    n0 = q->st.n_agents[w];
-    int sc_val = 0;
-    if (tid == S_TICK) sc_val = q->st.tick[w];
-    else if (tid == S_EPOCH) sc_val = q->st.epoch[w];
-    else if (tid == S_NEXT_UID) sc_val = q->st.next_uid[w];
-    else if (tid == S_MAX_GENE) sc_val = q->st.max_gene[w];
     int bu = -1, bb = 0; double bf = 0.0;
-    if (tid < RL_N_BEST) {
-        bu = q->st.best_uid[(size_t)w * RL_N_BEST + tid];
-        bf = q->st.best_fit[(size_t)w * RL_N_BEST + tid];
-        bb = q->st.best_brain[(size_t)w * RL_N_BEST + tid];
-    }
+    if (tid < RL_N_BEST) { bu = g_bu[tid]; bf = g_bf[tid]; bb = g_bb[tid]; }
     uint8_t ty[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int c = tid + u * T; ty[u] = c < p.C ? gt[c] : kPadCell; }
@@ -292,23 +302,27 @@ __device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
     uint8_t r_i = 0, r_j = 0, r_fl = 0; signed char r_act = -1;
     int r_h = 0, r_age = 0, r_ma = 0, r_g = 0, r_b = 0, r_u = 0; double r_f = 0.0;
     if (ha) {
-        r_i = q->st.a_i[b + tid]; r_j = q->st.a_j[b + tid];
-        r_h = q->st.a_health[b + tid]; r_age = q->st.a_age[b + tid]; r_ma = q->st.a_max_age[b + tid];
-        r_g = q->st.a_gene[b + tid]; r_b = q->st.a_brain[b + tid]; r_u = q->st.a_uid[b + tid];
-        r_fl = q->st.a_flags[b + tid];
-        r_act = q->actions ? q->actions[b + tid] : q->st.a_action[b + tid];
-        r_f = q->st.a_fitness[b + tid];
+        r_i = g_i[tid]; r_j = g_j[tid];
+        r_h = g_h[tid]; r_age = g_age[tid]; r_ma = g_ma[tid];
+        r_g = g_g[tid]; r_b = g_b[tid]; r_u = g_u[tid];
+        r_fl = g_fl[tid];
+        r_act = g_act[tid];
+        r_f = g_f[tid];
     }
+    const int sc_val = tid == S_TICK ? v_tick : tid == S_EPOCH ? v_epoch : tid == S_NEXT_UID ? v_uid : tid == S_MAX_GENE ? v_mg : 0;
+    RL_MARK(30);
     // ---- LDS initialisation that needs no loaded value
     for (int c = tid; c < p.Cp; c += T) { s.occ[c] = -1; ((unsigned*)s.foodv)[c] = 0u; }
     for (int i = tid; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
     if (tid < RL_MAX_BRAINS) s.present[tid] = 0;
+    RL_MARK(31);
     // ---- consume the loads
     if (tid < S_COUNT) s.scal[tid] = tid == S_NSLOTS ? n0 : sc_val;
     if (tid < RL_N_BEST) { s.best_uid[tid] = bu; s.best_fit[tid] = bf; s.best_brain[tid] = bb; }
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int c = tid + u * T; if (c < p.Cp) s.type[c] = ty[u]; }
     for (int c = tid + 4 * T; c < p.Cp; c += T) s.type[c] = c < p.C ? gt[c] : kPadCell;
+    RL_MARK(32);
     auto put = [&](int a, int pi, int pj, int h, int age, int ma, int g, int br, int u, int fl, int act, double f) {
         s.pos[a] = (unsigned short)(pi | (pj << 8));
         s.health[a] = h; s.age[a] = age; s.max_age[a] = ma; s.gene[a] = g; s.brain[a] = br; s.uid[a] = u;
@@ -317,9 +331,7 @@ __device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
     };
     if (ha && tid < n0) put(tid, r_i, r_j, r_h, r_age, r_ma, r_g, r_b, r_u, r_fl, r_act, r_f);
     for (int a = tid + T; a < n0; a += T)
-        put(a, q->st.a_i[b + a], q->st.a_j[b + a], q->st.a_health[b + a], q->st.a_age[b + a], q->st.a_max_age[b + a], q->st.a_gene[b + a],
-            q->st.a_brain[b + a], q->st.a_uid[b + a], q->st.a_flags[b + a], q->actions ? q->actions[b + a] : q->st.a_action[b + a],
-            q->st.a_fitness[b + a]);
+        put(a, g_i[a], g_j[a], g_h[a], g_age[a], g_ma[a], g_g[a], g_b[a], g_u[a], g_fl[a], g_act[a], g_f[a]);
     RL_MARK(33);
     lds_barrier();
     RL_MARK(34);
@@ -979,35 +991,35 @@ template <int T>
 __device__ void store_world(const KParams& p, Smem& s, int w, int n)
 {
     const int tid = threadIdx.x;
-    const KParams* q = kernargs();
+    KParamsC* q = kernargs();
     if (RL_ABL(64)) return;
-    uint8_t* gt = q->st.cell_type + (size_t)w * p.C;
+    auto gt = RL_G(q->st.cell_type) + (size_t)w * p.C;
     if (!RL_ABL(1024)) for (int c = tid; c < p.C; c += T) gt[c] = s.type[c];
     const size_t b = (size_t)w * p.cap;
     if (!RL_ABL(2048))
     for (int k = tid; k < n; k += T) {
         const int a = s.order[k];
         if (!RL_ABL(4096)) {
-        q->st.a_i[b + k] = (uint8_t)(s.pos[a] & 255);
-        q->st.a_j[b + k] = (uint8_t)(s.pos[a] >> 8);
-        q->st.a_flags[b + k] = s.flags[a];
-        q->st.a_action[b + k] = s.action[a];
+        RL_G(q->st.a_i)[b + k] = (uint8_t)(s.pos[a] & 255);
+        RL_G(q->st.a_j)[b + k] = (uint8_t)(s.pos[a] >> 8);
+        RL_G(q->st.a_flags)[b + k] = s.flags[a];
+        RL_G(q->st.a_action)[b + k] = s.action[a];
         }
         if (!RL_ABL(8192)) {
-        q->st.a_health[b + k] = s.health[a];
-        q->st.a_age[b + k] = s.age[a];
-        q->st.a_max_age[b + k] = s.max_age[a];
-        q->st.a_gene[b + k] = s.gene[a];
-        q->st.a_brain[b + k] = s.brain[a];
-        q->st.a_uid[b + k] = s.uid[a];
+        RL_G(q->st.a_health)[b + k] = s.health[a];
+        RL_G(q->st.a_age)[b + k] = s.age[a];
+        RL_G(q->st.a_max_age)[b + k] = s.max_age[a];
+        RL_G(q->st.a_gene)[b + k] = s.gene[a];
+        RL_G(q->st.a_brain)[b + k] = s.brain[a];
+        RL_G(q->st.a_uid)[b + k] = s.uid[a];
         }
-        if (!RL_ABL(16384)) q->st.a_fitness[b + k] = s.fitness[a];
+        if (!RL_ABL(16384)) RL_G(q->st.a_fitness)[b + k] = s.fitness[a];
     }
-    if (tid == 0) q->st.n_agents[w] = n;
+    if (tid == 0) RL_G(q->st.n_agents)[w] = n;
     if (tid < RL_N_BEST && !p.static_families) {
-        q->st.best_uid[(size_t)w * RL_N_BEST + tid] = s.best_uid[tid];
-        q->st.best_fit[(size_t)w * RL_N_BEST + tid] = s.best_fit[tid];
-        q->st.best_brain[(size_t)w * RL_N_BEST + tid] = s.best_brain[tid];
+        RL_G(q->st.best_uid)[(size_t)w * RL_N_BEST + tid] = s.best_uid[tid];
+        RL_G(q->st.best_fit)[(size_t)w * RL_N_BEST + tid] = s.best_fit[tid];
+        RL_G(q->st.best_brain)[(size_t)w * RL_N_BEST + tid] = s.best_brain[tid];
     }
 }
 
@@ -1022,12 +1034,31 @@ template <int T, int MODE, bool LEAN>
 __global__ __launch_bounds__(T) void k_world(const KParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+#ifdef RL_PHASE_PROFILE
+    unsigned long long t_entry;  // before the first kernel-argument access
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry));
+#endif
+    {   // Touch every 64-byte line of the kernel-argument block with ONE batch of scalar loads: the compiler fetches
+        // arguments lazily, a few at a time, and each first touch of a line is a scalar-cache miss (~0.2 us) on the
+        // critical path of load_world; afterwards they are hits.
+        auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+        int t0, t1, t2, t3, t4, t5, t6, t7;
+        asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\t"
+                     "s_load_dword %3, %8, 0xc0\n\ts_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\t"
+                     "s_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=s"(t0), "=s"(t1), "=s"(t2), "=s"(t3), "=s"(t4), "=s"(t5), "=s"(t6), "=s"(t7)
+                     : "s"(ka) : "memory");
+        static_assert(sizeof(KParams) >= 0x1c0 + 4 && sizeof(KParams) <= 0x200, "the warm-up loads must cover the argument block");
+    }
     Smem s;
     carve(s, smem_raw, p.Cp, p.cap, p.hash_size);
     const int w = blockIdx.x;
     const int tid = threadIdx.x;
     int n0;
     RL_MARK(0);
+#ifdef RL_PHASE_PROFILE
+    if (p.prof && (int)blockIdx.x == p.prof_world && threadIdx.x == 0) p.prof[23] = (long long)t_entry;
+#endif
     if (RL_ABL(32768)) return;
     load_world<T>(p, s, w, n0);
     RL_MARK(1);
