@@ -298,23 +298,23 @@ __device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
     uint8_t ty[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int c = tid + u * T; ty[u] = c < p.C ? gt[c] : kPadCell; }
+    // unconditional (index clamped into the allocation, not predicated): a predicated block attracts the first uses of
+    // the loaded values -- and with them a wait -- into itself
     const bool ha = tid < p.cap;
-    uint8_t r_i = 0, r_j = 0, r_fl = 0; signed char r_act = -1;
-    int r_h = 0, r_age = 0, r_ma = 0, r_g = 0, r_b = 0, r_u = 0; double r_f = 0.0;
-    if (ha) {
-        r_i = g_i[tid]; r_j = g_j[tid];
-        r_h = g_h[tid]; r_age = g_age[tid]; r_ma = g_ma[tid];
-        r_g = g_g[tid]; r_b = g_b[tid]; r_u = g_u[tid];
-        r_fl = g_fl[tid];
-        r_act = g_act[tid];
-        r_f = g_f[tid];
-    }
+    const int ti = ha ? tid : p.cap - 1;
+    const uint8_t r_i = g_i[ti], r_j = g_j[ti], r_fl = g_fl[ti];
+    const signed char r_act = g_act[ti];
+    const int r_h = g_h[ti], r_age = g_age[ti], r_ma = g_ma[ti], r_g = g_g[ti], r_b = g_b[ti], r_u = g_u[ti];
+    const double r_f = g_f[ti];
     const int sc_val = tid == S_TICK ? v_tick : tid == S_EPOCH ? v_epoch : tid == S_NEXT_UID ? v_uid : tid == S_MAX_GENE ? v_mg : 0;
+    __builtin_amdgcn_sched_barrier(0);  // keep every use of a loaded value below the LDS initialisation (the compiler hoisted
+                                        // a shift of r_j up here, i.e. a wait for the loads right after issuing them)
     RL_MARK(30);
     // ---- LDS initialisation that needs no loaded value
     for (int c = tid; c < p.Cp; c += T) { s.occ[c] = -1; ((unsigned*)s.foodv)[c] = 0u; }
     for (int i = tid; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
     if (tid < RL_MAX_BRAINS) s.present[tid] = 0;
+    __builtin_amdgcn_sched_barrier(0);
     RL_MARK(31);
     // ---- consume the loads
     if (tid < S_COUNT) s.scal[tid] = tid == S_NSLOTS ? n0 : sc_val;
