@@ -132,25 +132,27 @@ __device__ inline void stage_x(f32x4* __restrict__ xs, const float* __restrict__
     const int lo = (int)(row_of_lane & 0xffffffff), hi = (int)(row_of_lane >> 32);
     f32x2* x2 = (f32x2*)xs;
     const int unit0 = (lane >> 1) * kXGroup + 8 * v, half = lane & 1;  // lane m: floats 4m..4m+3 = half (m&1) of group m>>1
+    const int off = lane < 38 ? 4 * lane : 149;  // every lane loads (lanes >= 38 read floats 149..152, inside the row): not
+                                                 // predicated -- a predicated load drags its first use, and a wait, up to itself
+    {
+        constexpr int r0 = 0;
+        f32x4 val[8];  // all eight rows of this wave in flight: one round trip
 #pragma unroll
-    for (int r0 = 0; r0 < 8; r0 += 4) {  // four rows in flight at a time (registers are shared with the weight ring)
-        f32x4 val[4];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
+        for (int rr = 0; rr < 8; ++rr) {
             const int jj = 8 * v + r0 + rr;
             const int64_t r = ((int64_t)__builtin_amdgcn_readlane(hi, jj) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, jj);
-            const float* xr = obs + r * RL_OBS_DIM;
-            f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (lane < 38) t = *(const f32x4u*)(xr + 4 * lane);
-            else if (lane == 38) t = f32x4{xr[152], 1.0f, 0.0f, 0.0f};  // k = 152, the bias input, padding
-            val[rr] = t;
+            val[rr] = *(const f32x4u*)(obs + r * RL_OBS_DIM + off);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (lane < 40) {
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
+            for (int rr = 0; rr < 8; ++rr) {
+                f32x4 t = val[rr];
+                if (lane == 38) t = f32x4{t.w, 1.0f, 0.0f, 0.0f};  // k = 152, the bias input, padding
+                else if (lane == 39) t = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 bf16x4 ph, pm, pl;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { __bf16 a, b, c; split3(val[rr][e], a, b, c); ph[e] = a; pm[e] = b; pl[e] = c; }
+                for (int e = 0; e < 4; ++e) { __bf16 a, b, c; split3(t[e], a, b, c); ph[e] = a; pm[e] = b; pl[e] = c; }
                 const int u = (unit0 + r0 + rr) * 2 + half;
                 x2[u] = __builtin_bit_cast(f32x2, ph);
                 x2[kXPlane * 2 + u] = __builtin_bit_cast(f32x2, pm);
