@@ -107,7 +107,11 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 3)) void k_policy(const 
         io.prof = (A.prof && (int)blockIdx.x == A.prof_block) ? A.prof : nullptr;
         if (io.prof && threadIdx.x == 0) io.prof[49] = (long long)clock64();
 #endif
+#ifdef RL_ABL_TILE  // tuning experiment: front end only
+        if (io.actions && io.valid && v == 0 && lane < 32) io.actions[io.row] = (int8_t)(io.key_tick & 7);
+#else
         policy_tile<KIND, false>(io, true, lds_h, lds_part, lane, v);
+#endif
     }
 }
 

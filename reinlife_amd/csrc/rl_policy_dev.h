@@ -107,6 +107,10 @@ __device__ inline void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo)
 // the six partial products of one K-chunk, three per accumulator chain (a / b: planes hi, mid, lo)
 __device__ inline void mfma6(const f32x4 (&a)[3], const f32x4 (&b)[3], f32x16& acc, f32x16& acc2)
 {
+#ifdef RL_ABL_MFMA  // tuning experiment: no matrix instructions (results are WRONG)
+    acc[0] += a[0][0] + a[1][0] + a[2][0] + b[0][0] + b[1][0] + b[2][0]; acc2[0] += 1.0f;
+    return;
+#endif
     acc2 = mfma(a[0], b[2], acc2);  // hi.lo
     acc = mfma(a[2], b[0], acc);    // lo.hi
     acc2 = mfma(a[1], b[1], acc2);  // mid.mid
@@ -141,7 +145,11 @@ __device__ inline void stage_x(f32x4* __restrict__ xs, const float* __restrict__
         for (int rr = 0; rr < 8; ++rr) {
             const int jj = 8 * v + r0 + rr;
             const int64_t r = ((int64_t)__builtin_amdgcn_readlane(hi, jj) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, jj);
+#ifdef RL_ABL_X  // tuning experiment: no observation reads (results are WRONG)
+            val[rr] = f32x4{(float)r, 1.0f, 2.0f, 3.0f};
+#else
             val[rr] = *(const f32x4u*)(obs + r * RL_OBS_DIM + off);
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         if (lane < 40) {
@@ -179,7 +187,11 @@ struct WRing {
     gf32x4* p;
     __device__ inline void start(gfloat* __restrict__ pw, int lane, int t0)
     {
+#ifdef RL_ABL_W  // tuning experiment: every chunk re-reads the first 3 KiB of the layer (cache hits; results are WRONG)
+        p = (gf32x4*)pw + lane;
+#else
         p = (gf32x4*)pw + t0 * 3 * 64 + lane;
+#endif
 #pragma unroll
         for (int d = 0; d < D; ++d)
 #pragma unroll
@@ -196,7 +208,9 @@ struct WRing {
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) ac[t][pl] = a[cur][t][pl];
+#ifndef RL_ABL_W
         p += TOUT * 3 * 64;
+#endif
         asm volatile("" : "+v"(p));
         if (s + D < NS) {
 #pragma unroll
@@ -349,6 +363,10 @@ __device__ inline void head_mfma(const HeadW<NT, TSTRIDE>& w, const f32x16 (&hin
 // ---------------------------------------------------------------------------------------------------------------
 // one 32-row tile, executed by 4 waves (v = 0..3) that share `lds_h` / `lds_part`
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef RL_RING_D
+#define RL_RING_D 3   // K-chunks of weights in flight per wave and layer (dueling brains)
+#endif
+
 struct TileIO {
     gfloat* packed;        // the brain's packed weights
     const float* obs;      // observation rows (153 floats each)
@@ -423,7 +441,7 @@ __device__ inline void policy_tile(const TileIO& io, bool active, f32x4* __restr
     } else if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
         f32x16 h1[1], h2[1];
         float adv[4], val[4];
-        WRing<4, 1, 1, 3> w1, w2;
+        WRing<4, 1, 1, RL_RING_D> w1, w2;
         HeadW<1, 1> wh;
         if (on) {
             w1.start(packed + L.l1, lane, v);
