@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 3)) void k_policy(const 
         static_assert(sizeof(PolicyArgs) >= 0x140 + 4 && sizeof(PolicyArgs) <= 0x180, "the warm-up loads must cover the argument block");
     }
 #ifdef RL_PHASE_PROFILE
-    if (A.prof && (int)blockIdx.x == A.prof_block && threadIdx.x == 0) A.prof[48] = (long long)clock64();
+    if (A.prof && (int)blockIdx.x == A.prof_block && blockIdx.y == 0 && threadIdx.x == 0) A.prof[48] = (long long)clock64();
 #endif
     // grid = (tiles a brain can have at most, brains of this launch): the brain and the tile follow from the block index,
     // so the row-list entry is requested together with the brain's row count instead of after it (one dependent round
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 3)) void k_policy(const 
             io.key_tick = (uint32_t)A.tick[w]; io.key_epoch = (uint32_t)A.epoch[w];
         }
 #ifdef RL_PHASE_PROFILE
-        io.prof = (A.prof && (int)blockIdx.x == A.prof_block) ? A.prof : nullptr;
+        io.prof = (A.prof && (int)blockIdx.x == A.prof_block && blockIdx.y == 0) ? A.prof : nullptr;
         if (io.prof && threadIdx.x == 0) io.prof[49] = (long long)clock64();
 #endif
 #ifdef RL_ABL_TILE  // tuning experiment: front end only

@@ -30,7 +30,7 @@ def main():
     dw = bench.make_worlds(args, 0, "cuda:0")
     stamps = torch.zeros(64, dtype=torch.int64, device="cuda:0")
     lib = _lib.lib()
-    for blocks in (0, 300, 600):
+    for blocks in (0, 150, 330):
         acc, ends = [], []
         for t in range(40):
             _lib.check(lib.rl_bind_phase_profile(dw.handle, C.c_void_p(stamps.data_ptr()), blocks), "bind")
