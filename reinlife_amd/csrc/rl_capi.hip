@@ -51,7 +51,7 @@ int rl_create(const rl_config* cfg, rl_world** out)
     const int cells = cfg->width * cfg->height;
     if (cells > RL_MAX_CELLS) { rl_set_error("rl_create: %d cells > %d supported", cells, RL_MAX_CELLS); return RL_E_UNSUPPORTED; }
     if (cfg->n_brains < 1 || cfg->n_brains > RL_MAX_BRAINS) { rl_set_error("rl_create: n_brains must be in [1,%d]", RL_MAX_BRAINS); return RL_E_INVALID; }
-    if (cfg->n_worlds < 1) { rl_set_error("rl_create: n_worlds must be >= 1"); return RL_E_INVALID; }
+    if (cfg->n_worlds < 1 || cfg->n_worlds >= (1 << 19)) { rl_set_error("rl_create: n_worlds must be in [1, 2^19)"); return RL_E_INVALID; }
     if (cfg->max_agents < 1) { rl_set_error("rl_create: max_agents must be >= 1"); return RL_E_INVALID; }
     if (cfg->slot_cap < 64 || (cfg->slot_cap & 63) || cfg->slot_cap > 4096 || cfg->slot_cap < 2 * cfg->max_agents + 2) {
         rl_set_error("rl_create: slot_cap must be a multiple of 64 in [max(64, 2*max_agents+2), 4096] (got %d)", cfg->slot_cap);

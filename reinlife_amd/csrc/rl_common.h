@@ -25,6 +25,12 @@ struct rl_world {
 
 void rl_set_error(const char* fmt, ...);
 
+// Row-list entry of the policy work buffer: (world << 12) | slot (slot_cap <= 4096, n_worlds < 2^19), so that the policy
+// kernel gets world and slot without an integer division by the runtime slot capacity.
+__host__ __device__ inline int rl_list_entry(int world, int slot) { return (world << 12) | slot; }
+__host__ __device__ inline int rl_list_world(int e) { return e >> 12; }
+__host__ __device__ inline int rl_list_slot(int e) { return e & 4095; }
+
 // ---------------------------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11).  counter = (index, site, tick, world), key = (seed_lo, seed_hi ^ epoch*phi)
 // ---------------------------------------------------------------------------------------------------------------

@@ -87,7 +87,10 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 3)) void k_policy(const 
         const int bi = blockIdx.y, tile = blockIdx.x;
         const BrainSlot B = A.b[bi];
         const int li = tile * 32 + j;
-        const int64_t listed = B.rowlist ? (int64_t)B.rowlist[li] : (int64_t)li;
+        // list entries are (world << 12) | slot (rl_common.h): world and slot without a division, row = world * cap + slot
+        const int entry = B.rowlist ? B.rowlist[li] : 0;
+        const int e_w = rl_list_world(entry), e_k = rl_list_slot(entry);
+        const int64_t listed = B.rowlist ? (int64_t)e_w * A.cap + e_k : (int64_t)li;
         const int n = B.count_ptr ? ((cint*)B.count_ptr)[0] : (int)A.n_rows;
         if (tile * 32 >= n) return;
         TileIO io;
@@ -98,10 +101,9 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 3)) void k_policy(const 
         io.eps = B.eps; io.out = A.out; io.actions = A.actions; io.seed = A.seed;
         io.key_world = io.key_tick = io.key_epoch = io.key_index = 0;
         // the draw's Philox key needs the world's tick / epoch: fetch them now, not in the epilogue's dependent chain
-        if (A.actions && v == 0 && lane < 32) {
-            const int w = (int)(io.row / A.cap);
-            io.key_world = (uint32_t)(A.world_base + w); io.key_index = (uint32_t)(io.row - (int64_t)w * A.cap);
-            io.key_tick = (uint32_t)A.tick[w]; io.key_epoch = (uint32_t)A.epoch[w];
+        if (A.actions && v == 0 && lane < 32) {  // rl_policy_act always passes row lists
+            io.key_world = (uint32_t)(A.world_base + e_w); io.key_index = (uint32_t)e_k;
+            io.key_tick = (uint32_t)A.tick[e_w]; io.key_epoch = (uint32_t)A.epoch[e_w];
         }
 #ifdef RL_PHASE_PROFILE
         io.prof = (A.prof && (int)blockIdx.x == A.prof_block && blockIdx.y == 0) ? A.prof : nullptr;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void k_bucket(const int32_t* __restrict__ n_ag
         for (int bb = 0; bb < n_brains; ++bb) {
             const unsigned long long m = __ballot(b == bb);
             const int start = __shfl(pos, bb);
-            if (b == bb) lists[bb * list_stride + start + __popcll(m & ((1ull << lane) - 1ull))] = w * cap + k;
+            if (b == bb) lists[bb * list_stride + start + __popcll(m & ((1ull << lane) - 1ull))] = rl_list_entry(w, k);
             if (lane == bb) pos += __popcll(m);
         }
     }

@@ -981,7 +981,7 @@ __device__ inline void emit_brain_lists_wave0(const KParams& p, int w, int n, F 
         for (int bb = 0; bb < p.n_brains; ++bb) {
             const unsigned long long m = __ballot(b == bb);
             const int start = read_lane(pos, bb);
-            if (b == bb) p.lists[bb * p.list_stride + start + __popcll(m & lowmask(lane))] = w * p.cap + k;
+            if (b == bb) p.lists[bb * p.list_stride + start + __popcll(m & lowmask(lane))] = rl_list_entry(w, k);
             if (lane == bb) pos += __popcll(m);
         }
     }
