@@ -61,8 +61,8 @@ typedef struct {
     int32_t width, height;
     int32_t max_agents;
     int32_t n_brains;            /* len(brains) */
-    int32_t slot_cap;            /* capacity of the per-world agent arrays; multiple of 64, >= 2*max_agents+2 */
-    int32_t n_worlds;
+    int32_t slot_cap;            /* capacity of the per-world agent arrays; multiple of 64, >= 2*max_agents+2, <= 4096 */
+    int32_t n_worlds;            /* independent replicas on this GPU, < 2^19 */
     int32_t static_families, limit_reproduction, incentivize_killing;
     int32_t world_base;          /* global id of world 0 (replica sharding across GPUs): Philox uses world_base + w */
     uint64_t seed;               /* Philox key */
