@@ -430,21 +430,25 @@ __device__ void write_observations(const KParams& p, Smem& s, int w, int n, floa
 {
     if (!obs || RL_ABL(1)) return;
     float* base = obs + (size_t)w * p.cap * RL_OBS_DIM;
-    const int total = n * 49;
-    for (int q = threadIdx.x; q < total; q += T) {
-        const int k = q / 49, idx = q - k * 49;
-        const int a = s.order[k];
-        const int i = s.pos[a] & 255, j = s.pos[a] >> 8;
-        const int r = idx / 7, cc = idx - r * 7;
-        int ci = i + r - 3, cj = j + cc - 3;
-        ci += ci < 0 ? p.H : 0; ci -= ci >= p.H ? p.H : 0;
-        cj += cj < 0 ? p.W : 0; cj -= cj >= p.W ? p.W : 0;
-        const int c = ci * p.W + cj;
-        const int g = s.genev[c];
-        float* o = base + (size_t)k * RL_OBS_DIM + idx;
-        o[0] = s.foodv[c];
-        o[49] = s.healthv[c];
-        o[98] = g == -2 ? 0.f : (g == s.gene[a] ? 1.f : -1.f);  // _extract_gene_observation, environment.py:424-428
+    // thread t owns window cell idx = t % 49 for agents t / 49, t / 49 + T / 49, ...: the divisions and the window offsets
+    // are computed once per thread, not once per (agent, cell) item
+    constexpr int G = T / 49;
+    const int g0 = threadIdx.x / 49, idx = threadIdx.x - g0 * 49;
+    const int dr = idx / 7 - 3, dc = idx - (idx / 7) * 7 - 3;
+    if (g0 < G) {
+        float* o = base + (size_t)g0 * RL_OBS_DIM + idx;
+        for (int k = g0; k < n; k += G, o += (size_t)G * RL_OBS_DIM) {
+            const int a = s.order[k];
+            const int pa = s.pos[a];
+            int ci = (pa & 255) + dr, cj = (pa >> 8) + dc;
+            ci += ci < 0 ? p.H : 0; ci -= ci >= p.H ? p.H : 0;
+            cj += cj < 0 ? p.W : 0; cj -= cj >= p.W ? p.W : 0;
+            const int c = ci * p.W + cj;
+            const int g = s.genev[c];
+            o[0] = s.foodv[c];
+            o[49] = s.healthv[c];
+            o[98] = g == -2 ? 0.f : (g == s.gene[a] ? 1.f : -1.f);  // _extract_gene_observation, environment.py:424-428
+        }
     }
     for (int k = threadIdx.x; k < n; k += T) {
         const int a = s.order[k];
