@@ -28,7 +28,10 @@
 //   * the narrow heads (8 / 1 outputs) run on the VALU (an MFMA tile would be 75-97 % padding), followed by the
 //     dueling combine / softmax and the epsilon-greedy / categorical draw (Philox) in the same kernel.
 #include "rl_policy_dev.h"
+#include <math.h>
 #include <string.h>
+
+#include <vector>
 
 namespace {
 
@@ -65,6 +68,7 @@ template <int KIND>
 __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 3)) void k_policy(const PolicyArgs A)
 {
     __shared__ __attribute__((aligned(16))) f32x4 lds_h[policy_lds_units(KIND)];
+    __shared__ __attribute__((aligned(16))) float lds_aux[kAuxFloats];  // row scales
     __shared__ float lds_part[4][32][9];                        // per-wave head partials
     const int lane = threadIdx.x & 63, j = lane & 31, v = threadIdx.x >> 6;
     {   // one batch of scalar loads touches every 64-byte line of the argument block (the brain table is read entry by
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 3)) void k_policy(const 
 #ifdef RL_ABL_TILE  // tuning experiment: front end only
         if (io.actions && io.valid && v == 0 && lane < 32) io.actions[io.row] = (int8_t)(io.key_tick & 7);
 #else
-        policy_tile<KIND, false>(io, true, lds_h, lds_part, lane, v);
+        policy_tile<KIND>(io, lds_h, lds_aux, lds_part, lane, v);
 #endif
     }
 }
@@ -169,52 +173,78 @@ int64_t rl_policy_packed_floats_impl(int kind)
     return layout_of(kind).total;
 }
 
-static inline uint16_t bf16_rne(float f)  // round to nearest even (finite inputs)
+// ---- f16 split of a scaled weight (host mirror of split_pair): hi = x toward zero, lo' = (x - hi) * 2^11 toward zero ----
+static inline uint16_t f16_rtz(float f)  // |f| < 65504 (scaled weights are < 2^12), result exact toward zero
 {
     uint32_t u;
     memcpy(&u, &f, 4);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const int e = (int)((u >> 23) & 0xff) - 127;
+    const uint32_t man = u & 0x7fffffu;
+    if (e < -24) return (uint16_t)sign;                                       // below the smallest subnormal
+    if (e < -14) return (uint16_t)(sign | ((man | 0x800000u) >> (13 + (-14 - e))));  // subnormal, truncated
+    return (uint16_t)(sign | (uint32_t)((e + 15) << 10) | (man >> 13));
 }
-static inline float bf16_to_float(uint16_t h)
+static inline float f16_to_float(uint16_t h)
 {
-    const uint32_t u = (uint32_t)h << 16;
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1f, man = h & 0x3ffu;
     float f;
+    if (e == 0) { f = (float)man * (1.0f / 16777216.0f); uint32_t u; memcpy(&u, &f, 4); u |= sign; memcpy(&f, &u, 4); return f; }
+    const uint32_t u = sign | ((e - 15 + 127) << 23) | (man << 13);
     memcpy(&f, &u, 4);
     return f;
 }
-static inline void split3_host(float x, uint16_t (&out)[3])
+static inline void split2_host(float x, uint16_t (&out)[2])
 {
-    out[0] = bf16_rne(x);
-    const float r1 = x - bf16_to_float(out[0]);
-    out[1] = bf16_rne(r1);
-    out[2] = bf16_rne(r1 - bf16_to_float(out[1]));
+    out[0] = f16_rtz(x);
+    out[1] = f16_rtz((x - f16_to_float(out[0])) * kLoScale);
+}
+// scale of output feature o of a row-major [n_out][n_in] matrix: 2^(kScaleExp - exponent(max |W[o][:]|))
+static void feature_scales(const float* W, int n_out, int n_in, std::vector<float>& sc, std::vector<float>& un)
+{
+    sc.resize(n_out); un.resize(n_out);
+    for (int o = 0; o < n_out; ++o) {
+        float mx = 0.0f;
+        for (int k = 0; k < n_in; ++k) mx = fmaxf(mx, fabsf(W[(size_t)o * n_in + k]));
+        row_scale(mx, sc[o], un[o]);
+    }
+}
+static void write_epilogue_consts(float* consts, int tout, const std::vector<float>& un, const float* b)
+{
+    // per output tile t2 and lane half h: [unscale 16 | bias 16] for feature 32 t2 + (r&3) + 8(r>>2) + 4h, r = 0..15
+    for (int t2 = 0; t2 < tout; ++t2)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) {
+                const int o = 32 * t2 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                consts[(t2 * 2 + h) * 32 + r] = un[o];
+                consts[(t2 * 2 + h) * 32 + 16 + r] = b[o];
+            }
 }
 
 static void pack_in_layer(const float* W, const float* b, int n_out, float* dst)
 {
-    // dst16[c][t][plane][lane][e] = part_plane(Wext[32t + (lane&31)][16c + 8(lane>>5) + e]),  Wext[:,153] = bias,
-    // Wext[:,154..159] = 0
+    // dst16[c][t][plane][lane][e] = part_plane(scale[o] * W[o = 32t + (lane&31)][k = 16c + 8(lane>>5) + e]), zero for k >= 153
     const int tout = n_out / 32;
+    std::vector<float> sc, un;
+    feature_scales(W, n_out, 153, sc, un);
     uint16_t* d16 = (uint16_t*)dst;
     for (int c = 0; c < kInChunks; ++c)
         for (int t = 0; t < tout; ++t)
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 8; ++e) {
                     const int o = 32 * t + (lane & 31), k = 16 * c + 8 * (lane >> 5) + e;
-                    float v = 0.0f;
-                    if (k < 153) v = W[(size_t)o * 153 + k];
-                    else if (k == kBiasK) v = b[o];
-                    uint16_t parts[3];
-                    split3_host(v, parts);
-                    for (int pl = 0; pl < 3; ++pl) d16[(((((size_t)c * tout + t) * 3 + pl) * 64 + lane) * 8) + e] = parts[pl];
+                    uint16_t parts[2];
+                    split2_host(k < 153 ? W[(size_t)o * 153 + k] * sc[o] : 0.0f, parts);
+                    for (int pl = 0; pl < kPlanes; ++pl) d16[(((((size_t)c * tout + t) * kPlanes + pl) * 64 + lane) * 8) + e] = parts[pl];
                 }
+    write_epilogue_consts(dst + frag_floats(kInChunks, tout), tout, un, b);
 }
 static void pack_hidden_layer(const float* W, const float* b, int n_in, int n_out, float* dst)
 {
-    // dst16[s = t*2+c][t2][plane][lane][e] = part_plane(W[32 t2 + (lane&31)][32 t + (r&3) + 8(r>>2) + 4(lane>>5)]), r = 8c + e;
-    // then f32 bias[t2][h][r] = b[32 t2 + (r&3) + 8(r>>2) + 4h] (accumulator order)
+    // dst16[s = t*2+c][t2][plane][lane][e] = part_plane(scale[o] * W[o = 32 t2 + (lane&31)][32 t + (r&3) + 8(r>>2) + 4(lane>>5)]), r = 8c + e
     const int tin = n_in / 32, tout = n_out / 32;
+    std::vector<float> sc, un;
+    feature_scales(W, n_out, n_in, sc, un);
     uint16_t* d16 = (uint16_t*)dst;
     for (int t = 0; t < tin; ++t)
         for (int c = 0; c < 2; ++c)
@@ -223,32 +253,32 @@ static void pack_hidden_layer(const float* W, const float* b, int n_in, int n_ou
                     for (int e = 0; e < 8; ++e) {
                         const int r = 8 * c + e;
                         const int o = 32 * t2 + (lane & 31), k = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        uint16_t parts[3];
-                        split3_host(W[(size_t)o * n_in + k], parts);
+                        uint16_t parts[2];
+                        split2_host(W[(size_t)o * n_in + k] * sc[o], parts);
                         const size_t sidx = (size_t)t * 2 + c;
-                        for (int pl = 0; pl < 3; ++pl) d16[((((sidx * tout + t2) * 3 + pl) * 64 + lane) * 8) + e] = parts[pl];
+                        for (int pl = 0; pl < kPlanes; ++pl) d16[((((sidx * tout + t2) * kPlanes + pl) * 64 + lane) * 8) + e] = parts[pl];
                     }
-    float* bias = dst + (size_t)(2 * tin) * tout * 3 * 64 * 4;
-    for (int t2 = 0; t2 < tout; ++t2)
-        for (int h = 0; h < 2; ++h)
-            for (int r = 0; r < 16; ++r) bias[(t2 * 2 + h) * 16 + r] = b[32 * t2 + (r & 3) + 8 * (r >> 2) + 4 * h];
+    write_epilogue_consts(dst + frag_floats(2 * tin, tout), tout, un, b);
 }
 static void pack_head(const float* W, const float* b, int n_in, int n_out, float* dst)
 {
-    // dst16[t][c][plane][lane][e] = part_plane(W[lane&31][32 t + (r&3) + 8(r>>2) + 4(lane>>5)]), r = 8c + e, rows >= n_out
-    // are zero; then f32 bias[n_out]
+    // dst16[t][c][plane][lane][e] = part_plane(scale[o] * W[o = lane&31][32 t + (r&3) + 8(r>>2) + 4(lane>>5)]), r = 8c + e, rows
+    // >= n_out are zero; then unscale[8] (1 for unused outputs), then bias[8] (0 for unused outputs)
     const int tin = n_in / 32;
+    std::vector<float> sc, un;
+    feature_scales(W, n_out, n_in, sc, un);
     uint16_t* d16 = (uint16_t*)dst;
     for (int t = 0; t < tin; ++t)
         for (int c = 0; c < 2; ++c)
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 8; ++e) {
                     const int r = 8 * c + e, o = lane & 31, k = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    uint16_t parts[3];
-                    split3_host(o < n_out ? W[(size_t)o * n_in + k] : 0.0f, parts);
-                    for (int pl = 0; pl < 3; ++pl) d16[(((((size_t)t * 2 + c) * 3 + pl) * 64 + lane) * 8) + e] = parts[pl];
+                    uint16_t parts[2];
+                    split2_host(o < n_out ? W[(size_t)o * n_in + k] * sc[o] : 0.0f, parts);
+                    for (int pl = 0; pl < kPlanes; ++pl) d16[(((((size_t)t * 2 + c) * kPlanes + pl) * 64 + lane) * 8) + e] = parts[pl];
                 }
-    for (int i = 0; i < n_out; ++i) dst[head_bias_off(tin) + i] = b[i];
+    float* consts = dst + head_consts_off(tin);
+    for (int i = 0; i < 8; ++i) { consts[i] = i < n_out ? un[i] : 1.0f; consts[8 + i] = i < n_out ? b[i] : 0.0f; }
 }
 
 int rl_policy_pack_impl(int kind, const float* sd, float* packed)

@@ -11,14 +11,17 @@
 // chain per tile and 4x more waves than one-wave-per-tile, which is what matters at 256 worlds = ~700 tiles on
 // 1024 SIMDs), activations cross waves through LDS once per layer:
 //
-//   * fp32 results from the bf16 matrix pipe ("3 x bf16"): every f32 operand is split into three bf16 parts
-//     x = hi + mid + lo (8 + 8 + 8 mantissa bits, each part the round-to-nearest bf16 of the remaining residual, so the
-//     three parts carry the whole 24-bit f32 mantissa) and a product is the sum of the six partial products of weight
-//     2^-16 or more (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi), each EXACT in the f32 accumulator of
-//     v_mfma_f32_32x32x16_bf16.  The dropped terms are below 2^-23 relative -- the size of f32's own rounding -- so the
-//     result is f32-grade (measured error vs torch ~1e-6, the bar is 1e-5) at 6 x 32 cycles per 16 k instead of
-//     8 x 64 with v_mfma_f32_32x32x2_f32: 2.7x the f32 matrix rate.  Weights are split once when packed, activations
-//     once where they are produced (observation staging / layer output), so the split costs a few VALU ops per value.
+//   * f32-grade results from the f16 matrix pipe ("2 x f16, block-scaled"): every f32 operand row is scaled by a power
+//     of two so that its largest element lands in [2^10, 2^11) -- per observation / activation ROW (the B operand's
+//     columns) and per output FEATURE of the weights (the A operand's rows), so the scale factors leave the MFMA as one
+//     multiply per accumulator register -- and split into two f16 parts x = hi + lo' / 2048 (hi = x rounded toward zero to
+//     11 bits, lo' = the exact remainder times 2^11, again 11 bits: 22 bits of every operand, measured against the row
+//     maximum).  A product is hi.hi + (hi.lo' + lo'.hi) / 2048, three v_mfma_f32_32x32x16_f16 per 16 k with f32
+//     accumulation (the cross terms in their own accumulator); the dropped lo.lo term is 2^-22 relative.  Measured
+//     difference to the reference's torch outputs on the golden vectors: ~1e-7 (the bar is 1e-5) -- the same as an f32
+//     numpy forward.  The power-of-two scaling makes the scheme independent of the operands' magnitude (f16 alone
+//     would overflow at 65504 and lose small values).  History: f32-input MFMA (8 x 64 cycles per 16 k) -> three bf16
+//     planes, six products (6 x 32) -> this (3 x 32 cycles, 4 bytes per weight instead of 6).
 //   * transposed formulation  H_out[feature][row] = W[feature][k] . H_in[k][row]: the WEIGHTS are the MFMA A operand
 //     and the ACTIVATIONS the B operand.  The 32x32 f32 accumulator layout (lane = row, register r of half h =
 //     feature (r&3) + 8(r>>2) + 4h) is dtype-independent, so a lane's registers 8c..8c+7 are exactly its 8 B-operand
@@ -35,23 +38,27 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // weight pointers come out of a runtime-indexed brain table, which makes them generic (flat_load, counted on lgkmcnt AND
 // vmcnt); they always point to device global memory, so say so: global_load + a prefetch ring that survives LDS barriers
 typedef const float __attribute__((address_space(1))) gfloat;
 typedef const f32x4 __attribute__((address_space(1))) gf32x4;
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int kInChunks = 10;        // input layer: K = 153 padded to 160 = 10 chunks of 16 (lanes 0-31: k 16c..16c+7, lanes 32-63: +8)
+constexpr int kPlanes = 2;           // hi, lo' (= lo * 2^11)
+constexpr float kLoScale = 2048.0f;  // 2^11
+constexpr float kLoUnscale = 1.0f / 2048.0f;
+constexpr int kScaleExp = 10;        // a scaled row's maximum lies in [2^10, 2^11)
 
-constexpr int kInChunks = 10;    // input layer: K padded to 160 = 10 chunks of 16 (lanes 0-31: k 16c..16c+7, lanes 32-63: +8)
-constexpr int kBiasK = 153;      // x[153] := 1, W[:,153] := bias
-
-// packed sizes in 4-byte units: a fragment is 8 bf16 = 16 bytes per lane, three planes (hi, mid, lo) per fragment
-__host__ __device__ constexpr int64_t in_layer_floats(int tiles) { return (int64_t)kInChunks * tiles * 3 * 64 * 4; }
-__host__ __device__ constexpr int64_t hid_layer_floats(int tin, int tout) { return (int64_t)(2 * tin) * tout * 3 * 64 * 4 + (int64_t)tout * 32; }
-__host__ __device__ constexpr int64_t head_floats(int tin, int nout) { return (int64_t)tin * 2 * 3 * 64 * 4 + nout; }  // fragments + f32 bias
-__host__ __device__ constexpr int64_t head_bias_off(int tin) { return (int64_t)tin * 2 * 3 * 64 * 4; }
+// packed sizes in 4-byte units: a fragment is 8 f16 = 16 bytes per lane, two planes per fragment; every output tile of
+// an MFMA layer carries 64 epilogue constants [half h][unscale 16 | bias 16] in accumulator order
+__host__ __device__ constexpr int64_t frag_floats(int chunks, int tout) { return (int64_t)chunks * tout * kPlanes * 64 * 4; }
+__host__ __device__ constexpr int64_t in_layer_floats(int tout) { return frag_floats(kInChunks, tout) + (int64_t)tout * 64; }
+__host__ __device__ constexpr int64_t hid_layer_floats(int tin, int tout) { return frag_floats(2 * tin, tout) + (int64_t)tout * 64; }
+// head: fragments (output rows >= n_out are zero), then unscale[8], then bias[8]
+__host__ __device__ constexpr int64_t head_consts_off(int tin) { return frag_floats(2 * tin, 1); }
+__host__ __device__ constexpr int64_t head_floats(int tin, int nout) { return head_consts_off(tin) + 16; }
 
 struct Layout {  // offsets (floats) into a brain's packed buffer
     int64_t l1, l2a, l2b, ha, hb, total;
@@ -79,6 +86,18 @@ __host__ __device__ inline Layout layout_of(int kind)
     return L;
 }
 
+// power-of-two scale of a row whose largest magnitude is mx: s = 2^(kScaleExp - exponent(mx)), r = 1 / s.  Host and device
+// use the same rule.  mx == 0 (or tiny) is clamped to an exponent that keeps both factors finite.
+__host__ __device__ inline void row_scale(float mx, float& s, float& r)
+{
+    union { float f; int i; } u;
+    u.f = mx;
+    int eb = (u.i >> 23) & 0xff;
+    eb = eb < 32 ? 32 : (eb > 230 ? 230 : eb);
+    u.i = (254 + kScaleExp - eb) << 23; s = u.f;
+    u.i = (eb - kScaleExp) << 23; r = u.f;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // device building blocks (everything fully unrolled: accumulators must stay in registers)
 // ---------------------------------------------------------------------------------------------------------------
@@ -90,245 +109,234 @@ __device__ inline void lds_barrier() { __syncthreads(); }
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
 
-__device__ inline f32x16 mfma(const f32x4& a, const f32x4& b, f32x16 c)
+__device__ inline f32x16 mfma16(const f32x4& a, const f32x4& b, f32x16 c)
 {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// x = hi + mid + lo, each the bf16 nearest to what is left (the subtractions are exact in f32)
-__device__ inline void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo)
+// the three partial products of one K-chunk (a / b: planes hi, lo'): hi.hi into `main`, the cross terms into `cross`
+__device__ inline void mfma3(const f32x4 (&a)[kPlanes], const f32x4 (&b)[kPlanes], f32x16& main, f32x16& cross)
 {
-    hi = (__bf16)x;
-    const float r1 = x - (float)hi;
-    mid = (__bf16)r1;
-    lo = (__bf16)(r1 - (float)mid);
+    cross = mfma16(a[0], b[1], cross);  // hi.lo'
+    main = mfma16(a[0], b[0], main);    // hi.hi
+    cross = mfma16(a[1], b[0], cross);  // lo'.hi
 }
 
-// the six partial products of one K-chunk, three per accumulator chain (a / b: planes hi, mid, lo)
-__device__ inline void mfma6(const f32x4 (&a)[3], const f32x4 (&b)[3], f32x16& acc, f32x16& acc2)
+// two already-scaled values -> packed f16 pairs: hi = x toward zero, lo' = (x - hi) * 2^11 (the subtraction is exact)
+__device__ inline void split_pair(float x0, float x1, unsigned& hi, unsigned& lo)
 {
-#ifdef RL_ABL_MFMA  // tuning experiment: no matrix instructions (results are WRONG)
-    acc[0] += a[0][0] + a[1][0] + a[2][0] + b[0][0] + b[1][0] + b[2][0]; acc2[0] += 1.0f;
-    return;
-#endif
-    acc2 = mfma(a[0], b[2], acc2);  // hi.lo
-    acc = mfma(a[2], b[0], acc);    // lo.hi
-    acc2 = mfma(a[1], b[1], acc2);  // mid.mid
-    acc = mfma(a[1], b[0], acc);    // mid.hi
-    acc2 = mfma(a[0], b[1], acc2);  // hi.mid
-    acc = mfma(a[0], b[0], acc);    // hi.hi
+    const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    hi = __builtin_bit_cast(unsigned, h);
+    const auto l = __builtin_amdgcn_cvt_pkrtz((x0 - (float)h[0]) * kLoScale, (x1 - (float)h[1]) * kLoScale);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ inline void split8(const float (&x)[8], f32x4& hi, f32x4& lo)
+{
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split_pair(x[2 * q], x[2 * q + 1], h[q], l[q]);
+    hi = f32x4{__builtin_bit_cast(float, h[0]), __builtin_bit_cast(float, h[1]), __builtin_bit_cast(float, h[2]), __builtin_bit_cast(float, h[3])};
+    lo = f32x4{__builtin_bit_cast(float, l[0]), __builtin_bit_cast(float, l[1]), __builtin_bit_cast(float, l[2]), __builtin_bit_cast(float, l[3])};
 }
 
-// Observation tile in LDS, split and already in B-operand order: plane p (hi, mid, lo) holds, for K-chunk c and lane
-// (row j = lane&31, half kh = lane>>5), the 8 bf16 x[j][16c + 8kh + 0..7] as one 16-byte unit at
-// p*kXPlane + (2c + kh)*33 + j, with x[153] := 1 (bias input) and x[154..159] := 0.  Groups are 33 (not 32) units
-// apart so that the staging writes of one row (40 lanes, one 8-byte half unit each) spread over the banks.
+// maximum of a non-negative float over the 64 lanes (DPP: no LDS traffic), returned in every lane
+__device__ inline float wave_max_nonneg(float v)
+{
+    int i = __builtin_bit_cast(int, v);  // non-negative floats order like their bit patterns
+    i = max(i, __builtin_amdgcn_update_dpp(0, i, 0x111, 0xF, 0xF, true));  // row_shr:1
+    i = max(i, __builtin_amdgcn_update_dpp(0, i, 0x112, 0xF, 0xF, true));  // row_shr:2
+    i = max(i, __builtin_amdgcn_update_dpp(0, i, 0x114, 0xF, 0xF, true));  // row_shr:4
+    i = max(i, __builtin_amdgcn_update_dpp(0, i, 0x118, 0xF, 0xF, true));  // row_shr:8
+    i = max(i, __builtin_amdgcn_update_dpp(0, i, 0x142, 0xA, 0xF, true));  // row_bcast:15
+    i = max(i, __builtin_amdgcn_update_dpp(0, i, 0x143, 0xC, 0xF, true));  // row_bcast:31
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 63));
+}
+
+// Observation tile in LDS, scaled, split and already in B-operand order: plane p (hi, lo') holds, for K-chunk c and lane
+// (row j = lane&31, half kh = lane>>5), the 8 f16 of x[j][16c + 8kh + 0..7] (zero beyond k = 152) as one 16-byte unit
+// at p*kXPlane + (2c + kh)*33 + j.  Groups are 33 (not 32) units apart so that the staging writes of one row (40 lanes,
+// one 8-byte half unit each) spread over the banks.
 constexpr int kXGroup = 33;
 constexpr int kXPlane = 2 * kInChunks * kXGroup;
-constexpr int kXsUnits = 3 * kXPlane;
+constexpr int kXsUnits = kPlanes * kXPlane;
 
 // Stage the 32 rows of a tile: wave v loads rows 8v..8v+7, ONE coalesced 612-byte read per row (lane m reads floats
 // 4m..4m+3), instead of every wave gathering 16 bytes per lane from 32 different rows for each K-step (64 cache lines
-// per load instruction, four times over): the input layer was request-bound on the vector L1.
+// per load instruction, four times over).  Every row gets its power-of-two scale here (row maximum by DPP); 1 / scale
+// goes to row_unscale[row] for the input layer's epilogue.
 // `row_of_lane`: observation row id of tile row (lane & 31).
-__device__ inline void stage_x(f32x4* __restrict__ xs, const float* __restrict__ obs, int64_t row_of_lane, int lane, int v)
+__device__ inline void stage_x(f32x4* __restrict__ xs, float* __restrict__ row_unscale, const float* __restrict__ obs,
+                               int64_t row_of_lane, int lane, int v)
 {
     const int lo = (int)(row_of_lane & 0xffffffff), hi = (int)(row_of_lane >> 32);
     f32x2* x2 = (f32x2*)xs;
     const int unit0 = (lane >> 1) * kXGroup + 8 * v, half = lane & 1;  // lane m: floats 4m..4m+3 = half (m&1) of group m>>1
     const int off = lane < 38 ? 4 * lane : 149;  // every lane loads (lanes >= 38 read floats 149..152, inside the row): not
                                                  // predicated -- a predicated load drags its first use, and a wait, up to itself
-    {
-        constexpr int r0 = 0;
-        f32x4 val[8];  // all eight rows of this wave in flight: one round trip
+    f32x4 val[8];  // all eight rows of this wave in flight: one round trip
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int jj = 8 * v + r0 + rr;
-            const int64_t r = ((int64_t)__builtin_amdgcn_readlane(hi, jj) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, jj);
+    for (int rr = 0; rr < 8; ++rr) {
+        const int jj = 8 * v + rr;
+        const int64_t r = ((int64_t)__builtin_amdgcn_readlane(hi, jj) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, jj);
 #ifdef RL_ABL_X  // tuning experiment: no observation reads (results are WRONG)
-            val[rr] = f32x4{(float)r, 1.0f, 2.0f, 3.0f};
+        val[rr] = f32x4{(float)r, 1.0f, 2.0f, 3.0f};
 #else
-            val[rr] = *(const f32x4u*)(obs + r * RL_OBS_DIM + off);
+        val[rr] = *(const f32x4u*)(obs + r * RL_OBS_DIM + off);
 #endif
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        f32x4 t = val[rr];
+        if (lane == 38) t = f32x4{t.w, 0.0f, 0.0f, 0.0f};  // k = 152, then padding
+        else if (lane > 38) t = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const float mx = wave_max_nonneg(fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w))));
+        float sc, un;
+        row_scale(mx, sc, un);
+        if (lane == 0) row_unscale[8 * v + rr] = un;
         if (lane < 40) {
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                f32x4 t = val[rr];
-                if (lane == 38) t = f32x4{t.w, 1.0f, 0.0f, 0.0f};  // k = 152, the bias input, padding
-                else if (lane == 39) t = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                bf16x4 ph, pm, pl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { __bf16 a, b, c; split3(t[e], a, b, c); ph[e] = a; pm[e] = b; pl[e] = c; }
-                const int u = (unit0 + r0 + rr) * 2 + half;
-                x2[u] = __builtin_bit_cast(f32x2, ph);
-                x2[kXPlane * 2 + u] = __builtin_bit_cast(f32x2, pm);
-                x2[kXPlane * 4 + u] = __builtin_bit_cast(f32x2, pl);
-            }
+            unsigned h0, l0, h1, l1;
+            split_pair(t.x * sc, t.y * sc, h0, l0);
+            split_pair(t.z * sc, t.w * sc, h1, l1);
+            const int u = (unit0 + rr) * 2 + half;
+            x2[u] = f32x2{__builtin_bit_cast(float, h0), __builtin_bit_cast(float, h1)};
+            x2[kXPlane * 2 + u] = f32x2{__builtin_bit_cast(float, l0), __builtin_bit_cast(float, l1)};
         }
     }
 }
 
-// The packed weights are STEP-major: [K-chunk][output tile][plane][lane][8 bf16], so the fragments of one chunk are
+// The packed weights are STEP-major: [K-chunk][output tile][plane][lane][8 f16], so the fragments of one chunk are
 // 1 KiB apart (immediate offsets of one running pointer).  The pointer is made opaque at every step so that the
 // compiler neither precomputes nor hoists hundreds of 64-bit addresses, and a sched_barrier per step bounds the
 // prefetch distance to exactly one step.
 //
-// layer_in: this wave computes output tiles {t0, t0 + TSTRIDE, ...} (NT of them) of a layer with TOUT tiles; the
-// B operand comes from the staged observation tile.  D = prefetch ring depth in K-chunks: a chunk is only 6*NT MFMAs
-// (192*NT cycles), an L2 round trip under load is several times that, so D chunks of weights are kept in flight.
-// Weight prefetch ring of one layer for one wave: D K-chunks of A fragments (3 planes each) in flight.  start() only
+// Weight prefetch ring of one layer for one wave: D K-chunks of A fragments (2 planes each) in flight.  start() only
 // needs the packed pointer, so it is issued BEFORE the wait that precedes the layer (observation staging, the LDS
-// exchange of the previous layer, the VALU head): the first L2 round trip of every layer overlaps that wait.
+// exchange of the previous layer, the head): the first L2 round trip of every layer overlaps that wait.
 template <int TOUT, int NT, int TSTRIDE, int D>
 struct WRing {
-    f32x4 a[D][NT][3];
+    f32x4 a[D][NT][kPlanes];
     gf32x4* p;
     __device__ inline void start(gfloat* __restrict__ pw, int lane, int t0)
     {
-#ifdef RL_ABL_W  // tuning experiment: every chunk re-reads the first 3 KiB of the layer (cache hits; results are WRONG)
+#ifdef RL_ABL_W  // tuning experiment: every chunk re-reads the first fragments of the layer (cache hits; results are WRONG)
         p = (gf32x4*)pw + lane;
 #else
-        p = (gf32x4*)pw + t0 * 3 * 64 + lane;
+        p = (gf32x4*)pw + t0 * kPlanes * 64 + lane;
 #endif
 #pragma unroll
         for (int d = 0; d < D; ++d)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[d][t][pl] = p[((d * TOUT + t * TSTRIDE) * 3 + pl) * 64];
+                for (int pl = 0; pl < kPlanes; ++pl) a[d][t][pl] = p[((d * TOUT + t * TSTRIDE) * kPlanes + pl) * 64];
     }
     // take chunk s out of the ring and refill its slot with chunk s + D (of NS)
     template <int NS>
-    __device__ inline void next(int s, f32x4 (&ac)[NT][3])
+    __device__ inline void next(int s, f32x4 (&ac)[NT][kPlanes])
     {
         const int cur = s % D;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) ac[t][pl] = a[cur][t][pl];
+            for (int pl = 0; pl < kPlanes; ++pl) ac[t][pl] = a[cur][t][pl];
 #ifndef RL_ABL_W
-        p += TOUT * 3 * 64;
+        p += TOUT * kPlanes * 64;
 #endif
         asm volatile("" : "+v"(p));
         if (s + D < NS) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[cur][t][pl] = p[(((D - 1) * TOUT + t * TSTRIDE) * 3 + pl) * 64];
+                for (int pl = 0; pl < kPlanes; ++pl) a[cur][t][pl] = p[(((D - 1) * TOUT + t * TSTRIDE) * kPlanes + pl) * 64];
         }
     }
 };
 
-template <int TOUT, int NT, int TSTRIDE, int D>
-__device__ inline void layer_in(WRing<TOUT, NT, TSTRIDE, D>& w, int lane, const f32x4* __restrict__ xs, f32x16 (&acc)[NT])
+// K loop of one layer: B fragments from LDS planes `bsrc` (unit stride `bstep` per chunk, plane stride `bplane`), A
+// fragments from the ring.  Leaves acc[t] = sum hi.hi + (hi.lo' + lo'.hi) / 2^11, still in the scaled domain.
+template <int NS, int TOUT, int NT, int TSTRIDE, int D>
+__device__ inline void k_loop(WRing<TOUT, NT, TSTRIDE, D>& w, const f32x4* __restrict__ bsrc, int bplane, int bstep, f32x16 (&acc)[NT])
 {
-    f32x16 acc2[NT];  // second accumulator chain: consecutive MFMAs of one wave do not wait for each other's result
+    f32x16 cross[NT];  // second accumulator chain: also keeps consecutive MFMAs of one wave independent
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; acc2[t][r] = 0.0f; }
-    f32x4 x[2][3];
-    const int xb = (lane >> 5) * kXGroup + (lane & 31);
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; cross[t][r] = 0.0f; }
+    f32x4 b[2][kPlanes];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) x[0][pl] = xs[pl * kXPlane + xb];
-#pragma unroll
-    for (int c = 0; c < kInChunks; ++c) {
-        f32x4 ac[NT][3], xc[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) xc[pl] = x[c & 1][pl];
-        w.template next<kInChunks>(c, ac);
-        if (c + 1 < kInChunks) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) x[(c + 1) & 1][pl] = xs[pl * kXPlane + xb + (c + 1) * 2 * kXGroup];
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) mfma6(ac[t], xc, acc[t], acc2[t]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] += acc2[t][r];
-}
-
-template <int NT>
-__device__ inline void relu_inplace(f32x16 (&h)[NT])
-{
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h[t][r] = fmaxf(h[t][r], 0.0f);
-}
-
-// Publish this wave's activation tile `t` to the workgroup, split: plane p unit (t*2 + c)*64 + lane = registers
-// 8c..8c+7, i.e. exactly the B-operand fragment of K-chunk (t, c) of the next layer for this lane.
-__device__ inline void publish_tile(f32x4* lds, int plane_units, int t, int lane, const f32x16& h)
-{
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        bf16x8 ph, pm, pl;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { __bf16 x, y, z; split3(h[8 * c + e], x, y, z); ph[e] = x; pm[e] = y; pl[e] = z; }
-        const int u = (t * 2 + c) * 64 + lane;
-        lds[u] = __builtin_bit_cast(f32x4, ph);
-        lds[plane_units + u] = __builtin_bit_cast(f32x4, pm);
-        lds[2 * plane_units + u] = __builtin_bit_cast(f32x4, pl);
-    }
-}
-
-// layer_hidden: input = TIN published tiles in LDS (three planes of TIN*128 units); this wave computes output tiles
-// {t0, t0 + TSTRIDE, ...}.  The accumulators start from the bias (packed in accumulator order, behind the fragments).
-template <int TIN, int TOUT, int NT, int TSTRIDE, int D>
-__device__ inline void layer_hidden(WRing<TOUT, NT, TSTRIDE, D>& w, gfloat* __restrict__ pw, int lane, int t0,
-                                    const f32x4* __restrict__ hin, f32x16 (&acc)[NT])
-{
-    constexpr int NS = TIN * 2;        // chunk s = t*2 + c covers input features 32t + (r&3) + 8(r>>2) + 4h, r = 8c..8c+7
-    constexpr int PS = TIN * 2 * 64;   // units per plane
-    gf32x4* bias = (gf32x4*)(pw + (int64_t)NS * TOUT * 3 * 64 * 4) + (t0 * 2 + (lane >> 5)) * 4;
-    f32x4 b[2][3];
-    f32x16 acc2[NT];
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) b[0][pl] = hin[pl * PS + lane];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 bq = bias[t * TSTRIDE * 8 + q];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { acc[t][4 * q + e] = bq[e]; acc2[t][4 * q + e] = 0.0f; }
-        }
-    }
+    for (int pl = 0; pl < kPlanes; ++pl) b[0][pl] = bsrc[pl * bplane];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        f32x4 ac[NT][3], bc[3];
+        f32x4 ac[NT][kPlanes], bc[kPlanes];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bc[pl] = b[s & 1][pl];
+        for (int pl = 0; pl < kPlanes; ++pl) bc[pl] = b[s & 1][pl];
         w.template next<NS>(s, ac);
         if (s + 1 < NS) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) b[(s + 1) & 1][pl] = hin[pl * PS + (s + 1) * 64 + lane];
+            for (int pl = 0; pl < kPlanes; ++pl) b[(s + 1) & 1][pl] = bsrc[pl * bplane + (s + 1) * bstep];
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) mfma6(ac[t], bc, acc[t], acc2[t]);
+        for (int t = 0; t < NT; ++t) mfma3(ac[t], bc, acc[t], cross[t]);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] += acc2[t][r];
+        for (int r = 0; r < 16; ++r) acc[t][r] = __builtin_fmaf(cross[t][r], kLoUnscale, acc[t][r]);
+}
+
+// layer epilogue of one output tile: back to the unscaled domain, bias, optional ReLU.
+// consts = the layer's epilogue block (behind its fragments): tile t2, half h -> [unscale 16 | bias 16] in register order
+template <bool RELU>
+__device__ inline void epilogue_tile(f32x16& h, gfloat* __restrict__ consts, int t2, int half, float row_un)
+{
+    gf32x4* c = (gf32x4*)(consts + (t2 * 2 + half) * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 un = c[q], bi = c[4 + q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float y = __builtin_fmaf(h[4 * q + e], un[e] * row_un, bi[e]);
+            h[4 * q + e] = RELU ? fmaxf(y, 0.0f) : y;
+        }
+    }
+}
+
+__device__ inline float reg_max(const f32x16& h)
+{
+    float m = fabsf(h[0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, fabsf(h[r]));
+    return m;
+}
+
+// Publish this wave's activation tile `t` to the workgroup, scaled by the row's factor and split: plane p unit
+// (t*2 + c)*64 + lane = registers 8c..8c+7, i.e. exactly the B-operand fragment of K-chunk (t, c) of the next layer.
+__device__ inline void publish_tile(f32x4* lds, int plane_units, int t, int lane, const f32x16& h, float sc)
+{
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = h[8 * c + e] * sc;
+        f32x4 hi, lo;
+        split8(x, hi, lo);
+        const int u = (t * 2 + c) * 64 + lane;
+        lds[u] = hi;
+        lds[plane_units + u] = lo;
+    }
 }
 
 // Narrow heads (8 / 1 outputs) also run on the matrix pipe: the head's weight rows are the A operand (outputs padded
 // to 32 rows with zeros), the B operand is this wave's own activation registers (a lane's registers 8c..8c+7 are its
-// B fragment of chunk c -- no exchange needed), 12 MFMAs per 32 input features.  A VALU version (16 FMAs per output
-// and input tile, weights fetched inside the loop) took 2-4 k cycles of mostly load latency per head.
-// Result: out[r], r = 0..3 = this wave's partial sum of output 4*(lane>>5) + r for row lane&31.
+// B fragment of chunk c -- no exchange needed), 6 MFMAs per 32 input features.
+// Result: out[r], r = 0..3 = this wave's partial sum of output 4*(lane>>5) + r for row lane&31 (unscaled, no bias).
 template <int NT, int TSTRIDE>
 struct HeadW {
-    f32x4 a[NT][2][3];
-    __device__ inline void start(gfloat* __restrict__ hw, int lane, int t0)
+    f32x4 a[NT][2][kPlanes];
+    f32x4 un;  // unscale of outputs 4h..4h+3
+    __device__ inline void start(gfloat* __restrict__ hw, int tin, int lane, int t0)
     {
         gf32x4* p = (gf32x4*)hw + lane;
 #pragma unroll
@@ -336,33 +344,39 @@ struct HeadW {
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[t][c][pl] = p[(((t0 + t * TSTRIDE) * 2 + c) * 3 + pl) * 64];
+                for (int pl = 0; pl < kPlanes; ++pl) a[t][c][pl] = p[(((t0 + t * TSTRIDE) * 2 + c) * kPlanes + pl) * 64];
+        un = ((gf32x4*)(hw + head_consts_off(tin)))[lane >> 5];
     }
 };
 
 template <int NT, int TSTRIDE>
 __device__ inline void head_mfma(const HeadW<NT, TSTRIDE>& w, const f32x16 (&hin)[NT], float (&out)[4])
 {
-    f32x16 acc, acc2;
+    // the row scale over this wave's features: both k-halves of a row (lanes j and j + 32) must use the same factor
+    float m = reg_max(hin[0]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; }
+    for (int t = 1; t < NT; ++t) m = fmaxf(m, reg_max(hin[t]));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sc, un;
+    row_scale(m, sc, un);
+    f32x16 acc, cross;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; cross[r] = 0.0f; }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            bf16x8 ph, pm, pl;
+            float x[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { __bf16 x, y, z; split3(hin[t][8 * c + e], x, y, z); ph[e] = x; pm[e] = y; pl[e] = z; }
-            const f32x4 b[3] = {__builtin_bit_cast(f32x4, ph), __builtin_bit_cast(f32x4, pm), __builtin_bit_cast(f32x4, pl)};
-            mfma6(w.a[t][c], b, acc, acc2);
+            for (int e = 0; e < 8; ++e) x[e] = hin[t][8 * c + e] * sc;
+            f32x4 b[kPlanes];
+            split8(x, b[0], b[1]);
+            mfma3(w.a[t][c], b, acc, cross);
         }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) out[r] = acc[r] + acc2[r];
+    for (int r = 0; r < 4; ++r) out[r] = __builtin_fmaf(cross[r], kLoUnscale, acc[r]) * (w.un[r] * un);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// one 32-row tile, executed by 4 waves (v = 0..3) that share `lds_h` / `lds_part`
-// ---------------------------------------------------------------------------------------------------------------
 #ifndef RL_RING_D
 #define RL_RING_D 3   // K-chunks of weights in flight per wave and layer (dueling brains)
 #endif
@@ -390,126 +404,126 @@ struct TileIO {
 
 constexpr __host__ __device__ int policy_lds_units(int kind)  // f32x4 units of lds_h one tile needs
 {
-    return (3 * (kind == RL_PPO ? 8 : 4) * 2 * 64 > kXsUnits) ? 3 * (kind == RL_PPO ? 8 : 4) * 2 * 64 : kXsUnits;
+    return (kPlanes * (kind == RL_PPO ? 8 : 4) * 2 * 64 > kXsUnits) ? kPlanes * (kind == RL_PPO ? 8 : 4) * 2 * 64 : kXsUnits;
+}
+constexpr int kAuxFloats = 32 + 32 * 8;  // lds_aux: 1 / scale of the 32 observation rows, then per row 8 partial maxima
+
+// Row scale of a hidden activation tile set: every wave leaves the maximum of its 16 registers per lane in
+// aux[32 + row * 8 + (wave * 2 + half)] BEFORE the workgroup barrier that precedes publishing; afterwards every lane reads
+// the 8 partial maxima of its row.
+__device__ inline void row_max_put(float* aux, int j, int slot, float m) { aux[32 + j * 8 + slot] = m; }
+__device__ inline float row_max_get(const float* aux, int j)
+{
+    const f32x4 a = *(const f32x4*)(aux + 32 + j * 8), b = *(const f32x4*)(aux + 32 + j * 8 + 4);
+    return fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
 }
 
-// Every layer's weight ring and head fragments are requested BEFORE the wait that precedes the layer (observation
-// staging, the LDS exchange, the previous head): ~154 VGPRs for the 128-wide brains, i.e. 3 waves per SIMD.  A variant
-// that starts the rings at their layer (128 VGPRs, 4 waves per SIMD) and one with 64-row tiles were measured slower at
-// 256 AND at 4096 worlds.
-// GUARD: the tile may be inactive (a world kernel running fewer tiles than it has wave quads): every workgroup barrier
-// is still executed, everything else is skipped.  The barriers are workgroup-wide, so all tiles of a workgroup must run
-// the same KIND.
-template <int KIND, bool GUARD>
-__device__ inline void policy_tile(const TileIO& io, bool active, f32x4* __restrict__ lds_h, float (*__restrict__ lds_part)[32][9],
-                                   int lane, int v)
+// One 32-row tile by 4 waves.  Every layer's weight ring and head fragments are requested BEFORE the wait that precedes
+// the layer (observation staging, the LDS exchange, the previous head): 3 waves per SIMD for the 128-wide brains.  A
+// variant that starts the rings at their layer (4 waves per SIMD) and one with 64-row tiles were measured slower at 256
+// AND at 4096 worlds.
+template <int KIND>
+__device__ inline void policy_tile(const TileIO& io, f32x4* __restrict__ lds_h, float* __restrict__ lds_aux,
+                                   float (*__restrict__ lds_part)[32][9], int lane, int v)
 {
     constexpr int HID_TILES = KIND == RL_PPO ? 8 : 4;
     constexpr int PS = HID_TILES * 2 * 64;  // units per plane of the published activations
     const int h = lane >> 5, j = lane & 31;
     const Layout L = layout_of(KIND);
     gfloat* __restrict__ packed = io.packed;
-    const bool on = !GUARD || active;
+    const int xb = h * kXGroup + j;  // this lane's unit of chunk 0 in the observation planes
     if (KIND == RL_DQN) {
         f32x16 h1[1], h2[1];
         WRing<4, 1, 1, 3> w1;
         WRing<2, 1, 1, 3> w2;
         HeadW<1, 1> wh;
         float q4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (on) {
-            w1.start(packed + L.l1, lane, v);
-            stage_x(lds_h, io.obs, io.row, lane, v);
-        }
+        w1.start(packed + L.l1, lane, v);
+        stage_x(lds_h, lds_aux, io.obs, io.row, lane, v);
         lds_barrier();
-        if (on) {
-            layer_in(w1, lane, lds_h, h1);
-            if (v < 2) { w2.start(packed + L.l2a, lane, v); wh.start(packed + L.ha, lane, v); }
-            relu_inplace<1>(h1);
-        }
+        k_loop<kInChunks>(w1, lds_h + xb, kXPlane, 2 * kXGroup, h1);
+        if (v < 2) { w2.start(packed + L.l2a, lane, v); wh.start(packed + L.ha, 2, lane, v); }
+        epilogue_tile<true>(h1[0], packed + L.l1 + frag_floats(kInChunks, 4), v, h, lds_aux[j]);
+        row_max_put(lds_aux, j, v * 2 + h, reg_max(h1[0]));
         lds_barrier();  // every wave is done with the observation tile: its LDS becomes the activation exchange
-        if (on) publish_tile(lds_h, PS, v, lane, h1[0]);
+        float sc1, un1;
+        row_scale(row_max_get(lds_aux, j), sc1, un1);
+        publish_tile(lds_h, PS, v, lane, h1[0], sc1);
         lds_barrier();
-        if (on) {
-            if (v < 2) {  // the second hidden layer has 2 output tiles: waves 0 and 1
-                layer_hidden<4>(w2, packed + L.l2a, lane, v, lds_h, h2);
-                relu_inplace<1>(h2);
-                head_mfma(wh, h2, q4);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) lds_part[v][j][4 * h + r] = q4[r];
+        if (v < 2) {  // the second hidden layer has 2 output tiles: waves 0 and 1
+            k_loop<8>(w2, lds_h + lane, PS, 64, h2);
+            epilogue_tile<true>(h2[0], packed + L.l2a + frag_floats(8, 2), v, h, un1);
+            head_mfma(wh, h2, q4);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds_part[v][j][4 * h + r] = q4[r];
     } else if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
         f32x16 h1[1], h2[1];
         float adv[4], val[4];
         WRing<4, 1, 1, RL_RING_D> w1, w2;
         HeadW<1, 1> wh;
-        if (on) {
-            w1.start(packed + L.l1, lane, v);
-            stage_x(lds_h, io.obs, io.row, lane, v);
-        }
+        w1.start(packed + L.l1, lane, v);
+        stage_x(lds_h, lds_aux, io.obs, io.row, lane, v);
         lds_barrier();
         RL_PMARK(10);
-        if (on) {
-            layer_in(w1, lane, lds_h, h1);
-            RL_PMARK(2);
-            w2.start(packed + L.l2a, lane, v);
-            wh.start(packed + L.ha, lane, v);
-            relu_inplace<1>(h1);  // relu(feature) feeds both branches (PERD3QN.py:200-201)
-        }
+        k_loop<kInChunks>(w1, lds_h + xb, kXPlane, 2 * kXGroup, h1);
+        RL_PMARK(2);
+        w2.start(packed + L.l2a, lane, v);
+        wh.start(packed + L.ha, 4, lane, v);
+        // relu(feature) feeds both branches (PERD3QN.py:200-201)
+        epilogue_tile<true>(h1[0], packed + L.l1 + frag_floats(kInChunks, 4), v, h, lds_aux[j]);
+        row_max_put(lds_aux, j, v * 2 + h, reg_max(h1[0]));
         lds_barrier();
-        if (on) publish_tile(lds_h, PS, v, lane, h1[0]);
+        float sc1, un1;
+        row_scale(row_max_get(lds_aux, j), sc1, un1);
+        publish_tile(lds_h, PS, v, lane, h1[0], sc1);
         lds_barrier();
         RL_PMARK(3);
-        if (on) {
-            layer_hidden<4>(w2, packed + L.l2a, lane, v, lds_h, h2);
-            RL_PMARK(4);
-            w1.start(packed + L.l2b, lane, v);  // the value branch's first chunks arrive while the advantage head runs
-            relu_inplace<1>(h2);
-            head_mfma(wh, h2, adv);
-            wh.start(packed + L.hb, lane, v);
-            RL_PMARK(5);
-            layer_hidden<4>(w1, packed + L.l2b, lane, v, lds_h, h2);
-            RL_PMARK(6);
-            relu_inplace<1>(h2);
-            head_mfma(wh, h2, val);
-            RL_PMARK(7);
+        k_loop<8>(w2, lds_h + lane, PS, 64, h2);
+        RL_PMARK(4);
+        w1.start(packed + L.l2b, lane, v);  // the value branch's first chunks arrive while the advantage head runs
+        epilogue_tile<true>(h2[0], packed + L.l2a + frag_floats(8, 4), v, h, un1);
+        head_mfma(wh, h2, adv);
+        wh.start(packed + L.hb, 4, lane, v);
+        RL_PMARK(5);
+        k_loop<8>(w1, lds_h + lane, PS, 64, h2);
+        RL_PMARK(6);
+        epilogue_tile<true>(h2[0], packed + L.l2b + frag_floats(8, 4), v, h, un1);
+        head_mfma(wh, h2, val);
+        RL_PMARK(7);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lds_part[v][j][4 * h + r] = adv[r];
-            if (h == 0) lds_part[v][j][8] = val[0];
-        }
+        for (int r = 0; r < 4; ++r) lds_part[v][j][4 * h + r] = adv[r];
+        if (h == 0) lds_part[v][j][8] = val[0];
     } else {
         f32x16 h1[2], h2[2];
         float q4[4];
         WRing<8, 2, 4, 3> w1, w2;
         HeadW<2, 4> wh;
-        if (on) {
-            w1.start(packed + L.l1, lane, v);   // tiles v and v+4
-            stage_x(lds_h, io.obs, io.row, lane, v);
-        }
+        w1.start(packed + L.l1, lane, v);   // tiles v and v+4
+        stage_x(lds_h, lds_aux, io.obs, io.row, lane, v);
         lds_barrier();
-        if (on) {
-            layer_in(w1, lane, lds_h, h1);
-            w2.start(packed + L.l2a, lane, v);
-            relu_inplace<2>(h1);
-        }
+        k_loop<kInChunks>(w1, lds_h + xb, kXPlane, 2 * kXGroup, h1);
+        w2.start(packed + L.l2a, lane, v);
+        epilogue_tile<true>(h1[0], packed + L.l1 + frag_floats(kInChunks, 8), v, h, lds_aux[j]);
+        epilogue_tile<true>(h1[1], packed + L.l1 + frag_floats(kInChunks, 8), v + 4, h, lds_aux[j]);
+        row_max_put(lds_aux, j, v * 2 + h, fmaxf(reg_max(h1[0]), reg_max(h1[1])));
         lds_barrier();
-        if (on) {
-            publish_tile(lds_h, PS, v, lane, h1[0]);
-            publish_tile(lds_h, PS, v + 4, lane, h1[1]);
-        }
+        float sc1, un1;
+        row_scale(row_max_get(lds_aux, j), sc1, un1);
+        publish_tile(lds_h, PS, v, lane, h1[0], sc1);
+        publish_tile(lds_h, PS, v + 4, lane, h1[1], sc1);
         lds_barrier();
-        if (on) {
-            wh.start(packed + L.ha, lane, v);
-            layer_hidden<8>(w2, packed + L.l2a, lane, v, lds_h, h2);
-            relu_inplace<2>(h2);
-            head_mfma(wh, h2, q4);
+        wh.start(packed + L.ha, 8, lane, v);
+        k_loop<16>(w2, lds_h + lane, PS, 64, h2);
+        epilogue_tile<true>(h2[0], packed + L.l2a + frag_floats(16, 8), v, h, un1);
+        epilogue_tile<true>(h2[1], packed + L.l2a + frag_floats(16, 8), v + 4, h, un1);
+        head_mfma(wh, h2, q4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lds_part[v][j][4 * h + r] = q4[r];
-        }
+        for (int r = 0; r < 4; ++r) lds_part[v][j][4 * h + r] = q4[r];
     }
     lds_barrier();
     RL_PMARK(8);
-    if (on && v == 0 && h == 0) {
+    if (v == 0 && h == 0) {
         float q[8];
         float sum9[9];
 #pragma unroll
@@ -517,8 +531,8 @@ __device__ inline void policy_tile(const TileIO& io, bool active, f32x4* __restr
             sum9[i] = (i < 8 || KIND == RL_D3QN || KIND == RL_PERD3QN)
                           ? ((lds_part[0][j][i] + lds_part[1][j][i]) + lds_part[2][j][i]) + lds_part[3][j][i] : 0.0f;
         if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
-            gfloat* ba = packed + L.ha + head_bias_off(4);
-            const float bv = packed[L.hb + head_bias_off(4)];
+            gfloat* ba = packed + L.ha + head_consts_off(4) + 8;
+            const float bv = packed[L.hb + head_consts_off(4) + 8];
             float adv[8], mean = 0.0f;  // advantage.mean() of the [1,8] tensor == per-row mean when batched
 #pragma unroll
             for (int i = 0; i < 8; ++i) { adv[i] = sum9[i] + ba[i]; mean += adv[i]; }
@@ -527,7 +541,7 @@ __device__ inline void policy_tile(const TileIO& io, bool active, f32x4* __restr
 #pragma unroll
             for (int i = 0; i < 8; ++i) q[i] = adv[i] + val - mean;
         } else {
-            gfloat* bq = packed + L.ha + head_bias_off(KIND == RL_DQN ? 2 : 8);
+            gfloat* bq = packed + L.ha + head_consts_off(KIND == RL_DQN ? 2 : 8) + 8;
 #pragma unroll
             for (int i = 0; i < 8; ++i) q[i] = sum9[i] + bq[i];
             if (KIND == RL_PPO) {

@@ -54,53 +54,103 @@ def test_philox_matches_oracle_and_known_answers():
         assert list(out) == orc.philox(a[0] * 7919 + 3, a[1] % 5, a[2], a[3], a[4] % 10, a[5])
 
 
-def _bf16_planes_sum(u16, shape):
-    """[..., 3 planes, 64 lanes, 8] bf16 -> the f32 values the three planes add up to."""
-    parts = (u16.astype(np.uint32) << 16).view(np.float32).reshape(shape).astype(np.float64)
-    return parts.sum(axis=-3)
+def _f16_planes_value(u16, shape):
+    """[..., 2 planes, 64 lanes, 8] f16 (hi, lo') -> hi + lo' / 2048, the scaled weights the two planes stand for."""
+    parts = u16.view(np.float16).reshape(shape).astype(np.float64)
+    return parts[..., 0, :, :] + parts[..., 1, :, :] / 2048.0
+
+
+def _feature_of(t2, lane_half, r):
+    return 32 * t2 + (r & 3) + 8 * (r >> 2) + 4 * lane_half
 
 
 @pytest.mark.parametrize("name", ["DQN", "D3QN", "PERD3QN", "PPO"])
-def test_weight_packing_keeps_every_weight_exactly(name):
-    """rl_policy_pack_weights: MFMA layers are stored as three bf16 planes (hi + mid + lo == the f32 weight, exactly),
-    permuted into fragment order with the input layer's bias folded in as column 153; the other biases stay f32.  Every parameter must be recoverable, none duplicated."""
+def test_weight_packing_keeps_every_weight_to_22_bits(name):
+    """rl_policy_pack_weights: MFMA layers are stored as two f16 planes of the weight scaled by a power of two per output
+    feature (hi + lo'/2048 == scale * w to 22 bits of the row maximum), permuted into fragment order; the per-feature
+    unscale factors and the biases follow in accumulator order as f32.  Every parameter must be recoverable, none
+    duplicated, and unscale * scaled weight must give the weight back."""
     from oracle import oracle as orc
     lib = _lib.lib()
     kind = _lib.KIND_BY_METHOD[name]
     n = lib.rl_policy_n_params(kind)
     assert n == orc.lib().rlo_policy_n_params(kind)
-    # a 24-bit-mantissa pattern per parameter, all distinct and nonzero
-    flat = ((np.arange(n, dtype=np.float64) + 1.0) * (1.0 + 2.0 ** -23) * 2.0 ** -10).astype(np.float32)
-    assert len(np.unique(flat)) == n
+    rng = np.random.RandomState(3)
+    flat = (rng.uniform(0.25, 1.0, size=n) * rng.choice([-1.0, 1.0], size=n) * 2.0 ** rng.randint(-6, 3, size=n)).astype(np.float32)
     packed = np.zeros(lib.rl_policy_packed_floats(kind), np.float32)
     assert lib.rl_policy_pack_weights(kind, flat.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)) == 0
     u16 = packed.view(np.uint16)
-    # (hidden width, [(tin, tout, head outputs)...]) per kind, in packed order
-    h1, branches = {"DQN": (128, [(4, 2, 8)]), "D3QN": (128, [(4, 4, 8), (4, 4, 1)]), "PERD3QN": (128, [(4, 4, 8), (4, 4, 1)]),
-                    "PPO": (256, [(8, 8, 8)])}[name]
-    got = []
-    off = 0  # in 4-byte units
-    t1 = h1 // 32
-    cnt = 10 * t1 * 3 * 64 * 4
-    got.append(_bf16_planes_sum(u16[off * 2:(off + cnt) * 2], (10, t1, 3, 64, 8)).reshape(-1))
-    off += cnt
+    # (input layer tiles, [(tin, tout, head outputs)...]) per kind, in packed order; parameters in state-dict order
+    t1, branches = {"DQN": (4, [(4, 2, 8)]), "D3QN": (4, [(4, 4, 8), (4, 4, 1)]), "PERD3QN": (4, [(4, 4, 8), (4, 4, 1)]),
+                    "PPO": (8, [(8, 8, 8)])}[name]
+    off = [0]  # in 4-byte units
+    par = [0]
+
+    def take_params(count):
+        v = flat[par[0]:par[0] + count]
+        par[0] += count
+        return v
+
+    def check_mfma_layer(chunks, tout, n_in, k_of):
+        """fragments [chunks][tout][2][64][8] + consts [tout][2][unscale 16 | bias 16]; k_of(chunk, lane_half, e) -> input index"""
+        W = take_params(tout * 32 * n_in).reshape(tout * 32, n_in).astype(np.float64)
+        b = take_params(tout * 32).astype(np.float64)
+        cnt = chunks * tout * 2 * 64 * 4
+        val = _f16_planes_value(u16[off[0] * 2:(off[0] + cnt) * 2], (chunks, tout, 2, 64, 8))
+        off[0] += cnt
+        consts = packed[off[0]:off[0] + tout * 64].reshape(tout, 2, 2, 16).astype(np.float64)  # [t2][half][unscale|bias][r]
+        off[0] += tout * 64
+        un = np.zeros(tout * 32); bias = np.zeros(tout * 32)
+        for t2 in range(tout):
+            for hh in range(2):
+                for r in range(16):
+                    un[_feature_of(t2, hh, r)] = consts[t2, hh, 0, r]
+                    bias[_feature_of(t2, hh, r)] = consts[t2, hh, 1, r]
+        assert np.array_equal(bias, b)
+        assert np.all(np.log2(un) == np.round(np.log2(un)))  # powers of two
+        seen = np.zeros_like(W, dtype=bool)
+        for c in range(chunks):
+            for t2 in range(tout):
+                for lane in range(64):
+                    o = 32 * t2 + (lane & 31)
+                    for e in range(8):
+                        k = k_of(c, lane >> 5, e)
+                        if k is None or k >= n_in:
+                            assert val[c, t2, lane, e] == 0
+                            continue
+                        assert not seen[o, k]
+                        seen[o, k] = True
+                        rowmax = np.abs(W[o]).max()
+                        assert abs(val[c, t2, lane, e] * un[o] - W[o, k]) <= rowmax * 2.0 ** -21
+        assert seen.all()
+
+    check_mfma_layer(10, t1, 153, lambda c, hh, e: 16 * c + 8 * hh + e)
     for tin, tout, nout in branches:
-        cnt = 2 * tin * tout * 3 * 64 * 4
-        got.append(_bf16_planes_sum(u16[off * 2:(off + cnt) * 2], (2 * tin, tout, 3, 64, 8)).reshape(-1))
-        off += cnt
-        got.append(packed[off:off + 32 * tout].astype(np.float64))       # hidden bias, accumulator order
-        off += 32 * tout
-        cnt = tout * 2 * 3 * 64 * 4
-        got.append(_bf16_planes_sum(u16[off * 2:(off + cnt) * 2], (tout * 2, 3, 64, 8)).reshape(-1))  # head fragments
-        off += cnt
-        got.append(packed[off:off + nout].astype(np.float64))             # head bias
-        off += nout
-    assert off == len(packed)
-    vals = np.concatenate(got)
-    nz = np.sort(vals[vals != 0])
-    used = n - (257 if name == "PPO" else 0)          # PPO's value head is not evaluated when acting (PPO.py:164-169)
-    want = np.sort(flat[:used].astype(np.float64))   # state-dict order: PPO's unused fc_v comes last
-    assert len(nz) == used and np.array_equal(nz, want)
+        def k_hidden(c, hh, e):
+            t, cc = divmod(c, 2)
+            r = 8 * cc + e
+            return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hh
+        check_mfma_layer(2 * tin, tout, tin * 32, k_hidden)
+        # head: fragments [tin*2][1][2][64][8] (rows >= nout zero), then unscale[8], bias[8]
+        W = take_params(nout * tout * 32).reshape(nout, tout * 32).astype(np.float64)
+        b = take_params(nout).astype(np.float64)
+        cnt = tout * 2 * 2 * 64 * 4
+        val = _f16_planes_value(u16[off[0] * 2:(off[0] + cnt) * 2], (tout * 2, 2, 64, 8))
+        off[0] += cnt
+        un, bias = packed[off[0]:off[0] + 8].astype(np.float64), packed[off[0] + 8:off[0] + 16].astype(np.float64)
+        off[0] += 16
+        assert np.array_equal(bias[:nout], b) and np.all(bias[nout:] == 0)
+        for c in range(tout * 2):
+            for lane in range(64):
+                o = lane & 31
+                for e in range(8):
+                    k = k_hidden(c, lane >> 5, e)
+                    if o >= nout:
+                        assert val[c, lane, e] == 0
+                    else:
+                        assert abs(val[c, lane, e] * un[o] - W[o, k]) <= np.abs(W[o]).max() * 2.0 ** -21
+    assert off[0] == len(packed)
+    assert par[0] == n - (257 if name == "PPO" else 0)   # PPO's value head (fc_v, last in the state dict) is not evaluated when acting
     assert lib.rl_policy_pack_weights(9, flat.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)) < 0
 
 
