@@ -41,10 +41,10 @@ TICK_BYTES_PER_AGENT_STEP = 612 + 612 + 36 + 36 + 1 + 4 + 1 + 4 + 18
 POLICY_BYTES_PER_AGENT = 612 + 1 + 4
 POLICY_FLOP_PER_AGENT = {"DQN": 56576, "D3QN": 107008, "PERD3QN": 107008, "PPO": 213504}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
-MFMA_BF16_PEAK_TFLOPS = 2516.6   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (16 x the 157.3 TF f32 matrix rate)
-# The policy kernel gets f32-grade results from the bf16 pipe: every f32 product is six bf16 partial products
-# (3 x bf16 split), so the ceiling for ALGORITHMIC (f32-equivalent) FLOP/s is the bf16 dense peak / 6.
-MFMA_SPLIT_PRODUCTS = 6
+MFMA_BF16_PEAK_TFLOPS = 2516.6   # MI355X_MICROARCH.md: ~2.5 PF dense f16 / bf16 (16 x the 157.3 TF f32 matrix rate)
+# The policy kernel gets f32-grade results from the f16 pipe: every f32 product is three f16 partial products
+# (2 x f16 block-scaled split), so the ceiling for ALGORITHMIC (f32-equivalent) FLOP/s is the f16 dense peak / 3.
+MFMA_SPLIT_PRODUCTS = 3
 MFMA_F32_EQUIV_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / MFMA_SPLIT_PRODUCTS
 
 
@@ -279,8 +279,8 @@ def main():
         pol_roof = {"kernel": "k_policy (rl_policy_act: one launch per brain kind)", "bound": "mfma", "achieved": round(pol_tflops, 3),
                     "peak": round(MFMA_F32_EQUIV_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
                     "frac": round(pol_tflops / MFMA_F32_EQUIV_PEAK_TFLOPS, 5),
-                    "peak_note": "algorithmic f32-equivalent FLOP/s; peak = bf16 dense %.1f TF / %d partial products of the "
-                                 "3xbf16 split (the f32-input MFMA peak would be 157.3)" % (MFMA_BF16_PEAK_TFLOPS, MFMA_SPLIT_PRODUCTS),
+                    "peak_note": "algorithmic f32-equivalent FLOP/s; peak = f16 dense %.1f TF / %d partial products of the "
+                                 "block-scaled 2 x f16 split (the f32-input MFMA peak would be 157.3)" % (MFMA_BF16_PEAK_TFLOPS, MFMA_SPLIT_PRODUCTS),
                     "traffic": pol_traffic, "avg_launch_us": round(t_act * 1e6, 2), "flop_per_agent": flop,
                     "agent_steps_per_launch": round(per_launch, 1)}
         roofline = tick_roof if t_tick >= t_act else pol_roof
@@ -303,7 +303,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32-grade policy via 3xbf16 split on v_mfma_f32_32x32x16_bf16 (f32 accumulate) / int32+u8 world state / f64 rewards",
+            "dtype": "f32-grade policy via block-scaled 2 x f16 split on v_mfma_f32_32x32x16_f16 (f32 accumulate) / int32+u8 world state / f64 rewards",
             "data": "synthetic",
             "config": {"workload": wl["name"], "worlds_per_gpu": args.worlds, "worlds_total": args.worlds * max(1, world_size),
                        "stream_groups": args.groups, "grid": "30x30", "max_agents": 100, "brains": wl["brains"], "static_families": wl["static_families"],

@@ -1,6 +1,6 @@
 """The four brains of the hot path with the reference's constructor keywords, attribute names and state-dict keys
 (ReinLife/Models/DQN.py:18-63, D3QN.py:16-80, PERD3QN.py:10-79, PPO.py:10-52), so `load_model=` accepts the
-reference's `pretrained/*.pt` files.  The forward pass and action selection run in libreinlife_hip.so (f32-grade split-precision MFMA):
+reference's `pretrained/*.pt` files.  The forward pass and action selection run in libreinlife_hip.so (f32-grade block-scaled f16 MFMA):
 batched over all agents through Environment.act(), or one state at a time through get_action().
 
 Training (replay buffers, optimizers, learn()) is outside this build's scope (BASELINE.json north_star): learn() is

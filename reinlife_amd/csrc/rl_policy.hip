@@ -65,7 +65,7 @@ struct PolicyArgs {
 // One launch serves every brain of one kind: the tile space is the concatenation of the brains' 32-row tiles; one
 // 4-wave workgroup per tile (policy_tile, rl_policy_dev.h).
 template <int KIND>
-__global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 3)) void k_policy(const PolicyArgs A)
+__global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const PolicyArgs A)
 {
     __shared__ __attribute__((aligned(16))) f32x4 lds_h[policy_lds_units(KIND)];
     __shared__ __attribute__((aligned(16))) float lds_aux[kAuxFloats];  // row scales
@@ -173,7 +173,7 @@ int64_t rl_policy_packed_floats_impl(int kind)
     return layout_of(kind).total;
 }
 
-// ---- f16 split of a scaled weight (host mirror of split_pair): hi = x toward zero, lo' = (x - hi) * 2^11 toward zero ----
+// ---- f16 split of a scaled weight (host mirror of split_pair): hi = x toward zero, lo = x - hi toward zero ----
 static inline uint16_t f16_rtz(float f)  // |f| < 65504 (scaled weights are < 2^12), result exact toward zero
 {
     uint32_t u;
@@ -197,7 +197,7 @@ static inline float f16_to_float(uint16_t h)
 static inline void split2_host(float x, uint16_t (&out)[2])
 {
     out[0] = f16_rtz(x);
-    out[1] = f16_rtz((x - f16_to_float(out[0])) * kLoScale);
+    out[1] = f16_rtz(x - f16_to_float(out[0]));
 }
 // scale of output feature o of a row-major [n_out][n_in] matrix: 2^(kScaleExp - exponent(max |W[o][:]|))
 static void feature_scales(const float* W, int n_out, int n_in, std::vector<float>& sc, std::vector<float>& un)

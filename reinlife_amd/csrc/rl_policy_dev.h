@@ -14,10 +14,10 @@
 //   * f32-grade results from the f16 matrix pipe ("2 x f16, block-scaled"): every f32 operand row is scaled by a power
 //     of two so that its largest element lands in [2^10, 2^11) -- per observation / activation ROW (the B operand's
 //     columns) and per output FEATURE of the weights (the A operand's rows), so the scale factors leave the MFMA as one
-//     multiply per accumulator register -- and split into two f16 parts x = hi + lo' / 2048 (hi = x rounded toward zero to
-//     11 bits, lo' = the exact remainder times 2^11, again 11 bits: 22 bits of every operand, measured against the row
-//     maximum).  A product is hi.hi + (hi.lo' + lo'.hi) / 2048, three v_mfma_f32_32x32x16_f16 per 16 k with f32
-//     accumulation (the cross terms in their own accumulator); the dropped lo.lo term is 2^-22 relative.  Measured
+//     multiply per accumulator register -- and split into two f16 parts x = hi + lo (hi = x rounded toward zero to 11
+//     bits, lo = the exact remainder, again up to 11 bits: 22 bits of every operand, measured against the row
+//     maximum).  A product is hi.hi + hi.lo + lo.hi, three v_mfma_f32_32x32x16_f16 per 16 k with f32 accumulation (the
+//     cross terms in their own accumulator); the dropped lo.lo term is 2^-22 relative.  Measured
 //     difference to the reference's torch outputs on the golden vectors: ~1e-7 (the bar is 1e-5) -- the same as an f32
 //     numpy forward.  The power-of-two scaling makes the scheme independent of the operands' magnitude (f16 alone
 //     would overflow at 65504 and lose small values).  History: f32-input MFMA (8 x 64 cycles per 16 k) -> three bf16
@@ -46,9 +46,7 @@ typedef const float __attribute__((address_space(1))) gfloat;
 typedef const f32x4 __attribute__((address_space(1))) gf32x4;
 
 constexpr int kInChunks = 10;        // input layer: K = 153 padded to 160 = 10 chunks of 16 (lanes 0-31: k 16c..16c+7, lanes 32-63: +8)
-constexpr int kPlanes = 2;           // hi, lo' (= lo * 2^11)
-constexpr float kLoScale = 2048.0f;  // 2^11
-constexpr float kLoUnscale = 1.0f / 2048.0f;
+constexpr int kPlanes = 2;           // hi, lo
 constexpr int kScaleExp = 10;        // a scaled row's maximum lies in [2^10, 2^11)
 
 // packed sizes in 4-byte units: a fragment is 8 f16 = 16 bytes per lane, two planes per fragment; every output tile of
@@ -114,20 +112,22 @@ __device__ inline f32x16 mfma16(const f32x4& a, const f32x4& b, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// the three partial products of one K-chunk (a / b: planes hi, lo'): hi.hi into `main`, the cross terms into `cross`
+// the three partial products of one K-chunk (a / b: planes hi, lo): hi.hi into `main`, the cross terms into `cross`
 __device__ inline void mfma3(const f32x4 (&a)[kPlanes], const f32x4 (&b)[kPlanes], f32x16& main, f32x16& cross)
 {
-    cross = mfma16(a[0], b[1], cross);  // hi.lo'
+    cross = mfma16(a[0], b[1], cross);  // hi.lo
     main = mfma16(a[0], b[0], main);    // hi.hi
-    cross = mfma16(a[1], b[0], cross);  // lo'.hi
+    cross = mfma16(a[1], b[0], cross);  // lo.hi
 }
 
-// two already-scaled values -> packed f16 pairs: hi = x toward zero, lo' = (x - hi) * 2^11 (the subtraction is exact)
+// two already-scaled values -> packed f16 pairs: hi = x toward zero (11 bits), lo = x - hi (exact in f32) toward zero.
+// lo of an element m times smaller than the row maximum is an f16 subnormal from m > 2^14 on: what is lost there is
+// below 2^-24 of the row maximum, i.e. below f32's own resolution of the dot product
 __device__ inline void split_pair(float x0, float x1, unsigned& hi, unsigned& lo)
 {
     const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
     hi = __builtin_bit_cast(unsigned, h);
-    const auto l = __builtin_amdgcn_cvt_pkrtz((x0 - (float)h[0]) * kLoScale, (x1 - (float)h[1]) * kLoScale);
+    const auto l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
     lo = __builtin_bit_cast(unsigned, l);
 }
 __device__ inline void split8(const float (&x)[8], f32x4& hi, f32x4& lo)
@@ -152,7 +152,7 @@ __device__ inline float wave_max_nonneg(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 63));
 }
 
-// Observation tile in LDS, scaled, split and already in B-operand order: plane p (hi, lo') holds, for K-chunk c and lane
+// Observation tile in LDS, scaled, split and already in B-operand order: plane p (hi, lo) holds, for K-chunk c and lane
 // (row j = lane&31, half kh = lane>>5), the 8 f16 of x[j][16c + 8kh + 0..7] (zero beyond k = 152) as one 16-byte unit
 // at p*kXPlane + (2c + kh)*33 + j.  Groups are 33 (not 32) units apart so that the staging writes of one row (40 lanes,
 // one 8-byte half unit each) spread over the banks.
@@ -254,7 +254,7 @@ struct WRing {
 };
 
 // K loop of one layer: B fragments from LDS planes `bsrc` (unit stride `bstep` per chunk, plane stride `bplane`), A
-// fragments from the ring.  Leaves acc[t] = sum hi.hi + (hi.lo' + lo'.hi) / 2^11, still in the scaled domain.
+// fragments from the ring.  Leaves acc[t] = sum hi.hi + hi.lo + lo.hi, still in the scaled domain.
 template <int NS, int TOUT, int NT, int TSTRIDE, int D>
 __device__ inline void k_loop(WRing<TOUT, NT, TSTRIDE, D>& w, const f32x4* __restrict__ bsrc, int bplane, int bstep, f32x16 (&acc)[NT])
 {
@@ -283,7 +283,7 @@ __device__ inline void k_loop(WRing<TOUT, NT, TSTRIDE, D>& w, const f32x4* __res
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = __builtin_fmaf(cross[t][r], kLoUnscale, acc[t][r]);
+        for (int r = 0; r < 16; ++r) acc[t][r] += cross[t][r];
 }
 
 // layer epilogue of one output tile: back to the unscaled domain, bias, optional ReLU.
@@ -374,7 +374,7 @@ __device__ inline void head_mfma(const HeadW<NT, TSTRIDE>& w, const f32x16 (&hin
             mfma3(w.a[t][c], b, acc, cross);
         }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) out[r] = __builtin_fmaf(cross[r], kLoUnscale, acc[r]) * (w.un[r] * un);
+    for (int r = 0; r < 4; ++r) out[r] = (acc[r] + cross[r]) * (w.un[r] * un);
 }
 
 #ifndef RL_RING_D

@@ -55,9 +55,9 @@ def test_philox_matches_oracle_and_known_answers():
 
 
 def _f16_planes_value(u16, shape):
-    """[..., 2 planes, 64 lanes, 8] f16 (hi, lo') -> hi + lo' / 2048, the scaled weights the two planes stand for."""
+    """[..., 2 planes, 64 lanes, 8] f16 (hi, lo) -> hi + lo, the scaled weights the two planes stand for."""
     parts = u16.view(np.float16).reshape(shape).astype(np.float64)
-    return parts[..., 0, :, :] + parts[..., 1, :, :] / 2048.0
+    return parts[..., 0, :, :] + parts[..., 1, :, :]
 
 
 def _feature_of(t2, lane_half, r):
@@ -67,7 +67,7 @@ def _feature_of(t2, lane_half, r):
 @pytest.mark.parametrize("name", ["DQN", "D3QN", "PERD3QN", "PPO"])
 def test_weight_packing_keeps_every_weight_to_22_bits(name):
     """rl_policy_pack_weights: MFMA layers are stored as two f16 planes of the weight scaled by a power of two per output
-    feature (hi + lo'/2048 == scale * w to 22 bits of the row maximum), permuted into fragment order; the per-feature
+    feature (hi + lo == scale * w to 22 bits of the row maximum), permuted into fragment order; the per-feature
     unscale factors and the biases follow in accumulator order as f32.  Every parameter must be recoverable, none
     duplicated, and unscale * scaled weight must give the weight back."""
     from oracle import oracle as orc

@@ -135,8 +135,8 @@ def test_hip_small_and_rect_grids_match_oracle():
 
 
 def test_hip_policy_forward_matches_reference_and_oracle():
-    """3xbf16 split-precision MFMA MLPs (f32-grade) vs the reference's torch networks (golden) and the C oracle: 1e-5
-    (north_star tolerance; the measured difference is ~1e-7)."""
+    """Block-scaled 2 x f16 split-precision MFMA MLPs (f32-grade) vs the reference's torch networks (golden) and the C
+    oracle: 1e-5 (north_star tolerance; the measured difference is ~2e-7)."""
     import torch
     from oracle import oracle as orc
     from reinlife_amd import _lib
@@ -154,9 +154,9 @@ def test_hip_policy_forward_matches_reference_and_oracle():
 
 
 def test_hip_policy_split_precision_holds_over_the_f32_range():
-    """The bf16 split keeps f32's exponent range and 24-bit mantissa: weights / observations scaled up or down by
-    large factors (activations up to ~1e6, down to ~1e-12) still match the f32 oracle to 1e-5 RELATIVE to the output
-    scale, for the Q-value brains (PPO's softmax output is scale-free; it is checked unscaled above)."""
+    """The power-of-two row scaling makes the f16 split independent of magnitudes: weights / observations scaled up or
+    down by large factors (activations up to ~1e6, down to ~1e-12) still match the f32 oracle to 1e-5 RELATIVE to the
+    output scale, for the Q-value brains (PPO's softmax output is scale-free; it is checked unscaled above)."""
     import torch
     from oracle import oracle as orc
     from reinlife_amd import _lib
