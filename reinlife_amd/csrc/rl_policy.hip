@@ -64,8 +64,8 @@ struct PolicyArgs {
 
 // One launch serves every brain of one kind: the tile space is the concatenation of the brains' 32-row tiles; one
 // 4-wave workgroup per tile (policy_tile, rl_policy_dev.h).
-template <int KIND>
-__global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const PolicyArgs A)
+template <int KIND, bool DEEP>
+__global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : (DEEP ? 3 : 4))) void k_policy(const PolicyArgs A)
 {
     __shared__ __attribute__((aligned(16))) f32x4 lds_h[policy_lds_units(KIND)];
     __shared__ __attribute__((aligned(16))) float lds_aux[kAuxFloats];  // row scales
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : 4)) void k_policy(const 
 #ifdef RL_ABL_TILE  // tuning experiment: front end only
         if (io.actions && io.valid && v == 0 && lane < 32) io.actions[io.row] = (int8_t)(io.key_tick & 7);
 #else
-        policy_tile<KIND>(io, lds_h, lds_aux, lds_part, lane, v);
+        policy_tile<KIND, DEEP>(io, lds_h, lds_aux, lds_part, lane, v);
 #endif
     }
 }
@@ -310,16 +310,21 @@ static int policy_grid(int64_t max_rows)  // tiles one brain can have: one 4-wav
     return (int)(blocks < 1 ? 1 : blocks);
 }
 
-static int launch_policy(int kind, const PolicyArgs& a, int64_t max_rows, hipStream_t st)
+// expected_rows: how many rows the launch will really process (max_rows only bounds the grid): picks the variant
+static int launch_policy(int kind, const PolicyArgs& a, int64_t max_rows, int64_t expected_rows, hipStream_t st)
 {
     const dim3 grid(policy_grid(max_rows), a.nb), block(256);
+    const bool deep = expected_rows / 32 <= 6 * 256;  // fewer than ~6 tiles per CU: latency-bound, deeper weight rings
+#define RL_LAUNCH(K) do { if (deep) hipLaunchKernelGGL((k_policy<K, true>), grid, block, 0, st, a); \
+                          else hipLaunchKernelGGL((k_policy<K, false>), grid, block, 0, st, a); } while (0)
     switch (kind) {
-        case RL_DQN: hipLaunchKernelGGL((k_policy<RL_DQN>), grid, block, 0, st, a); break;
-        case RL_D3QN: hipLaunchKernelGGL((k_policy<RL_D3QN>), grid, block, 0, st, a); break;
-        case RL_PERD3QN: hipLaunchKernelGGL((k_policy<RL_PERD3QN>), grid, block, 0, st, a); break;
-        case RL_PPO: hipLaunchKernelGGL((k_policy<RL_PPO>), grid, block, 0, st, a); break;
+        case RL_DQN: RL_LAUNCH(RL_DQN); break;
+        case RL_D3QN: RL_LAUNCH(RL_D3QN); break;
+        case RL_PERD3QN: RL_LAUNCH(RL_PERD3QN); break;
+        case RL_PPO: hipLaunchKernelGGL((k_policy<RL_PPO, false>), grid, block, 0, st, a); break;
         default: rl_set_error("unknown brain kind %d", kind); return RL_E_INVALID;
     }
+#undef RL_LAUNCH
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rl_set_error("policy kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
     return RL_OK;
@@ -329,7 +334,7 @@ int rl_policy_forward_impl(int kind, const float* packed, const float* obs, int6
 {
     PolicyArgs a{};
     a.nb = 1; a.b[0].packed = packed; a.obs = obs; a.n_rows = n_rows; a.out = out; a.cap = 1;
-    return launch_policy(kind, a, n_rows, st);
+    return launch_policy(kind, a, n_rows, n_rows, st);
 }
 
 // work layout: int counts[2][64] (parity double buffer, zero-initialised once by the caller), then
@@ -361,6 +366,7 @@ int rl_policy_act_impl(rl_world* h, const rl_brain* brains, int n_brains, const 
     }
     // every live agent: populations are bounded by 2*max_agents+1 (environment.py:501 snapshot rule)
     const int64_t bound = (int64_t)R * (int64_t)(2 * h->cfg.max_agents + 2 < cap ? 2 * h->cfg.max_agents + 2 : cap);
+    const int64_t expected = (int64_t)R * h->cfg.max_agents;  // populations hover around max_agents
     for (int kind = RL_DQN; kind <= RL_PPO; ++kind) {
         PolicyArgs a{};
         a.obs = obs; a.out = out_q; a.actions = actions; a.seed = h->cfg.seed; a.cap = cap; a.world_base = h->cfg.world_base;
@@ -373,11 +379,11 @@ int rl_policy_act_impl(rl_world* h, const rl_brain* brains, int n_brains, const 
             BrainSlot& s = a.b[a.nb++];
             s.packed = brains[b].packed; s.rowlist = lists + b * stride; s.count_ptr = counts + b; s.eps = brains[b].epsilon;
             if (a.nb == kMaxBrainsPerLaunch) {
-                if (int rc = launch_policy(kind, a, bound, st)) return rc;
+                if (int rc = launch_policy(kind, a, bound, expected, st)) return rc;
                 a.nb = 0;
             }
         }
-        if (a.nb) if (int rc = launch_policy(kind, a, bound, st)) return rc;
+        if (a.nb) if (int rc = launch_policy(kind, a, bound, expected, st)) return rc;
     }
     return RL_OK;
 }

@@ -377,10 +377,6 @@ __device__ inline void head_mfma(const HeadW<NT, TSTRIDE>& w, const f32x16 (&hin
     for (int r = 0; r < 4; ++r) out[r] = (acc[r] + cross[r]) * (w.un[r] * un);
 }
 
-#ifndef RL_RING_D
-#define RL_RING_D 3   // K-chunks of weights in flight per wave and layer (dueling brains)
-#endif
-
 struct TileIO {
     gfloat* packed;        // the brain's packed weights
     const float* obs;      // observation rows (153 floats each)
@@ -419,10 +415,11 @@ __device__ inline float row_max_get(const float* aux, int j)
 }
 
 // One 32-row tile by 4 waves.  Every layer's weight ring and head fragments are requested BEFORE the wait that precedes
-// the layer (observation staging, the LDS exchange, the previous head): 3 waves per SIMD for the 128-wide brains.  A
-// variant that starts the rings at their layer (4 waves per SIMD) and one with 64-row tiles were measured slower at 256
-// AND at 4096 worlds.
-template <int KIND>
+// the layer (observation staging, the LDS exchange, the previous head).
+// DEEP: the variant for launches of a few tiles per CU (256 worlds): five K-chunks of weights in flight per wave (latency),
+// 3 waves per SIMD; otherwise three chunks and 4 waves per SIMD (throughput).  Measured: 18.4 vs 19.8 us at 256 worlds,
+// 217 vs 201 us at 4096.
+template <int KIND, bool DEEP>
 __device__ inline void policy_tile(const TileIO& io, f32x4* __restrict__ lds_h, float* __restrict__ lds_aux,
                                    float (*__restrict__ lds_part)[32][9], int lane, int v)
 {
@@ -460,7 +457,7 @@ __device__ inline void policy_tile(const TileIO& io, f32x4* __restrict__ lds_h, 
     } else if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
         f32x16 h1[1], h2[1];
         float adv[4], val[4];
-        WRing<4, 1, 1, RL_RING_D> w1, w2;
+        WRing<4, 1, 1, DEEP ? 5 : 3> w1, w2;
         HeadW<1, 1> wh;
         w1.start(packed + L.l1, lane, v);
         stage_x(lds_h, lds_aux, io.obs, io.row, lane, v);
