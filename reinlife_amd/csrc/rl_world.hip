@@ -426,16 +426,17 @@ __device__ void build_planes(const KParams& p, Smem& s)
     }
 }
 
-// _get_observations (environment.py:349-375): n agents in order[] -> obs rows (coalesced 49-float runs)
-template <int T>
-__device__ void write_observations(const KParams& p, Smem& s, int w, int n, float* obs)
+// _get_observations (environment.py:349-375): n agents in order[] -> obs rows (coalesced 49-float runs).  Executed by NT
+// threads, `t` = this thread's index among them (the fused tick lets wave 0 run _reproduce meanwhile).
+template <int NT>
+__device__ void write_observations(const KParams& p, Smem& s, int w, int n, float* obs, int t)
 {
     if (!obs || RL_ABL(1)) return;
     float* base = obs + (size_t)w * p.cap * RL_OBS_DIM;
-    // thread t owns window cell idx = t % 49 for agents t / 49, t / 49 + T / 49, ...: the divisions and the window offsets
+    // thread t owns window cell idx = t % 49 for agents t / 49, t / 49 + NT / 49, ...: the divisions and the window offsets
     // are computed once per thread, not once per (agent, cell) item
-    constexpr int G = T / 49;
-    const int g0 = threadIdx.x / 49, idx = threadIdx.x - g0 * 49;
+    constexpr int G = NT / 49;
+    const int g0 = t / 49, idx = t - g0 * 49;
     const int dr = idx / 7 - 3, dc = idx - (idx / 7) * 7 - 3;
     if (g0 < G) {
         float* o = base + (size_t)g0 * RL_OBS_DIM + idx;
@@ -452,7 +453,7 @@ __device__ void write_observations(const KParams& p, Smem& s, int w, int n, floa
             o[98] = g == -2 ? 0.f : (g == s.gene[a] ? 1.f : -1.f);  // _extract_gene_observation, environment.py:424-428
         }
     }
-    for (int k = threadIdx.x; k < n; k += T) {
+    for (int k = t; k < n; k += NT) {
         const int a = s.order[k];
         const int same = (int)(s.hcnt[s.hslot[a]] >> 16);
         float* o = base + (size_t)k * RL_OBS_DIM + 147;
@@ -463,6 +464,11 @@ __device__ void write_observations(const KParams& p, Smem& s, int w, int n, floa
         o[4] = (s.flags[a] & RL_F_KILLED) ? 1.f : 0.f;
         o[5] = (s.flags[a] & RL_F_ATE_SUPER) ? 1.f : -1.f;
     }
+}
+template <int T>
+__device__ inline void write_observations(const KParams& p, Smem& s, int w, int n, float* obs)
+{
+    write_observations<T>(p, s, w, n, obs, (int)threadIdx.x);
 }
 
 // Environment.step up to (not including) the observation pass
@@ -668,6 +674,127 @@ __device__ inline void init_newborn(Smem& s, int idx, int cell, int W, int gene,
     s.occ[cell] = (short)idx; s.type[cell] = RL_AGENT;
 }
 
+// _reproduce + _produce + _remove_dead_agents (environment.py:488-547, 795-799) by WAVE 0 alone, no workgroup barriers:
+// gates for the eligible agents in list order, one draw each (rank among the eligible = draw index); births are placed
+// sequentially on the occupancy bitmap, the newborns themselves are initialised in parallel afterwards.  Touches only
+// the occupancy grid, the new slots and (limit_reproduction) the parents' flags, so a fused tick runs it next to the
+// state_prime observation pass of the other waves.
+template <int T, bool LEAN>
+__device__ void reproduce_wave0(const KParams& p, Smem& s, int w, int n1, int nslots)
+{
+    const int tid = threadIdx.x;
+    const bool room = n1 <= p.max_agents;
+    const bool tape = !LEAN && p.tape.food_k != nullptr;
+    const uint32_t epoch = (uint32_t)s.scal[S_EPOCH], tick = (uint32_t)s.scal[S_TICK];
+    if (RL_ABL(8)) return;
+    const int lane = tid;
+    int rank_base = 0, npar = 0;
+    for (int base = 0; base < n1; base += 64) {
+        const int k = base + lane;
+        const bool act = k < n1;
+        const int a = act ? s.order[k] : 0;
+        const int fl = act ? s.flags[a] : 0;
+        const bool e = act && room && !(fl & (RL_F_DEAD | RL_F_REPRODUCED)) && s.age[a] > 5;  // can_reproduce, entities.py:244
+        if (act && p.static_families && s.gene[a] >= 0 && s.gene[a] < RL_MAX_BRAINS) s.present[s.gene[a]] = 1;
+        const unsigned long long em = __ballot(e);
+        bool par = false;
+        if (e) {
+            const int rank = rank_base + __popcll(em & lowmask(lane));
+            double u;
+            if (tape) u = p.tape.repro_u[(size_t)w * p.cap + rank];
+            else u = rl_u24(rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_REPRO, (uint32_t)rank).x);
+            par = u > 0.95;
+            if (par && p.limit_reproduction) s.flags[a] = (uint8_t)(fl | RL_F_REPRODUCED);
+        }
+        const unsigned long long pm = __ballot(par);
+        if (par) s.plist[npar + __popcll(pm & lowmask(lane))] = (short)a;
+        npar += __popcll(pm);
+        rank_base += __popcll(em);
+    }
+    RL_MARK(14);
+    Placer P;
+    placer_init(P, tid < p.nW ? s.occbits[tid] : ~0ull);
+    int next_uid = s.scal[S_NEXT_UID];
+    int max_gene = s.scal[S_MAX_GENE];
+    int n_birth = 0, slots = nslots;
+    // draw b of this tick's birth placements lives in lane b%64 (fetched / generated 64 at a time, in parallel)
+    unsigned bdraw = 0; int bdraw_base = -64;
+    auto birth_draw = [&](int b) -> unsigned {
+        if (b >= bdraw_base + 64 || b < bdraw_base) {
+            bdraw_base = b & ~63;
+            const int mine = bdraw_base + tid;
+            if (tape) bdraw = mine <= p.cap ? (unsigned)p.tape.birth_k[(size_t)w * (p.cap + 1) + mine] : 0u;
+            else bdraw = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_BIRTH, (uint32_t)mine).x;
+        }
+        return (unsigned)read_lane((int)bdraw, b & 63);
+    };
+    // sequential part: only the placement; (cell, gene, brain) of newborn i are parked in tgt/gene/brain of its slot
+    auto place_birth = [&](int gene, int brain, int errtag) {
+        const unsigned x = birth_draw(n_birth);  // draw indices advance only when a draw happens
+        const int k = tape ? (int)x : (int)rl_mulhi(x, (unsigned)P.n_empty);
+        ++n_birth;
+        if (k < 0 || k >= P.n_empty) { if (tid == 0) flag_error(p, s, 2, w, errtag, k); return; }
+        const int cell = placer_take(P, k);
+        if (slots >= p.cap) { if (tid == 0) flag_error(p, s, 3, w, slots, 0); return; }
+        if (tid == 0) { s.tgt[slots] = (unsigned short)cell; s.gene[slots] = gene; s.brain[slots] = brain; }
+        ++slots;
+    };
+    for (int b = 0; b < npar; ++b) {
+        if (P.n_empty <= 0) continue;  // full grid: randint raises, no draw, no offspring (grid.py:82-83)
+        const int par = s.plist[b];
+        const int g = s.gene[par];
+        place_birth(g, p.static_families ? g : s.brain[par], b);
+    }
+    RL_MARK(41);
+    // _produce
+    if (room) {
+        double u; unsigned x1 = 0;
+        if (tape) u = p.tape.produce_u[w];
+        else { const rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_PRODUCE, 0u); u = rl_u24(r.x); x1 = r.y; }
+        if (u > 0.95) {
+            int gene = -1, brain = 0;
+            if (p.static_families) {
+                if (tape) gene = p.tape.produce_choice[w];
+                else {
+                    const bool absent = tid < p.n_brains && !s.present[tid];
+                    const unsigned long long m = __ballot(absent);
+                    const int cntabs = __popcll(m);
+                    if (cntabs > 0) {
+                        const int want = (int)rl_mulhi(x1, (unsigned)cntabs);
+                        const unsigned long long hit = __ballot(absent && __popcll(m & lowmask(tid)) == want);
+                        gene = __ffsll((long long)hit) - 1;
+                    } else gene = (int)rl_mulhi(x1, (unsigned)p.n_brains);
+                }
+                brain = gene;
+            } else {
+                max_gene += 1;  // incremented even if the placement fails (environment.py:543)
+                const int c = tape ? p.tape.produce_choice[w] : (int)rl_mulhi(x1, RL_N_BEST);
+                gene = max_gene;
+                brain = (c >= 0 && c < RL_N_BEST) ? s.best_brain[c] : 0;
+                if (c < 0 || c >= RL_N_BEST) { if (tid == 0) flag_error(p, s, 4, w, c, 0); }
+            }
+            if (P.n_empty > 0 && gene >= 0) place_birth(gene, brain, -1);
+        }
+    }
+    RL_MARK(42);
+    // newborns (entities.py:145-159), initialised in parallel: lane i -> slot nslots + i
+    for (int i = nslots + lane; i < slots; i += 64) {
+        const int cell = s.tgt[i];
+        init_newborn(s, i, cell, p.W, s.gene[i], s.brain[i], next_uid + (i - nslots));
+    }
+    next_uid += slots - nslots;
+    if (tid == 0) { s.scal[S_NSLOTS] = slots; p.st.next_uid[w] = next_uid; p.st.max_gene[w] = max_gene; }
+    // _remove_dead_agents (environment.py:795-799): corpses become Food -- after the placements, which must still
+    // see their cells as occupied; same wave, so no barrier in between
+    for (int k = lane; k < n1; k += 64) {
+        const int a = s.order[k];
+        if (s.flags[a] & RL_F_DEAD) {
+            const int cell = (s.pos[a] & 255) * p.W + (s.pos[a] >> 8);
+            s.type[cell] = RL_FOOD; s.occ[cell] = -1;
+        }
+    }
+}
+
 // Environment.update_env up to (not including) the observation pass.  order[0..n1) is the grid list.
 template <int T, bool LEAN>
 __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslots, bool fresh_bitmap)
@@ -700,12 +827,6 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
         lds_barrier();
     }
     RL_MARK(13);
-    // ---- _reproduce + _produce (environment.py:488-547): wave 0 alone, no workgroup barriers -------------------------
-    // gates: eligible agents in list order, one draw each (rank among the eligible = draw index); births are placed
-    // sequentially on the occupancy bitmap, the newborns themselves are initialised in parallel afterwards.
-    const bool room = n1 <= p.max_agents;
-    const bool tape = !LEAN && p.tape.food_k != nullptr;
-    const uint32_t epoch = (uint32_t)s.scal[S_EPOCH], tick = (uint32_t)s.scal[S_TICK];
     RL_MARK(13);
     if (!fresh_bitmap) {  // standalone update: rebuild the occupancy bitmap (a fused tick reuses the food phase's)
         for (int c = tid; c < p.Cp; c += T) {
@@ -714,114 +835,7 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
         }
         lds_barrier();
     }
-    if (tid < 64 && !RL_ABL(8)) {
-        const int lane = tid;
-        int rank_base = 0, npar = 0;
-        for (int base = 0; base < n1; base += 64) {
-            const int k = base + lane;
-            const bool act = k < n1;
-            const int a = act ? s.order[k] : 0;
-            const int fl = act ? s.flags[a] : 0;
-            const bool e = act && room && !(fl & (RL_F_DEAD | RL_F_REPRODUCED)) && s.age[a] > 5;  // can_reproduce, entities.py:244
-            if (act && p.static_families && s.gene[a] >= 0 && s.gene[a] < RL_MAX_BRAINS) s.present[s.gene[a]] = 1;
-            const unsigned long long em = __ballot(e);
-            bool par = false;
-            if (e) {
-                const int rank = rank_base + __popcll(em & lowmask(lane));
-                double u;
-                if (tape) u = p.tape.repro_u[(size_t)w * p.cap + rank];
-                else u = rl_u24(rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_REPRO, (uint32_t)rank).x);
-                par = u > 0.95;
-                if (par && p.limit_reproduction) s.flags[a] = (uint8_t)(fl | RL_F_REPRODUCED);
-            }
-            const unsigned long long pm = __ballot(par);
-            if (par) s.plist[npar + __popcll(pm & lowmask(lane))] = (short)a;
-            npar += __popcll(pm);
-            rank_base += __popcll(em);
-        }
-        RL_MARK(14);
-        Placer P;
-        placer_init(P, tid < p.nW ? s.occbits[tid] : ~0ull);
-        int next_uid = s.scal[S_NEXT_UID];
-        int max_gene = s.scal[S_MAX_GENE];
-        int n_birth = 0, slots = nslots;
-        // draw b of this tick's birth placements lives in lane b%64 (fetched / generated 64 at a time, in parallel)
-        unsigned bdraw = 0; int bdraw_base = -64;
-        auto birth_draw = [&](int b) -> unsigned {
-            if (b >= bdraw_base + 64 || b < bdraw_base) {
-                bdraw_base = b & ~63;
-                const int mine = bdraw_base + tid;
-                if (tape) bdraw = mine <= p.cap ? (unsigned)p.tape.birth_k[(size_t)w * (p.cap + 1) + mine] : 0u;
-                else bdraw = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_BIRTH, (uint32_t)mine).x;
-            }
-            return (unsigned)read_lane((int)bdraw, b & 63);
-        };
-        // sequential part: only the placement; (cell, gene, brain) of newborn i are parked in tgt/gene/brain of its slot
-        auto place_birth = [&](int gene, int brain, int errtag) {
-            const unsigned x = birth_draw(n_birth);  // draw indices advance only when a draw happens
-            const int k = tape ? (int)x : (int)rl_mulhi(x, (unsigned)P.n_empty);
-            ++n_birth;
-            if (k < 0 || k >= P.n_empty) { if (tid == 0) flag_error(p, s, 2, w, errtag, k); return; }
-            const int cell = placer_take(P, k);
-            if (slots >= p.cap) { if (tid == 0) flag_error(p, s, 3, w, slots, 0); return; }
-            if (tid == 0) { s.tgt[slots] = (unsigned short)cell; s.gene[slots] = gene; s.brain[slots] = brain; }
-            ++slots;
-        };
-        for (int b = 0; b < npar; ++b) {
-            if (P.n_empty <= 0) continue;  // full grid: randint raises, no draw, no offspring (grid.py:82-83)
-            const int par = s.plist[b];
-            const int g = s.gene[par];
-            place_birth(g, p.static_families ? g : s.brain[par], b);
-        }
-        RL_MARK(41);
-        // _produce
-        if (room) {
-            double u; unsigned x1 = 0;
-            if (tape) u = p.tape.produce_u[w];
-            else { const rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_PRODUCE, 0u); u = rl_u24(r.x); x1 = r.y; }
-            if (u > 0.95) {
-                int gene = -1, brain = 0;
-                if (p.static_families) {
-                    if (tape) gene = p.tape.produce_choice[w];
-                    else {
-                        const bool absent = tid < p.n_brains && !s.present[tid];
-                        const unsigned long long m = __ballot(absent);
-                        const int cntabs = __popcll(m);
-                        if (cntabs > 0) {
-                            const int want = (int)rl_mulhi(x1, (unsigned)cntabs);
-                            const unsigned long long hit = __ballot(absent && __popcll(m & lowmask(tid)) == want);
-                            gene = __ffsll((long long)hit) - 1;
-                        } else gene = (int)rl_mulhi(x1, (unsigned)p.n_brains);
-                    }
-                    brain = gene;
-                } else {
-                    max_gene += 1;  // incremented even if the placement fails (environment.py:543)
-                    const int c = tape ? p.tape.produce_choice[w] : (int)rl_mulhi(x1, RL_N_BEST);
-                    gene = max_gene;
-                    brain = (c >= 0 && c < RL_N_BEST) ? s.best_brain[c] : 0;
-                    if (c < 0 || c >= RL_N_BEST) { if (tid == 0) flag_error(p, s, 4, w, c, 0); }
-                }
-                if (P.n_empty > 0 && gene >= 0) place_birth(gene, brain, -1);
-            }
-        }
-        RL_MARK(42);
-        // newborns (entities.py:145-159), initialised in parallel: lane i -> slot nslots + i
-        for (int i = nslots + lane; i < slots; i += 64) {
-            const int cell = s.tgt[i];
-            init_newborn(s, i, cell, p.W, s.gene[i], s.brain[i], next_uid + (i - nslots));
-        }
-        next_uid += slots - nslots;
-        if (tid == 0) { s.scal[S_NSLOTS] = slots; p.st.next_uid[w] = next_uid; p.st.max_gene[w] = max_gene; }
-        // _remove_dead_agents (environment.py:795-799): corpses become Food -- after the placements, which must still
-        // see their cells as occupied; same wave, so no barrier in between
-        for (int k = lane; k < n1; k += 64) {
-            const int a = s.order[k];
-            if (s.flags[a] & RL_F_DEAD) {
-                const int cell = (s.pos[a] & 255) * p.W + (s.pos[a] >> 8);
-                s.type[cell] = RL_FOOD; s.occ[cell] = -1;
-            }
-        }
-    }
+    if (tid < 64) reproduce_wave0<T, LEAN>(p, s, w, n1, nslots);
     lds_barrier();
     nslots = s.scal[S_NSLOTS];
     RL_MARK(15);
@@ -1071,6 +1085,7 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
     if (RL_ABL(65536)) return;
     int nslots = n0;
     int n_cur = n0;  // length of order[]
+    bool overlapped = false;  // the update's wave-0 section already ran next to the state_prime pass
 
     if (MODE == MODE_FOOD) {
         // second half of a split step (_add_food with a host-drawn tape, then the observation pass, environment.py:185-186)
@@ -1128,32 +1143,49 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
         if (!split) build_planes<T>(p, s);
         lds_barrier();
         RL_MARK(10);
-        if (!split) write_observations<T>(p, s, w, n1, p.so.obs);
-        RL_MARK(11);
+        // Lean fused tick with static families: wave 0 runs _reproduce / _produce / _remove_dead_agents (serial work on
+        // the occupancy bitmap and the new slots) WHILE the other waves write the state_prime rows and the step outputs.
+        // (Non-static families need workgroup barriers for _update_best_agents first; limit_reproduction sets a flag the
+        // observation pass reads: those take the sequential path.)
+        overlapped = LEAN && MODE == MODE_TICK && T > 64 && p.static_families && !p.limit_reproduction && !RL_ABL(256);
         const size_t b = (size_t)w * p.cap;
-        for (int k = tid; k < n1; k += T) {
-            const int a = s.order[k];
-            if (p.so.reward) p.so.reward[b + k] = (float)s.reward[a];
-            if (p.so.done) p.so.done[b + k] = (s.flags[a] & RL_F_DEAD) ? 1 : 0;
-            if (p.so.src) p.so.src[b + k] = (short)a;
-            if (!LEAN && p.so.age) p.so.age[b + k] = s.age[a];
-            if (!LEAN && p.so.brain) p.so.brain[b + k] = s.brain[a];
+        auto step_outputs = [&](int t, int nt) {
+            for (int k = t; k < n1; k += nt) {
+                const int a = s.order[k];
+                if (p.so.reward) p.so.reward[b + k] = (float)s.reward[a];
+                if (p.so.done) p.so.done[b + k] = (s.flags[a] & RL_F_DEAD) ? 1 : 0;
+                if (p.so.src) p.so.src[b + k] = (short)a;
+                if (!LEAN && p.so.age) p.so.age[b + k] = s.age[a];
+                if (!LEAN && p.so.brain) p.so.brain[b + k] = s.brain[a];
+            }
+            if (t == 0 && p.so.n_acted) p.so.n_acted[w] = n0;
+            if (!LEAN && t == 0 && p.so.n_post) p.so.n_post[w] = n1;
+            if (t == 0 && p.so.acted_total && n0) atomicAdd(p.so.acted_total, (unsigned long long)n0);
+        };
+        if (overlapped) {
+            if (tid < 64) reproduce_wave0<T, LEAN>(p, s, w, n1, nslots);
+            else {
+                write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n1, p.so.obs, tid - 64);
+                step_outputs(tid - 64, T - 64);
+            }
+        } else {
+            if (!split) write_observations<T>(p, s, w, n1, p.so.obs);
+            RL_MARK(11);
+            step_outputs(tid, T);
         }
-        if (tid == 0 && p.so.n_acted) p.so.n_acted[w] = n0;
-        if (!LEAN && tid == 0 && p.so.n_post) p.so.n_post[w] = n1;
-        if (tid == 0 && p.so.acted_total && n0) atomicAdd(p.so.acted_total, (unsigned long long)n0);
         if (!LEAN && p.so.trk_tick && tid < 64) track_world_wave0(p, s, w, n1);
         n_cur = n1;
         if (MODE == MODE_STEP) { store_world<T>(p, s, w, n1); return; }
         lds_barrier();
-        // fused tick: agents keep their LDS slot; remember their post-step list index for uo.src
+        // fused tick: agents keep their LDS slot; remember their post-step list index for uo.src (newborns carry -1)
         for (int a = tid; a < nslots; a += T) s.src[a] = s.newidx[a];
         lds_barrier();
+        if (overlapped) nslots = s.scal[S_NSLOTS];
     }
     if (MODE == MODE_UPDATE || MODE == MODE_TICK) {
         const int n1 = n_cur;
         RL_MARK(12);
-        if (!RL_ABL(256)) phase_update<T, LEAN>(p, s, w, n1, nslots, MODE == MODE_TICK);
+        if (!RL_ABL(256) && !overlapped) phase_update<T, LEAN>(p, s, w, n1, nslots, MODE == MODE_TICK);
         RL_MARK(17);
         build_order<T>(p, s, nslots, S_N2);
         RL_MARK(18);
