@@ -1198,14 +1198,20 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
         build_planes<T>(p, s);
         lds_barrier();
         RL_MARK(20);
-        write_observations<T>(p, s, w, n2, p.uo.obs);
+        if (LEAN && MODE == MODE_TICK && T > 64 && p.lists && !RL_ABL(128)) {
+            // wave 0 reserves and fills the per-brain row lists (an atomic round trip) while the others write the rows
+            if (tid < 64) emit_brain_lists_wave0(p, w, n2, [&](int k) { return s.brain[s.order[k]]; });
+            else write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n2, p.uo.obs, tid - 64);
+        } else {
+            write_observations<T>(p, s, w, n2, p.uo.obs);
+            if (p.lists && tid < 64 && !RL_ABL(128)) emit_brain_lists_wave0(p, w, n2, [&](int k) { return s.brain[s.order[k]]; });
+        }
         RL_MARK(21);
         if (p.uo.src) {
             const size_t b = (size_t)w * p.cap;
             for (int k = tid; k < n2; k += T) p.uo.src[b + k] = s.src[s.order[k]];
         }
         store_world<T>(p, s, w, n2);
-        if (p.lists && tid < 64 && !RL_ABL(128)) emit_brain_lists_wave0(p, w, n2, [&](int k) { return s.brain[s.order[k]]; });
         RL_MARK(22);
         if (tid == 0 && !refill) p.st.tick[w] = s.scal[S_TICK] + 1;
     }
