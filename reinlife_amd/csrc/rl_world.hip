@@ -399,6 +399,29 @@ __device__ void build_order(const KParams& p, Smem& s, int nslots, int out_slot)
     lds_barrier();
 }
 
+// Third part of build_order alone (agbits / wordbase / scal[slot] already there); no trailing barrier
+template <int T>
+__device__ void assign_order(const KParams& p, Smem& s, int nslots)
+{
+    for (int a = threadIdx.x; a < nslots; a += T) {
+        const int cell = (s.pos[a] & 255) * p.W + (s.pos[a] >> 8);
+        short ni = -1;
+        if (s.occ[cell] == a) {
+            ni = (short)(s.wordbase[cell >> 6] + __popcll(s.agbits[cell >> 6] & lowmask(cell & 63)));
+            s.order[ni] = (short)a;
+        }
+        s.newidx[a] = ni;
+    }
+}
+// Second part of build_order by ONE wave (lane l = bitmap word l): exclusive prefix of the agent counts
+__device__ inline void scan_order_wave(const KParams& p, Smem& s, int lane, int out_slot)
+{
+    const int cntw = lane < p.nW ? __popcll(s.agbits[lane]) : 0;
+    const int incl = wave_incl_scan(cntw);
+    s.wordbase[lane] = incl - cntw;
+    if (lane == 63) s.scal[out_slot] = incl;
+}
+
 // _prepare_observations (environment.py:377-404) into LDS planes
 template <int T>
 __device__ void build_planes(const KParams& p, Smem& s)
@@ -604,18 +627,22 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
     }
     RL_MARK(5);
     // ---- _add_food (environment.py:763-776) ---------------------------------------------------------------------------
+    // (the agent bitmap of the post-step ordering is taken in the same sweep: food placement does not touch agent cells,
+    // so the ordering's prefix scan can run on wave 1 next to the placement on wave 0)
     int nf = 0, np_ = 0, ns = 0;
     for (int c = tid; c < p.Cp; c += T) {
         const int t = s.type[c];
         nf += t == RL_FOOD; np_ += t == RL_POISON; ns += t == kSuper;
         const unsigned long long m = __ballot(t != RL_EMPTY);
-        if (lane_id() == 0) s.occbits[c >> 6] = m;
+        const unsigned long long ma = __ballot(t == RL_AGENT);
+        if (lane_id() == 0) { s.occbits[c >> 6] = m; s.agbits[c >> 6] = ma; }
     }
     if (nf) atomicAdd(&s.scal[S_NFOOD], nf);
     if (np_) atomicAdd(&s.scal[S_NPOISON], np_);
     if (ns) atomicAdd(&s.scal[S_NSUPER], ns);
     lds_barrier();
     RL_MARK(6);
+    if (tid >= 64 && tid < 128) scan_order_wave(p, s, tid - 64, S_N1);
     if (!LEAN && p.split_food) {  // seed-compatible stepping: the host needs these counts to draw exactly like _add_food
         if (tid < 64) {
             int ne = tid < p.nW ? __popcll(~s.occbits[tid]) : 0;
@@ -1134,12 +1161,14 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
         return;
     }
     if (MODE == MODE_STEP || MODE == MODE_TICK) {
-        if (!RL_ABL(512)) phase_step<T, LEAN>(p, s, w, n0);
-        RL_MARK(8);
-        build_order<T>(p, s, nslots, S_N1);
+        const bool split = !LEAN && MODE == MODE_STEP && p.split_food;  // observation pass comes with the food half
+        if (!RL_ABL(512)) {
+            phase_step<T, LEAN>(p, s, w, n0);  // leaves the agent bitmap, its prefix and scal[S_N1] of the new ordering
+            RL_MARK(8);
+            assign_order<T>(p, s, nslots);     // same barrier interval as the planes: they do not read the ordering
+        } else build_order<T>(p, s, nslots, S_N1);
         RL_MARK(9);
         const int n1 = s.scal[S_N1];
-        const bool split = !LEAN && MODE == MODE_STEP && p.split_food;  // observation pass comes with the food half
         if (!split) build_planes<T>(p, s);
         lds_barrier();
         RL_MARK(10);
