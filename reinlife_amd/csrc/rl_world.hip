@@ -1208,22 +1208,40 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
         lds_barrier();
         // fused tick: agents keep their LDS slot; remember their post-step list index for uo.src (newborns carry -1)
         for (int a = tid; a < nslots; a += T) s.src[a] = s.newidx[a];
-        lds_barrier();
-        if (overlapped) nslots = s.scal[S_NSLOTS];
+        if (!overlapped) lds_barrier();  // (overlapped: this loop shares the interval of the update's first sweep below)
+        else nslots = s.scal[S_NSLOTS];
     }
     if (MODE == MODE_UPDATE || MODE == MODE_TICK) {
         const int n1 = n_cur;
         RL_MARK(12);
         if (!RL_ABL(256) && !overlapped) phase_update<T, LEAN>(p, s, w, n1, nslots, MODE == MODE_TICK);
         RL_MARK(17);
-        build_order<T>(p, s, nslots, S_N2);
+        // new ordering + on-grid gene counts + observation planes in three barrier intervals: (1) agent bitmap sweep and
+        // gene table clear, (2) prefix scan by one wave, (3) order assignment, gene counting by slot and the planes
+        for (int c = tid; c < p.Cp; c += T) {
+            const unsigned long long m = __ballot(s.type[c] == RL_AGENT);
+            if (lane_id() == 0) s.agbits[c >> 6] = m;
+        }
+        for (int i = tid; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
+        lds_barrier();
+        if (tid < 64) scan_order_wave(p, s, tid, S_N2);
+        lds_barrier();
         RL_MARK(18);
         int n2 = s.scal[S_N2];
         // optional fused refill: a world whose population fell below the threshold is re-generated
         const bool refill = p.refill_threshold >= 0 && n2 < p.refill_threshold;  // uniform per workgroup
-        if (refill) n2 = reset_world_lds<T>(p, s, w, (uint32_t)s.scal[S_EPOCH] + 1u);
         RL_MARK(19);
-        rebuild_gene_counts<T>(p, s, n2);
+        if (refill) {
+            n2 = reset_world_lds<T>(p, s, w, (uint32_t)s.scal[S_EPOCH] + 1u);
+            rebuild_gene_counts<T>(p, s, n2);
+        } else {
+            assign_order<T>(p, s, nslots);
+            const int nsp = (nslots + 63) & ~63;  // whole waves take part in the gene aggregation
+            for (int a = tid; a < nsp; a += T) {
+                const bool on = a < nslots && s.occ[(s.pos[a] & 255) * p.W + (s.pos[a] >> 8)] == a;
+                hash_insert_wave(s, p.hash_mask, on, a, on ? s.gene[a] : 0, 1u << 16);
+            }
+        }
         build_planes<T>(p, s);
         lds_barrier();
         RL_MARK(20);
