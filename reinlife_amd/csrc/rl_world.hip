@@ -33,7 +33,7 @@ constexpr uint8_t kPadCell = 0xFF;  // grid padding up to a multiple of 64 cells
 
 // scalar slots in LDS
 enum { S_ALIVE = 0, S_NFOOD, S_NPOISON, S_NSUPER, S_NSLOTS, S_N1, S_N2, S_NPARENTS, S_NELIG, S_BESTK, S_ERR, S_TICK, S_EPOCH,
-       S_NEXT_UID, S_MAX_GENE, S_ANYFLAG0, S_ANYFLAG1, S_COUNT = 24 };
+       S_NEXT_UID, S_MAX_GENE, S_ANYFLAG0, S_ANYFLAG1, S_NPLACED, S_COUNT = 24 };
 
 struct KParams {
     int W, H, C, Cp, nW;
@@ -424,11 +424,11 @@ __device__ inline void scan_order_wave(const KParams& p, Smem& s, int lane, int 
 
 // _prepare_observations (environment.py:377-404) into LDS planes
 template <int T>
-__device__ void build_planes(const KParams& p, Smem& s)
+__device__ void build_planes(const KParams& p, Smem& s, int t0 = threadIdx.x, int nt = T)
 {
     if (RL_ABL(2)) return;
     const bool float_mode = s.type[0] == RL_AGENT;  // np.vectorize dtype inference from cell (0,0)
-    for (int c = threadIdx.x; c < p.C; c += T) {
+    for (int c = t0; c < p.C; c += nt) {
         const int t = s.type[c];
         float f = 0.f, h = -1.f;
         int g = -2;
@@ -495,7 +495,7 @@ __device__ inline void write_observations(const KParams& p, Smem& s, int w, int 
 }
 
 // Environment.step up to (not including) the observation pass
-template <int T, bool LEAN>
+template <int T, bool LEAN, bool PLANES_EARLY>
 __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
 {
     const int tid = threadIdx.x;
@@ -655,7 +655,9 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
         lds_barrier();
         return;
     }
+    if (tid == 0) s.scal[S_NPLACED] = 0;
     if (tid < 64 && !RL_ABL(4)) {
+        int nplaced = 0;
         Placer P;
         placer_init(P, tid < p.nW ? s.occbits[tid] : ~0ull);
         const bool tape = !LEAN && p.tape.food_k != nullptr;
@@ -683,11 +685,31 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
             const int k = tape ? (int)x : (int)rl_mulhi(x, (unsigned)P.n_empty);
             if (k < 0 || k >= P.n_empty) { if (tid == 0) flag_error(p, s, 1, w, t, k); continue; }
             const int cell = placer_take(P, k);
-            if (tid == 0) s.type[cell] = (uint8_t)(t < 3 ? RL_FOOD : (t < 6 ? RL_POISON : kSuper));
+            if (tid == 0) {
+                s.type[cell] = (uint8_t)(t < 3 ? RL_FOOD : (t < 6 ? RL_POISON : kSuper));
+                s.plist[nplaced] = (short)cell;  // (plist is free until the update: remembered for the planes' patch)
+            }
+            ++nplaced;
         }
         if (tid < p.nW) s.occbits[tid] = P.word;
+        if (tid == 0) s.scal[S_NPLACED] = nplaced;
+    } else if (PLANES_EARLY && tid >= 128) {
+        // waves 2.. build the observation planes of the post-step grid meanwhile, as if nothing were placed; the (at most
+        // seven) placed cells are patched in the next interval (patch_placed_planes)
+        build_planes<T>(p, s, tid - 128, T - 128);
     }
     lds_barrier();
+}
+
+// the planes of the cells _add_food just filled (they were built as empty cells next to the placement)
+__device__ inline void patch_placed_planes(Smem& s)
+{
+    const int tid = threadIdx.x;
+    if (tid < s.scal[S_NPLACED]) {
+        const int c = s.plist[tid];
+        const int t = s.type[c];
+        s.foodv[c] = t == RL_FOOD ? 0.5f : (t == kSuper ? 1.f : -1.f);
+    }
 }
 
 __device__ inline void init_newborn(Smem& s, int idx, int cell, int W, int gene, int brain, int uid)
@@ -1162,14 +1184,17 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
     }
     if (MODE == MODE_STEP || MODE == MODE_TICK) {
         const bool split = !LEAN && MODE == MODE_STEP && p.split_food;  // observation pass comes with the food half
+        constexpr bool kPlanesEarly = T >= 256 && MODE == MODE_TICK;  // (a split step returns before the placement interval)
         if (!RL_ABL(512)) {
-            phase_step<T, LEAN>(p, s, w, n0);  // leaves the agent bitmap, its prefix and scal[S_N1] of the new ordering
+            // leaves the agent bitmap, its prefix and scal[S_N1] of the new ordering -- and, kPlanesEarly, the planes
+            phase_step<T, LEAN, kPlanesEarly>(p, s, w, n0);
             RL_MARK(8);
             assign_order<T>(p, s, nslots);     // same barrier interval as the planes: they do not read the ordering
+            if (kPlanesEarly) patch_placed_planes(s);
         } else build_order<T>(p, s, nslots, S_N1);
         RL_MARK(9);
         const int n1 = s.scal[S_N1];
-        if (!split) build_planes<T>(p, s);
+        if (!split && !(kPlanesEarly && !RL_ABL(512))) build_planes<T>(p, s);
         lds_barrier();
         RL_MARK(10);
         // Lean fused tick with static families: wave 0 runs _reproduce / _produce / _remove_dead_agents (serial work on
