@@ -844,6 +844,31 @@ __device__ void reproduce_wave0(const KParams& p, Smem& s, int w, int n1, int ns
     }
 }
 
+// _update_best_agents (environment.py:728-739) by ONE wave (no workgroup barrier): used when the update's serial section
+// runs on wave 0 next to the other waves' observation pass
+__device__ inline void best_agents_wave(Smem& s, int n1)
+{
+    const int lane = lane_id();
+    double bf = -1.0e300; int bk = 0x7fffffff;
+    for (int k = lane; k < n1; k += 64) {
+        const double f = s.fitness[s.order[k]];
+        if (f > bf || (f == bf && k < bk)) { bf = f; bk = k; }
+    }
+#pragma unroll
+    for (int m = 32; m; m >>= 1) {
+        const double of = shfl_xor_f64(bf, m); const int ok = __shfl_xor(bk, m);
+        if (of > bf || (of == bf && ok < bk)) { bf = of; bk = ok; }
+    }
+    if (lane == 0 && n1 > 0) {
+        int mi = 0;
+        for (int b = 1; b < RL_N_BEST; ++b) if (s.best_fit[b] < s.best_fit[mi]) mi = b;
+        const int a = s.order[bk];
+        bool present = false;
+        for (int b = 0; b < RL_N_BEST; ++b) present |= s.best_uid[b] == s.uid[a];
+        if (!present && bf > s.best_fit[mi]) { s.best_uid[mi] = s.uid[a]; s.best_fit[mi] = bf; s.best_brain[mi] = s.brain[a]; }
+    }
+}
+
 // Environment.update_env up to (not including) the observation pass.  order[0..n1) is the grid list.
 template <int T, bool LEAN>
 __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslots, bool fresh_bitmap)
@@ -1197,11 +1222,10 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
         if (!split && !(kPlanesEarly && !RL_ABL(512))) build_planes<T>(p, s);
         lds_barrier();
         RL_MARK(10);
-        // Lean fused tick with static families: wave 0 runs _reproduce / _produce / _remove_dead_agents (serial work on
+        // Lean fused tick: wave 0 runs _update_best_agents / _reproduce / _produce / _remove_dead_agents (serial work on
         // the occupancy bitmap and the new slots) WHILE the other waves write the state_prime rows and the step outputs.
-        // (Non-static families need workgroup barriers for _update_best_agents first; limit_reproduction sets a flag the
-        // observation pass reads: those take the sequential path.)
-        overlapped = LEAN && MODE == MODE_TICK && T > 64 && p.static_families && !p.limit_reproduction && !RL_ABL(256);
+        // (limit_reproduction sets a flag the observation pass reads: it takes the sequential path.)
+        overlapped = LEAN && MODE == MODE_TICK && T > 64 && !p.limit_reproduction && !RL_ABL(256);
         const size_t b = (size_t)w * p.cap;
         auto step_outputs = [&](int t, int nt) {
             for (int k = t; k < n1; k += nt) {
@@ -1217,8 +1241,10 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
             if (t == 0 && p.so.acted_total && n0) atomicAdd(p.so.acted_total, (unsigned long long)n0);
         };
         if (overlapped) {
-            if (tid < 64) reproduce_wave0<T, LEAN>(p, s, w, n1, nslots);
-            else {
+            if (tid < 64) {
+                if (!p.static_families) best_agents_wave(s, n1);  // _produce reads best_brain: same wave, program order
+                reproduce_wave0<T, LEAN>(p, s, w, n1, nslots);
+            } else {
                 write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n1, p.so.obs, tid - 64);
                 step_outputs(tid - 64, T - 64);
             }

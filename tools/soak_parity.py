@@ -1,5 +1,5 @@
 """Long free run: the HIP path (policy-driven actions, fused tick + refill) against the oracle fed the same actions
-(one-off confidence check; GPU + oracle; ~1-2 minutes).   python tools/soak_parity.py [worlds] [ticks]"""
+(one-off confidence check; GPU + oracle; ~1-2 minutes).   python tools/soak_parity.py [worlds] [ticks] [static|nonstatic]"""
 import os
 import sys
 
@@ -15,7 +15,8 @@ from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights  # noqa: E402
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 600
-cfg = dict(width=30, height=30, max_agents=100, n_brains=2, static_families=True, limit_reproduction=False, incentivize_killing=True)
+static = (sys.argv[3] != "nonstatic") if len(sys.argv) > 3 else True
+cfg = dict(width=30, height=30, max_agents=100, n_brains=2, static_families=static, limit_reproduction=False, incentivize_killing=True)
 dw = DeviceWorlds(n_worlds=R, seed=4242, **cfg)
 ow = orc.OracleWorlds(n_worlds=R, seed=4242, **cfg)
 dw.set_brains([(_lib.KIND_BY_METHOD["PERD3QN"], 0.1 * k, pack_brain_weights(_lib.KIND_BY_METHOD["PERD3QN"], bench.brain_weights("PERD3QN", 100 + k)))
@@ -42,5 +43,5 @@ for t in range(ticks):
         o = dw.obs_state().cpu().numpy()
         for w in range(R):
             assert np.array_equal(o[w, :ow.s["n_agents"][w]], ow.obs2[w, :ow.s["n_agents"][w]]), (t, "obs2", w)
-print("soak ok: %d worlds x %d ticks, %d agent-steps, %d refills, state and observations bit-identical to the oracle"
-      % (R, ticks, steps, int(dw.refill_count.item())))
+print("soak ok (%s families): %d worlds x %d ticks, %d agent-steps, %d refills, state and observations bit-identical to the oracle"
+      % ("static" if static else "non-static", R, ticks, steps, int(dw.refill_count.item())))
