@@ -1491,7 +1491,7 @@ template <int MODE>
 int launch_world(const rl_world* h, const KParams& p, hipStream_t stream)
 {
     if (int rc = rl_world_prepare_bytes(h->smem_bytes)) return rc;
-    const bool lean = MODE == MODE_TICK && !p.tape.food_k && !p.so.trk_tick && !p.so.age && !p.so.brain && !p.so.n_post && !p.prof;
+    const bool lean = MODE == MODE_TICK && !p.tape.food_k && !p.so.trk_tick && !p.so.age && !p.so.brain && !p.so.n_post;
     return lean ? launch_world_v<MODE, true>(h, p, stream) : launch_world_v<MODE, false>(h, p, stream);
 }
 
