@@ -494,6 +494,42 @@ __device__ inline void write_observations(const KParams& p, Smem& s, int w, int 
     write_observations<T>(p, s, w, n, obs, (int)threadIdx.x);
 }
 
+// Lean tick: every Philox draw of the tick depends only on (seed, epoch, world, tick, site, index), so the idle upper half of
+// the workgroup computes them during the first agent phase and parks them in LDS (the tracker's scratch, unused in the lean
+// kernel); the serial sections on wave 0 (_add_food, _reproduce, _produce) then just read them.
+// layout (32-bit words): [0..6] food x, [8..14] food y, [16,17] produce x,y, [32..95] birth draws 0..63, [128..) gate draws
+struct DrawCache {
+    unsigned* w;
+    int n_gate;  // gate draws cached for ranks < n_gate
+};
+__device__ inline DrawCache draw_cache(const KParams& p, Smem& s)
+{
+    DrawCache c;
+    c.w = (unsigned*)s.trk_rew;
+    c.n_gate = max(0, min(p.cap, 2 * p.cap - 128));
+    return c;
+}
+template <int T>
+__device__ inline void precompute_draws(const KParams& p, Smem& s, int w)
+{
+    const DrawCache c = draw_cache(p, s);
+    const uint32_t epoch = (uint32_t)s.scal[S_EPOCH], tick = (uint32_t)s.scal[S_TICK], world = (uint32_t)(p.world_base + w);
+    for (int item = (int)threadIdx.x - T / 2; item < 128 + c.n_gate; item += T / 2) {
+        if (item < 0) break;
+        if (item < RL_FOOD_TRIES) {
+            const rl_u4 r = rl_philox4x32(p.seed, epoch, world, tick, RL_SITE_FOOD, (uint32_t)item);
+            c.w[item] = r.x; c.w[8 + item] = r.y;
+        } else if (item == 16) {
+            const rl_u4 r = rl_philox4x32(p.seed, epoch, world, tick, RL_SITE_PRODUCE, 0u);
+            c.w[16] = r.x; c.w[17] = r.y;
+        } else if (item >= 32 && item < 96) {
+            c.w[item] = rl_philox4x32(p.seed, epoch, world, tick, RL_SITE_BIRTH, (uint32_t)(item - 32)).x;
+        } else if (item >= 128) {
+            c.w[item] = rl_philox4x32(p.seed, epoch, world, tick, RL_SITE_REPRO, (uint32_t)(item - 128)).x;
+        }
+    }
+}
+
 // Environment.step up to (not including) the observation pass
 template <int T, bool LEAN, bool PLANES_EARLY>
 __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
@@ -536,6 +572,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
         s.tgt[a] = (unsigned short)tg;
         atomicAdd(&cnt[tg], 1u);
     }
+    if (LEAN && tid >= T / 2) precompute_draws<T>(p, s, w);
     lds_barrier();
     RL_MARK(2);
     // ---- _execute_movement: Jacobi fixed point (environment.py:637-644) --------------------------------------------
@@ -664,6 +701,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
         unsigned xk = 0; double u = 2.0;
         if (tid < RL_FOOD_TRIES) {
             if (tape) { xk = (unsigned)p.tape.food_k[(size_t)w * RL_FOOD_TRIES + tid]; u = p.tape.food_u[(size_t)w * RL_FOOD_TRIES + tid]; }
+            else if (LEAN) { const DrawCache c = draw_cache(p, s); xk = c.w[tid]; u = rl_u24(c.w[8 + tid]); }
             else {
                 const rl_u4 r = rl_philox4x32(p.seed, (uint32_t)s.scal[S_EPOCH], (uint32_t)(p.world_base + w), (uint32_t)s.scal[S_TICK], RL_SITE_FOOD, (uint32_t)tid);
                 xk = r.x; u = rl_u24(r.y);
@@ -735,6 +773,7 @@ __device__ void reproduce_wave0(const KParams& p, Smem& s, int w, int n1, int ns
     const bool room = n1 <= p.max_agents;
     const bool tape = !LEAN && p.tape.food_k != nullptr;
     const uint32_t epoch = (uint32_t)s.scal[S_EPOCH], tick = (uint32_t)s.scal[S_TICK];
+    const DrawCache dc = draw_cache(p, s);
     if (RL_ABL(8)) return;
     const int lane = tid;
     int rank_base = 0, npar = 0;
@@ -751,6 +790,7 @@ __device__ void reproduce_wave0(const KParams& p, Smem& s, int w, int n1, int ns
             const int rank = rank_base + __popcll(em & lowmask(lane));
             double u;
             if (tape) u = p.tape.repro_u[(size_t)w * p.cap + rank];
+            else if (LEAN && rank < dc.n_gate) u = rl_u24(dc.w[128 + rank]);
             else u = rl_u24(rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_REPRO, (uint32_t)rank).x);
             par = u > 0.95;
             if (par && p.limit_reproduction) s.flags[a] = (uint8_t)(fl | RL_F_REPRODUCED);
@@ -773,6 +813,7 @@ __device__ void reproduce_wave0(const KParams& p, Smem& s, int w, int n1, int ns
             bdraw_base = b & ~63;
             const int mine = bdraw_base + tid;
             if (tape) bdraw = mine <= p.cap ? (unsigned)p.tape.birth_k[(size_t)w * (p.cap + 1) + mine] : 0u;
+            else if (LEAN && mine < 64) bdraw = dc.w[32 + mine];
             else bdraw = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_BIRTH, (uint32_t)mine).x;
         }
         return (unsigned)read_lane((int)bdraw, b & 63);
@@ -799,6 +840,7 @@ __device__ void reproduce_wave0(const KParams& p, Smem& s, int w, int n1, int ns
     if (room) {
         double u; unsigned x1 = 0;
         if (tape) u = p.tape.produce_u[w];
+        else if (LEAN) { u = rl_u24(dc.w[16]); x1 = dc.w[17]; }
         else { const rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), tick, RL_SITE_PRODUCE, 0u); u = rl_u24(r.x); x1 = r.y; }
         if (u > 0.95) {
             int gene = -1, brain = 0;
