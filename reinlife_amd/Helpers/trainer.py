@@ -26,6 +26,8 @@ def trainer(brains, n_episodes=10_000, width=30, height=30, visualize_results=Fa
             for agent in env.agents:
                 agent.learn(n_epi=n_epi)
         env.update_env(n_epi)
+        if render:  # trainer.py:101-102
+            env.render(fps=120)
     if save:
         env.save_results()
     return env

@@ -11,7 +11,7 @@ reset() / step() / update_env() (environment.py:133-158, 488-547, 741-776; grid.
 you would for the reference and the world follows the reference's trajectory bit for bit (tests/test_hip_seed_compat.py
 replays the golden traces from their seeds alone).  The draws of _add_food depend on the grid after movement, so a step
 is two launches (rl_step_split -> host draws -> rl_step_food).  `rng="philox"` (the default and only choice for
-n_worlds > 1) draws inside the kernels from counter-based Philox streams keyed by `seed`.  The Tracker's statistics are accumulated in the step kernel (Helpers/tracker.py); Saver / renderer are out of scope.
+n_worlds > 1) draws inside the kernels from counter-based Philox streams keyed by `seed`.  The Tracker's statistics are accumulated in the step kernel (Helpers/tracker.py); Saver and a headless painter (Helpers/render.py) mirror the reference's; pygame windows are out of scope.
 """
 import numpy as np
 import torch
@@ -112,6 +112,11 @@ class Environment:
         if self.rng not in ("reference", "philox") or (self.rng == "reference" and n_worlds != 1):
             raise ValueError("rng must be 'reference' (single world only) or 'philox'")
         self.best_agents = []
+        # environment.py:118: the painter is built first (pastel colours draw from `random` here, its background tiles at
+        # the first render() -- both matter for same-seed runs)
+        from ..Helpers.render import Visualize
+        self.viz = Visualize(self.width, self.height, grid_size, pastel=pastel_colors)
+        self.frame = None
         self.worlds = DeviceWorlds(n_worlds=n_worlds, width=width, height=height, max_agents=max_agents,
                                    n_brains=len(brains), static_families=static_families,
                                    limit_reproduction=limit_reproduction, incentivize_killing=incentivize_killing, seed=seed,
@@ -255,8 +260,16 @@ class Environment:
         return ({"food_k": np.zeros(_lib.FOOD_TRIES, np.int32), "food_u": np.zeros(_lib.FOOD_TRIES), "repro_u": repro_u,
                  "birth_k": birth_k, "produce_u": produce_u, "produce_choice": choice}, produced)
 
-    def render(self, fps=10):
-        return False  # renderer out of scope
+    def render_feed(self, world=0):
+        """What the reference's painter reads (render.py:90-200) for one world: agents i/j/gene/health/killed/dead + food cells."""
+        from ..Helpers.render import RenderFeed
+        return RenderFeed.from_world(self.width, self.height, self.worlds.world(world))
+
+    def render(self, fps=10, world=0):
+        """environment.py:217-231.  No pygame window here: the frame is painted into `self.frame` (uint8 RGB,
+        [height*grid_size, width*grid_size, 3]); returns True = keep going, like an open pygame window does."""
+        self.frame = self.viz.frame(self.render_feed(world))
+        return True
 
     def save_results(self, main_folder="experiments"):
         """environment.py:233-256: brains + parameters + results.json + settings.json in the reference's layout."""

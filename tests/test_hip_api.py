@@ -56,9 +56,19 @@ def test_trainer_and_tester_run_the_batched_loop():
     assert env.worlds.s["tick"].cpu().numpy().tolist() == [41] * 4
     for a in env.agents:
         assert a.state.shape == (153,) and 0 <= a.gene < 2 and a.brain.method == "PERD3QN"
+    frames = []
     env2 = tester([Models.PPO(), Models.DQN(training=False), Models.D3QN(training=False)], width=30, height=20, max_agents=150,
-                  n_steps=25)
+                  n_steps=25, on_frame=lambda e: frames.append(e.frame))
     assert env2.grid.shape == (20, 30) and int(env2.worlds.s["tick"][0].item()) == 25
+    # tester.py:55,72: one frame after reset and one per tick; the last one shows the device world as it stands
+    assert len(frames) == 25 and frames[-1].shape == (20 * 24, 30 * 24, 3) and frames[-1].dtype == np.uint8
+    feed = env2.render_feed()
+    assert len(feed.i) == len(env2.agents) > 0
+    for a, i, j, g in zip(env2.agents, feed.i, feed.j, feed.gene):
+        assert (a.i, a.j, a.gene) == (i, j, g)
+        assert tuple(frames[-1][i * 24 + 12, j * 24 + 6]) == env2.viz.colors[g % 8]   # body colour, inside the border, off the eyes
+    ii, jj = feed.cells(env2.entities.food)
+    assert len(ii) and all(tuple(frames[-1][i * 24 + 12, j * 24 + 12]) == (255, 255, 255) for i, j in zip(ii, jj))
 
 
 def test_single_state_get_action_matches_batched_forward():
