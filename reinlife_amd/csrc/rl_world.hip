@@ -90,10 +90,14 @@ enum { AUX_VANISH = 1, AUX_PARENT = 2 };
 
 #ifdef RL_PHASE_PROFILE
 #define RL_ABL(bit) (p.ablate & (bit))  /* tuning build only: skip a section (results are then WRONG) */
-#define RL_MARK(i) do { if (p.prof && (int)blockIdx.x == p.prof_world && threadIdx.x == 0) p.prof[i] = (long long)clock64(); } while (0)
+#define RL_MARK(i) do { if (p.prof && (int)blockIdx.x == p.prof_world && threadIdx.x == 0) RL_G(p.prof)[i] = (long long)__builtin_readcyclecounter(); } while (0) /* global (not flat) store: stays off lgkmcnt */
+#define RL_MARK_T(i, t) do { if (p.prof && (int)blockIdx.x == p.prof_world && (int)threadIdx.x == (t)) RL_G(p.prof)[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define RL_MARK_W(base) do { if (p.prof && (int)blockIdx.x == p.prof_world && (threadIdx.x & 63) == 0) RL_G(p.prof)[(base) + (threadIdx.x >> 6)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
+#define RL_MARK_W(base) do { } while (0)
 #define RL_ABL(bit) 0
 #define RL_MARK(i) do { } while (0)
+#define RL_MARK_T(i, t) do { } while (0)
 #endif
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -623,28 +627,35 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
     }
     lds_barrier();
     RL_MARK(36);
-    int alive_local = 0;
+    // (per-wave counts are taken with ballots and added by one lane: a per-lane atomicAdd on one LDS word is turned by the
+    // compiler into a scalar loop over the active lanes, ~60 cycles per lane -- 2 us for a full wave)
+    int alive_wave = 0;
     const int n0p = (n0 + 63) & ~63;  // whole waves take part in the gene aggregation
     for (int a = tid; a < n0p; a += T) {
-        if (a >= n0) { hash_insert_wave(s, p.hash_mask, false, 0, 0, 0u); continue; }
-        const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
-        const int tg = s.tgt[a];
-        if (tg != cx) {
-            if (!(s.aux[a] & AUX_VANISH)) { s.type[tg] = RL_AGENT; s.occ[tg] = (short)a; }
-            const int ti = tg / W;
-            s.pos[a] = (unsigned short)(ti | ((tg - ti * W) << 8));
+        const bool valid = a < n0;
+        unsigned alive = 0u, ongrid = 0u;
+        int gene = 0;
+        if (valid) {
+            const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
+            const int tg = s.tgt[a];
+            if (tg != cx) {
+                if (!(s.aux[a] & AUX_VANISH)) { s.type[tg] = RL_AGENT; s.occ[tg] = (short)a; }
+                const int ti = tg / W;
+                s.pos[a] = (unsigned short)(ti | ((tg - ti * W) << 8));
+            }
+            // _update_death_status (environment.py:789-793)
+            int fl = s.flags[a];
+            if (s.health[a] <= 0 || s.age[a] == s.max_age[a]) fl |= RL_F_DEAD;
+            s.flags[a] = (uint8_t)fl;
+            alive = (fl & RL_F_DEAD) ? 0u : 1u;
+            ongrid = (s.aux[a] & AUX_VANISH) ? 0u : 1u;
+            gene = s.gene[a];
         }
-        // _update_death_status (environment.py:789-793)
-        int fl = s.flags[a];
-        if (s.health[a] <= 0 || s.age[a] == s.max_age[a]) fl |= RL_F_DEAD;
-        s.flags[a] = (uint8_t)fl;
-        const unsigned alive = (fl & RL_F_DEAD) ? 0u : 1u;
-        const unsigned ongrid = (s.aux[a] & AUX_VANISH) ? 0u : 1u;
-        alive_local += (int)alive;
-        hash_insert_wave(s, p.hash_mask, true, a, s.gene[a], alive | (ongrid << 16));
+        alive_wave += __popcll(__ballot(alive != 0u));
+        hash_insert_wave(s, p.hash_mask, valid, a, gene, alive | (ongrid << 16));
     }
     RL_MARK(37);
-    if (alive_local) atomicAdd(&s.scal[S_ALIVE], alive_local);
+    if (alive_wave && lane_id() == 0) atomicAdd(&s.scal[S_ALIVE], alive_wave);
     lds_barrier();
     RL_MARK(4);
     // ---- _get_rewards over the _act list incl. vanished agents (environment.py:291-311) ------------------------------
@@ -666,17 +677,19 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
     // ---- _add_food (environment.py:763-776) ---------------------------------------------------------------------------
     // (the agent bitmap of the post-step ordering is taken in the same sweep: food placement does not touch agent cells,
     // so the ordering's prefix scan can run on wave 1 next to the placement on wave 0)
-    int nf = 0, np_ = 0, ns = 0;
+    int nf = 0, np_ = 0, ns = 0;  // per wave (Cp is a multiple of 64: whole waves run each iteration)
     for (int c = tid; c < p.Cp; c += T) {
         const int t = s.type[c];
-        nf += t == RL_FOOD; np_ += t == RL_POISON; ns += t == kSuper;
+        nf += __popcll(__ballot(t == RL_FOOD)); np_ += __popcll(__ballot(t == RL_POISON)); ns += __popcll(__ballot(t == kSuper));
         const unsigned long long m = __ballot(t != RL_EMPTY);
         const unsigned long long ma = __ballot(t == RL_AGENT);
         if (lane_id() == 0) { s.occbits[c >> 6] = m; s.agbits[c >> 6] = ma; }
     }
-    if (nf) atomicAdd(&s.scal[S_NFOOD], nf);
-    if (np_) atomicAdd(&s.scal[S_NPOISON], np_);
-    if (ns) atomicAdd(&s.scal[S_NSUPER], ns);
+    if (lane_id() == 0) {
+        if (nf) atomicAdd(&s.scal[S_NFOOD], nf);
+        if (np_) atomicAdd(&s.scal[S_NPOISON], np_);
+        if (ns) atomicAdd(&s.scal[S_NSUPER], ns);
+    }
     lds_barrier();
     RL_MARK(6);
     if (tid >= 64 && tid < 128) scan_order_wave(p, s, tid - 64, S_N1);
@@ -1205,16 +1218,18 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
 
     if (MODE == MODE_FOOD) {
         // second half of a split step (_add_food with a host-drawn tape, then the observation pass, environment.py:185-186)
-        int nf = 0, np_ = 0, ns = 0;
+        int nf = 0, np_ = 0, ns = 0;  // per wave
         for (int c = tid; c < p.Cp; c += T) {
             const int t = s.type[c];
-            nf += t == RL_FOOD; np_ += t == RL_POISON; ns += t == kSuper;
+            nf += __popcll(__ballot(t == RL_FOOD)); np_ += __popcll(__ballot(t == RL_POISON)); ns += __popcll(__ballot(t == kSuper));
             const unsigned long long m = __ballot(t != RL_EMPTY);
             if (lane_id() == 0) s.occbits[c >> 6] = m;
         }
-        if (nf) atomicAdd(&s.scal[S_NFOOD], nf);
-        if (np_) atomicAdd(&s.scal[S_NPOISON], np_);
-        if (ns) atomicAdd(&s.scal[S_NSUPER], ns);
+        if (lane_id() == 0) {
+            if (nf) atomicAdd(&s.scal[S_NFOOD], nf);
+            if (np_) atomicAdd(&s.scal[S_NPOISON], np_);
+            if (ns) atomicAdd(&s.scal[S_NSUPER], ns);
+        }
         lds_barrier();
         if (tid < 64) {
             Placer P;
@@ -1287,8 +1302,11 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
                 if (!p.static_families) best_agents_wave(s, n1);  // _produce reads best_brain: same wave, program order
                 reproduce_wave0<T, LEAN>(p, s, w, n1, nslots);
             } else {
+                RL_MARK_T(43, 64); RL_MARK_T(48, 512); RL_MARK_T(51, 896);
                 write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n1, p.so.obs, tid - 64);
+                RL_MARK_T(44, 64); RL_MARK_T(49, 512); RL_MARK_T(52, 896);
                 step_outputs(tid - 64, T - 64);
+                RL_MARK_T(45, 64); RL_MARK_T(50, 512); RL_MARK_T(53, 896);
             }
         } else {
             if (!split) write_observations<T>(p, s, w, n1, p.so.obs);
@@ -1298,7 +1316,9 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
         if (!LEAN && p.so.trk_tick && tid < 64) track_world_wave0(p, s, w, n1);
         n_cur = n1;
         if (MODE == MODE_STEP) { store_world<T>(p, s, w, n1); return; }
+        RL_MARK_W(64);   // (tuning build: stamps need a 128-entry buffer)
         lds_barrier();
+        RL_MARK_W(80);
         // fused tick: agents keep their LDS slot; remember their post-step list index for uo.src (newborns carry -1)
         for (int a = tid; a < nslots; a += T) s.src[a] = s.newidx[a];
         if (!overlapped) lds_barrier();  // (overlapped: this loop shares the interval of the update's first sweep below)
@@ -1341,7 +1361,11 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
         if (LEAN && MODE == MODE_TICK && T > 64 && p.lists && !RL_ABL(128)) {
             // wave 0 reserves and fills the per-brain row lists (an atomic round trip) while the others write the rows
             if (tid < 64) emit_brain_lists_wave0(p, w, n2, [&](int k) { return s.brain[s.order[k]]; });
-            else write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n2, p.uo.obs, tid - 64);
+            else {
+                RL_MARK_T(46, 64);
+                write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n2, p.uo.obs, tid - 64);
+                RL_MARK_T(47, 64);
+            }
         } else {
             write_observations<T>(p, s, w, n2, p.uo.obs);
             if (p.lists && tid < 64 && !RL_ABL(128)) emit_brain_lists_wave0(p, w, n2, [&](int k) { return s.brain[s.order[k]]; });
