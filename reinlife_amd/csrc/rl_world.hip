@@ -23,6 +23,7 @@
 #include "rl_common.h"
 
 int rl_world_prepare_bytes(size_t bytes);
+size_t rl_world_smem_bytes(int cpad, int cap, int hash);
 static int g_ablate = 0;  // tuning only
 extern "C" void rl_debug_set_ablate(int mask) { g_ablate = mask; }
 
@@ -306,10 +307,18 @@ __device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
     // the loaded values -- and with them a wait -- into itself
     const bool ha = tid < p.cap;
     const int ti = ha ? tid : p.cap - 1;
-    const uint8_t r_i = g_i[ti], r_j = g_j[ti], r_fl = g_fl[ti];
-    const signed char r_act = g_act[ti];
-    const int r_h = g_h[ti], r_age = g_age[ti], r_ma = g_ma[ti], r_g = g_g[ti], r_b = g_b[ti], r_u = g_u[ti];
-    const double r_f = g_f[ti];
+    // (waves whose slots all lie beyond the allocation skip the agent loads -- a wave-uniform branch: their eleven load
+    // instructions would only queue in front of the useful ones of the last waves)
+    uint8_t r_i = 0, r_j = 0, r_fl = 0;
+    signed char r_act = 0;
+    int r_h = 0, r_age = 0, r_ma = 0, r_g = 0, r_b = 0, r_u = 0;
+    double r_f = 0.0;
+    if (__builtin_amdgcn_readfirstlane(tid) < p.cap) {
+        r_i = g_i[ti]; r_j = g_j[ti]; r_fl = g_fl[ti];
+        r_act = g_act[ti];
+        r_h = g_h[ti]; r_age = g_age[ti]; r_ma = g_ma[ti]; r_g = g_g[ti]; r_b = g_b[ti]; r_u = g_u[ti];
+        r_f = g_f[ti];
+    }
     const int sc_val = tid == S_TICK ? v_tick : tid == S_EPOCH ? v_epoch : tid == S_NEXT_UID ? v_uid : tid == S_MAX_GENE ? v_mg : 0;
     __builtin_amdgcn_sched_barrier(0);  // keep every use of a loaded value below the LDS initialisation (the compiler hoisted
                                         // a shift of r_j up here, i.e. a wait for the loads right after issuing them)
@@ -514,23 +523,28 @@ __device__ inline DrawCache draw_cache(const KParams& p, Smem& s)
     return c;
 }
 template <int T>
-__device__ inline void precompute_draws(const KParams& p, Smem& s, int w)
+__device__ inline void precompute_draws(const KParams& p, Smem& s, int w, int n0)
 {
+    // One Philox block per item and ONE call site: item -> (site, index) first.  (Separate calls per kind made a wave that
+    // held items of three kinds run three blocks back to back -- the longest path of the first agent phase.)  Gate ranks are
+    // positions among the eligible agents of the post-step list, so only ranks < n0 can be asked for.  Items are dealt
+    // from the top thread down: the low waves carry the agents.
     const DrawCache c = draw_cache(p, s);
     const uint32_t epoch = (uint32_t)s.scal[S_EPOCH], tick = (uint32_t)s.scal[S_TICK], world = (uint32_t)(p.world_base + w);
-    for (int item = (int)threadIdx.x - T / 2; item < 128 + c.n_gate; item += T / 2) {
-        if (item < 0) break;
-        if (item < RL_FOOD_TRIES) {
-            const rl_u4 r = rl_philox4x32(p.seed, epoch, world, tick, RL_SITE_FOOD, (uint32_t)item);
-            c.w[item] = r.x; c.w[8 + item] = r.y;
-        } else if (item == 16) {
-            const rl_u4 r = rl_philox4x32(p.seed, epoch, world, tick, RL_SITE_PRODUCE, 0u);
-            c.w[16] = r.x; c.w[17] = r.y;
-        } else if (item >= 32 && item < 96) {
-            c.w[item] = rl_philox4x32(p.seed, epoch, world, tick, RL_SITE_BIRTH, (uint32_t)(item - 32)).x;
-        } else if (item >= 128) {
-            c.w[item] = rl_philox4x32(p.seed, epoch, world, tick, RL_SITE_REPRO, (uint32_t)(item - 128)).x;
-        }
+    constexpr int kFirst = T > 128 ? 128 : T / 2;  // threads below stay out of it
+    const int n_items = 128 + min(c.n_gate, n0);
+    if ((int)threadIdx.x < kFirst) return;
+    for (int item = T - 1 - (int)threadIdx.x; item < n_items; item += T - kFirst) {
+        uint32_t site, idx;
+        if (item < RL_FOOD_TRIES) { site = RL_SITE_FOOD; idx = (uint32_t)item; }
+        else if (item == 16) { site = RL_SITE_PRODUCE; idx = 0u; }
+        else if (item >= 32 && item < 96) { site = RL_SITE_BIRTH; idx = (uint32_t)(item - 32); }
+        else if (item >= 128) { site = RL_SITE_REPRO; idx = (uint32_t)(item - 128); }
+        else continue;
+        const rl_u4 r = rl_philox4x32(p.seed, epoch, world, tick, site, idx);
+        c.w[item] = r.x;
+        if (item < RL_FOOD_TRIES) c.w[8 + item] = r.y;
+        else if (item == 16) c.w[17] = r.y;
     }
 }
 
@@ -576,7 +590,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
         s.tgt[a] = (unsigned short)tg;
         atomicAdd(&cnt[tg], 1u);
     }
-    if (LEAN && tid >= T / 2) precompute_draws<T>(p, s, w);
+    if (LEAN) precompute_draws<T>(p, s, w, n0);
     lds_barrier();
     RL_MARK(2);
     // ---- _execute_movement: Jacobi fixed point (environment.py:637-644) --------------------------------------------
@@ -1179,7 +1193,12 @@ enum { MODE_STEP = 0, MODE_UPDATE = 1, MODE_TICK = 2, MODE_OBSERVE = 3, MODE_FOO
 
 // LEAN = performance path: no recorded tape, no tracker, no capture outputs (their pointers are known to be null), which
 // lets the compiler drop those parameters and branches (SGPR pressure: the full kernel keeps ~45 pointers alive)
-template <int T, int MODE, bool LEAN>
+// FIXED: the LDS layout is carved with compile-time bounds (kFixCp cells, kFixCap slots, kFixHash table entries) instead
+// of the world's own sizes, so every LDS array base is an immediate.  With run-time sizes the ~35 bases do not fit in
+// SGPRs next to everything else and the compiler RE-DERIVES them (an s_add/s_and chain of ~70 scalar instructions) at the
+// top of most barrier intervals -- a few hundred cycles, twenty-odd times per tick.
+constexpr int kFixCp = 960, kFixCap = 256, kFixHash = 512;  // the 30x30 / 100-agent shape: 37,024 bytes, four workgroups per CU
+template <int T, int MODE, bool LEAN, bool FIXED = false>
 __global__ __launch_bounds__(T) void k_world(const KParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1200,7 +1219,8 @@ __global__ __launch_bounds__(T) void k_world(const KParams p)
         static_assert(sizeof(KParams) >= 0x1c0 + 4 && sizeof(KParams) <= 0x200, "the warm-up loads must cover the argument block");
     }
     Smem s;
-    carve(s, smem_raw, p.Cp, p.cap, p.hash_size);
+    if (FIXED) carve(s, smem_raw, kFixCp, kFixCap, kFixHash);
+    else carve(s, smem_raw, p.Cp, p.cap, p.hash_size);
     const int w = blockIdx.x;
     const int tid = threadIdx.x;
     int n0;
@@ -1542,12 +1562,20 @@ template <int MODE, bool LEAN>
 int launch_world_v(const rl_world* h, const KParams& p, hipStream_t stream)
 {
     const int blk = pick_block(h);
-    if (blk == 1024)
-        hipLaunchKernelGGL((k_world<1024, MODE, LEAN>), dim3(h->cfg.n_worlds), dim3(1024), h->smem_bytes, stream, p);
+    static const size_t fixed_bytes = rl_world_smem_bytes(kFixCp, kFixCap, kFixHash);  // inside the default 64 KB window
+    const bool fixed = LEAN && MODE == MODE_TICK && p.Cp <= kFixCp && p.cap <= kFixCap && p.hash_size <= kFixHash &&
+                       fixed_bytes <= 64 * 1024 && !getenv("RL_WORLD_DYNAMIC_LDS");  // (env: tuning A/B)
+    const dim3 grid(h->cfg.n_worlds);
+    if (fixed) {
+        if (blk == 1024) hipLaunchKernelGGL((k_world<1024, MODE_TICK, true, true>), grid, dim3(1024), fixed_bytes, stream, p);
+        else if (blk == 512) hipLaunchKernelGGL((k_world<512, MODE_TICK, true, true>), grid, dim3(512), fixed_bytes, stream, p);
+        else hipLaunchKernelGGL((k_world<256, MODE_TICK, true, true>), grid, dim3(256), fixed_bytes, stream, p);
+    } else if (blk == 1024)
+        hipLaunchKernelGGL((k_world<1024, MODE, LEAN>), grid, dim3(1024), h->smem_bytes, stream, p);
     else if (blk == 512)
-        hipLaunchKernelGGL((k_world<512, MODE, LEAN>), dim3(h->cfg.n_worlds), dim3(512), h->smem_bytes, stream, p);
+        hipLaunchKernelGGL((k_world<512, MODE, LEAN>), grid, dim3(512), h->smem_bytes, stream, p);
     else
-        hipLaunchKernelGGL((k_world<256, MODE, LEAN>), dim3(h->cfg.n_worlds), dim3(256), h->smem_bytes, stream, p);
+        hipLaunchKernelGGL((k_world<256, MODE, LEAN>), grid, dim3(256), h->smem_bytes, stream, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rl_set_error("world kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
     return RL_OK;
