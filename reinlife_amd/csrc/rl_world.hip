@@ -1193,14 +1193,27 @@ enum { MODE_STEP = 0, MODE_UPDATE = 1, MODE_TICK = 2, MODE_OBSERVE = 3, MODE_FOO
 
 // LEAN = performance path: no recorded tape, no tracker, no capture outputs (their pointers are known to be null), which
 // lets the compiler drop those parameters and branches (SGPR pressure: the full kernel keeps ~45 pointers alive)
-// FIXED: the LDS layout is carved with compile-time bounds (kFixCp cells, kFixCap slots, kFixHash table entries) instead
-// of the world's own sizes, so every LDS array base is an immediate.  With run-time sizes the ~35 bases do not fit in
-// SGPRs next to everything else and the compiler RE-DERIVES them (an s_add/s_and chain of ~70 scalar instructions) at the
-// top of most barrier intervals -- a few hundred cycles, twenty-odd times per tick.
-constexpr int kFixCp = 960, kFixCap = 256, kFixHash = 512;  // the 30x30 / 100-agent shape: 37,024 bytes, four workgroups per CU
+// FIXED: the kernel is specialised for ONE world shape -- the reference's default, trainer(width=30, height=30,
+// max_agents=100) -- and the host picks it when the handle has exactly that shape (any other shape runs the generic code).
+// Two things come from it:
+//  * the LDS layout is carved from constants, so every array base is an immediate.  With run-time sizes the ~35 bases do
+//    not fit in SGPRs next to everything else and the compiler RE-DERIVES them (an s_add/s_and chain of ~70 scalar
+//    instructions) at the top of most barrier intervals -- a few hundred cycles, twenty-odd times per tick;
+//  * width, height, the padded cell count and the slot capacity fold into the address arithmetic (no run-time division by
+//    the width, single-trip cell loops, constant window wrap): another ~1,100 instructions and 28 VGPRs less.
+constexpr int kFixW = 30, kFixH = 30, kFixMaxAgents = 100;
+constexpr int kFixC = kFixW * kFixH, kFixCp = (kFixC + 63) & ~63;
+constexpr int kFixCap = ((2 * kFixMaxAgents + 2 + 63) / 64) * 64;   // 256: births can overshoot max_agents up to 2n+1
+constexpr int kFixHash = 512;                                       // rl_create: the power of two >= 2 * slot_cap
+static_assert(kFixHash >= 2 * kFixCap && kFixHash / 2 < 2 * kFixCap, "hash size rule of rl_create");
 template <int T, int MODE, bool LEAN, bool FIXED = false>
-__global__ __launch_bounds__(T) void k_world(const KParams p)
+__global__ __launch_bounds__(T) void k_world(const KParams p_in)
 {
+    KParams p = p_in;
+    if (FIXED) {
+        p.W = kFixW; p.H = kFixH; p.C = kFixC; p.Cp = kFixCp; p.nW = kFixCp / 64;
+        p.cap = kFixCap; p.hash_size = kFixHash; p.hash_mask = kFixHash - 1;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 #ifdef RL_PHASE_PROFILE
     unsigned long long t_entry;  // before the first kernel-argument access
@@ -1563,8 +1576,8 @@ int launch_world_v(const rl_world* h, const KParams& p, hipStream_t stream)
 {
     const int blk = pick_block(h);
     static const size_t fixed_bytes = rl_world_smem_bytes(kFixCp, kFixCap, kFixHash);  // inside the default 64 KB window
-    const bool fixed = LEAN && MODE == MODE_TICK && p.Cp <= kFixCp && p.cap <= kFixCap && p.hash_size <= kFixHash &&
-                       fixed_bytes <= 64 * 1024 && !getenv("RL_WORLD_DYNAMIC_LDS");  // (env: tuning A/B)
+    const bool fixed = LEAN && MODE == MODE_TICK && p.W == kFixW && p.H == kFixH && p.cap == kFixCap && p.hash_size == kFixHash &&
+                       fixed_bytes <= 64 * 1024 && !getenv("RL_WORLD_GENERIC");  // (env: run the generic code -- tests, A/B)
     const dim3 grid(h->cfg.n_worlds);
     if (fixed) {
         if (blk == 1024) hipLaunchKernelGGL((k_world<1024, MODE_TICK, true, true>), grid, dim3(1024), fixed_bytes, stream, p);

@@ -115,6 +115,57 @@ def test_hip_fused_tick_refill_matches_oracle():
     assert refills > 20 and int(hb.dw.refill_count.item()) == refills
 
 
+@pytest.mark.parametrize("static", [True, False], ids=["static", "nonstatic"])
+@pytest.mark.parametrize("generic", [False, True], ids=["specialised", "generic"])
+def test_hip_lean_tick_matches_oracle(static, generic, monkeypatch):
+    """The launch bench.py times: the lean fused tick (no tape, no tracker, no capture outputs) on the reference's default
+    30x30 / 100-agent shape -- the shape-specialised kernel and, with RL_WORLD_GENERIC set, the generic code for the same
+    worlds -- against the oracle: state, rewards, done flags, both permutations and both observation passes, every tick."""
+    from oracle import oracle as orc
+    from reinlife_amd.worlds import DeviceWorlds
+    if generic:
+        monkeypatch.setenv("RL_WORLD_GENERIC", "1")   # read by the library at every launch
+    else:
+        monkeypatch.delenv("RL_WORLD_GENERIC", raising=False)
+    R = 32
+    cfg = dict(width=30, height=30, max_agents=100, n_brains=2, static_families=static, limit_reproduction=False,
+               incentivize_killing=True)
+    dw = DeviceWorlds(n_worlds=R, seed=777, world_base=64, **cfg)
+    assert dw.cap == 256
+
+    class _HB:  # the attribute _compare_states reads
+        pass
+    hb = _HB(); hb.dw = dw
+    ow = orc.OracleWorlds(n_worlds=R, seed=777, world_base=64, **cfg)
+    dw.reset_synthetic(100); ow.reset_synthetic(100)
+    rng = np.random.RandomState(17)
+    refills = 0
+    for t in range(70):
+        acts = rng.randint(0, 8, size=(R, dw.cap)).astype(np.int8)
+        n0 = ow.s["n_agents"].copy()
+        ow.step(acts)
+        n1 = ow.s["n_agents"].copy()
+        want = {k: getattr(ow, k).copy() for k in ("reward", "done", "src1", "obs1")}
+        ow.update()
+        want_src2 = ow.src2.copy(); n2 = ow.s["n_agents"].copy(); epoch = ow.s["epoch"].copy()
+        refills += ow.refill(70, 100)
+        dw.set_actions(acts)
+        dw.tick_refill(70, 100)
+        dw.check_error_flag()
+        assert np.array_equal(dw.n_acted.cpu().numpy(), n0)
+        _compare_rows(dw.reward.cpu().numpy(), want["reward"], n1, "tick %d reward" % t)
+        _compare_rows(dw.done.cpu().numpy(), want["done"], n1, "tick %d done" % t)
+        _compare_rows(dw.src1.cpu().numpy(), want["src1"], n1, "tick %d src1" % t)
+        _compare_rows(dw.obs_state_prime().cpu().numpy(), want["obs1"], n1, "tick %d obs1" % t)
+        _compare_states(hb, ow, "tick %d" % t)
+        _compare_rows(dw.obs_state().cpu().numpy(), ow.obs2, ow.s["n_agents"], "tick %d obs2" % t)
+        keep = ow.s["epoch"] == epoch   # (a refilled world has a fresh list: its update permutation is not defined)
+        got_src2 = dw.src2.cpu().numpy()
+        for w in np.nonzero(keep)[0]:
+            assert np.array_equal(got_src2[w, : n2[w]], want_src2[w, : n2[w]]), "tick %d src2 world %d" % (t, w)
+    assert refills > 5
+
+
 def test_hip_small_and_rect_grids_match_oracle():
     from hip_backend import HipBackend
     from oracle import oracle as orc
