@@ -165,8 +165,9 @@ constexpr int kXsUnits = kPlanes * kXPlane;
 // per load instruction, four times over).  Every row gets its power-of-two scale here (row maximum by DPP); 1 / scale
 // goes to row_unscale[row] for the input layer's epilogue.
 // `row_of_lane`: observation row id of tile row (lane & 31).
+template <typename WHILE_IN_FLIGHT>
 __device__ inline void stage_x(f32x4* __restrict__ xs, float* __restrict__ row_unscale, const float* __restrict__ obs,
-                               int64_t row_of_lane, int lane, int v)
+                               int64_t row_of_lane, int lane, int v, WHILE_IN_FLIGHT&& while_in_flight)
 {
     const int lo = (int)(row_of_lane & 0xffffffff), hi = (int)(row_of_lane >> 32);
     f32x2* x2 = (f32x2*)xs;
@@ -184,6 +185,8 @@ __device__ inline void stage_x(f32x4* __restrict__ xs, float* __restrict__ row_u
         val[rr] = *(const f32x4u*)(obs + r * RL_OBS_DIM + off);
 #endif
     }
+    __builtin_amdgcn_sched_barrier(0);
+    while_in_flight();  // independent work for the HBM round trip of the rows (the action draw)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
@@ -253,10 +256,22 @@ struct WRing {
     }
 };
 
+// The 32 epilogue constants of one output tile (see epilogue_tile): tile t2, half h -> [unscale 16 | bias 16].
+struct EpiConsts {
+    f32x4 un[4], bi[4];
+    __device__ inline void start(gfloat* __restrict__ consts, int t2, int half)
+    {
+        gf32x4* c = (gf32x4*)(consts + (t2 * 2 + half) * 32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { un[q] = c[q]; bi[q] = c[4 + q]; }
+    }
+};
+
 // K loop of one layer: B fragments from LDS planes `bsrc` (unit stride `bstep` per chunk, plane stride `bplane`), A
 // fragments from the ring.  Leaves acc[t] = sum hi.hi + hi.lo + lo.hi, still in the scaled domain.
 template <int NS, int TOUT, int NT, int TSTRIDE, int D>
-__device__ inline void k_loop(WRing<TOUT, NT, TSTRIDE, D>& w, const f32x4* __restrict__ bsrc, int bplane, int bstep, f32x16 (&acc)[NT])
+__device__ inline void k_loop(WRing<TOUT, NT, TSTRIDE, D>& w, const f32x4* __restrict__ bsrc, int bplane, int bstep, f32x16 (&acc)[NT],
+                              EpiConsts* epi = nullptr, gfloat* __restrict__ epi_consts = nullptr, int epi_t2 = 0, int epi_half = 0)
 {
     f32x16 cross[NT];  // second accumulator chain: also keeps consecutive MFMAs of one wave independent
 #pragma unroll
@@ -278,6 +293,9 @@ __device__ inline void k_loop(WRing<TOUT, NT, TSTRIDE, D>& w, const f32x4* __res
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) mfma3(ac[t], bc, acc[t], cross[t]);
+        // the layer's epilogue constants are requested four steps before the end: by then the ring has stopped asking for
+        // chunks and its registers are draining (asked for before the loop they cost spills; at their use site an L2 trip)
+        if (epi && s == (NS > 4 ? NS - 4 : 0)) epi->start(epi_consts, epi_t2, epi_half);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -287,20 +305,27 @@ __device__ inline void k_loop(WRing<TOUT, NT, TSTRIDE, D>& w, const f32x4* __res
 }
 
 // layer epilogue of one output tile: back to the unscaled domain, bias, optional ReLU.
-// consts = the layer's epilogue block (behind its fragments): tile t2, half h -> [unscale 16 | bias 16] in register order
+// consts = the layer's epilogue block (behind its fragments): tile t2, half h -> [unscale 16 | bias 16] in register order.
+// The 32 constants are REQUESTED before the layer's K loop (EpiConsts::start) and only consumed here: read at their use
+// site they put an L2 round trip on the tile's dependency chain after every layer.
 template <bool RELU>
-__device__ inline void epilogue_tile(f32x16& h, gfloat* __restrict__ consts, int t2, int half, float row_un)
+__device__ inline void epilogue_tile(f32x16& h, const EpiConsts& k, float row_un)
 {
-    gf32x4* c = (gf32x4*)(consts + (t2 * 2 + half) * 32);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 un = c[q], bi = c[4 + q];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float y = __builtin_fmaf(h[4 * q + e], un[e] * row_un, bi[e]);
+            const float y = __builtin_fmaf(h[4 * q + e], k.un[q][e] * row_un, k.bi[q][e]);
             h[4 * q + e] = RELU ? fmaxf(y, 0.0f) : y;
         }
     }
+}
+template <bool RELU>
+__device__ inline void epilogue_tile(f32x16& h, gfloat* __restrict__ consts, int t2, int half, float row_un)
+{
+    EpiConsts k;
+    k.start(consts, t2, half);
+    epilogue_tile<RELU>(h, k, row_un);
 }
 
 __device__ inline float reg_max(const f32x16& h)
@@ -393,7 +418,7 @@ struct TileIO {
 };
 
 #ifdef RL_PHASE_PROFILE
-#define RL_PMARK(i) do { if (io.prof && threadIdx.x == 0) io.prof[48 + (i)] = (long long)clock64(); } while (0)
+#define RL_PMARK(i) do { if (io.prof && threadIdx.x == 0) io.prof[100 + (i)] = (long long)clock64(); } while (0)
 #else
 #define RL_PMARK(i) do { } while (0)
 #endif
@@ -426,6 +451,16 @@ __device__ inline void policy_tile(const TileIO& io, f32x4* __restrict__ lds_h, 
     constexpr int HID_TILES = KIND == RL_PPO ? 8 : 4;
     constexpr int PS = HID_TILES * 2 * 64;  // units per plane of the published activations
     const int h = lane >> 5, j = lane & 31;
+    f32x4 duel_ba0 = {0.0f, 0.0f, 0.0f, 0.0f}, duel_ba1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    float duel_bv = 0.0f;
+    // the action draw of tile row j depends only on the row's key: wave 0 computes it while the observation rows are in flight
+    // (inside stage_x, between the loads and their first use)
+    // (not in the 128-register dueling variant: 13 more live registers spill there)
+    constexpr bool EARLY = DEEP || KIND == RL_DQN || KIND == RL_PPO;
+    rl_u4 draw = {0u, 0u, 0u, 0u};
+    auto early_draw = [&]() {
+        if (EARLY && v == 0 && io.actions) draw = rl_philox4x32(io.seed, io.key_epoch, io.key_world, io.key_tick, RL_SITE_ACT, io.key_index);
+    };
     const Layout L = layout_of(KIND);
     gfloat* __restrict__ packed = io.packed;
     const int xb = h * kXGroup + j;  // this lane's unit of chunk 0 in the observation planes
@@ -436,7 +471,7 @@ __device__ inline void policy_tile(const TileIO& io, f32x4* __restrict__ lds_h, 
         HeadW<1, 1> wh;
         float q4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         w1.start(packed + L.l1, lane, v);
-        stage_x(lds_h, lds_aux, io.obs, io.row, lane, v);
+        stage_x(lds_h, lds_aux, io.obs, io.row, lane, v, early_draw);
         lds_barrier();
         k_loop<kInChunks>(w1, lds_h + xb, kXPlane, 2 * kXGroup, h1);
         if (v < 2) { w2.start(packed + L.l2a, lane, v); wh.start(packed + L.ha, 2, lane, v); }
@@ -459,16 +494,25 @@ __device__ inline void policy_tile(const TileIO& io, f32x4* __restrict__ lds_h, 
         float adv[4], val[4];
         WRing<4, 1, 1, DEEP ? 5 : 3> w1, w2;
         HeadW<1, 1> wh;
+        EpiConsts e1, e2;
         w1.start(packed + L.l1, lane, v);
-        stage_x(lds_h, lds_aux, io.obs, io.row, lane, v);
+        if (EARLY && v == 0) {  // wave 0 finishes the tile: its head biases are asked for now, not after the last barrier
+            const gf32x4* ba = (const gf32x4*)(packed + L.ha + head_consts_off(4) + 8);
+            duel_ba0 = ba[0]; duel_ba1 = ba[1];
+            duel_bv = packed[L.hb + head_consts_off(4) + 8];
+        }
+        stage_x(lds_h, lds_aux, io.obs, io.row, lane, v, early_draw);
         lds_barrier();
         RL_PMARK(10);
-        k_loop<kInChunks>(w1, lds_h + xb, kXPlane, 2 * kXGroup, h1);
+        k_loop<kInChunks>(w1, lds_h + xb, kXPlane, 2 * kXGroup, h1, DEEP ? &e1 : nullptr, packed + L.l1 + frag_floats(kInChunks, 4), v, h);
         RL_PMARK(2);
         w2.start(packed + L.l2a, lane, v);
         wh.start(packed + L.ha, 4, lane, v);
         // relu(feature) feeds both branches (PERD3QN.py:200-201)
-        epilogue_tile<true>(h1[0], packed + L.l1 + frag_floats(kInChunks, 4), v, h, lds_aux[j]);
+        // (the DEEP variant has the registers to ask for the epilogue constants inside the K loop; the 128-register variant
+        // reads them here)
+        if (!DEEP) e1.start(packed + L.l1 + frag_floats(kInChunks, 4), v, h);
+        epilogue_tile<true>(h1[0], e1, lds_aux[j]);
         row_max_put(lds_aux, j, v * 2 + h, reg_max(h1[0]));
         lds_barrier();
         float sc1, un1;
@@ -476,16 +520,18 @@ __device__ inline void policy_tile(const TileIO& io, f32x4* __restrict__ lds_h, 
         publish_tile(lds_h, PS, v, lane, h1[0], sc1);
         lds_barrier();
         RL_PMARK(3);
-        k_loop<8>(w2, lds_h + lane, PS, 64, h2);
+        k_loop<8>(w2, lds_h + lane, PS, 64, h2, DEEP ? &e2 : nullptr, packed + L.l2a + frag_floats(8, 4), v, h);
         RL_PMARK(4);
         w1.start(packed + L.l2b, lane, v);  // the value branch's first chunks arrive while the advantage head runs
-        epilogue_tile<true>(h2[0], packed + L.l2a + frag_floats(8, 4), v, h, un1);
+        if (!DEEP) e2.start(packed + L.l2a + frag_floats(8, 4), v, h);
+        epilogue_tile<true>(h2[0], e2, un1);
         head_mfma(wh, h2, adv);
         wh.start(packed + L.hb, 4, lane, v);
         RL_PMARK(5);
-        k_loop<8>(w1, lds_h + lane, PS, 64, h2);
+        k_loop<8>(w1, lds_h + lane, PS, 64, h2, DEEP ? &e1 : nullptr, packed + L.l2b + frag_floats(8, 4), v, h);
         RL_PMARK(6);
-        epilogue_tile<true>(h2[0], packed + L.l2b + frag_floats(8, 4), v, h, un1);
+        if (!DEEP) e1.start(packed + L.l2b + frag_floats(8, 4), v, h);
+        epilogue_tile<true>(h2[0], e1, un1);
         head_mfma(wh, h2, val);
         RL_PMARK(7);
 #pragma unroll
@@ -497,7 +543,7 @@ __device__ inline void policy_tile(const TileIO& io, f32x4* __restrict__ lds_h, 
         WRing<8, 2, 4, 3> w1, w2;
         HeadW<2, 4> wh;
         w1.start(packed + L.l1, lane, v);   // tiles v and v+4
-        stage_x(lds_h, lds_aux, io.obs, io.row, lane, v);
+        stage_x(lds_h, lds_aux, io.obs, io.row, lane, v, early_draw);
         lds_barrier();
         k_loop<kInChunks>(w1, lds_h + xb, kXPlane, 2 * kXGroup, h1);
         w2.start(packed + L.l2a, lane, v);
@@ -528,8 +574,13 @@ __device__ inline void policy_tile(const TileIO& io, f32x4* __restrict__ lds_h, 
             sum9[i] = (i < 8 || KIND == RL_D3QN || KIND == RL_PERD3QN)
                           ? ((lds_part[0][j][i] + lds_part[1][j][i]) + lds_part[2][j][i]) + lds_part[3][j][i] : 0.0f;
         if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
-            gfloat* ba = packed + L.ha + head_consts_off(4) + 8;
-            const float bv = packed[L.hb + head_consts_off(4) + 8];
+            if (!EARLY) {
+                const gf32x4* bp = (const gf32x4*)(packed + L.ha + head_consts_off(4) + 8);
+                duel_ba0 = bp[0]; duel_ba1 = bp[1];
+                duel_bv = packed[L.hb + head_consts_off(4) + 8];
+            }
+            const float ba[8] = {duel_ba0.x, duel_ba0.y, duel_ba0.z, duel_ba0.w, duel_ba1.x, duel_ba1.y, duel_ba1.z, duel_ba1.w};
+            const float bv = duel_bv;
             float adv[8], mean = 0.0f;  // advantage.mean() of the [1,8] tensor == per-row mean when batched
 #pragma unroll
             for (int i = 0; i < 8; ++i) { adv[i] = sum9[i] + ba[i]; mean += adv[i]; }
@@ -558,7 +609,7 @@ __device__ inline void policy_tile(const TileIO& io, f32x4* __restrict__ lds_h, 
                 o[1] = f32x4{q[4], q[5], q[6], q[7]};
             }
             if (io.actions) {
-                const rl_u4 r = rl_philox4x32(io.seed, io.key_epoch, io.key_world, io.key_tick, RL_SITE_ACT, io.key_index);
+                const rl_u4 r = EARLY ? draw : rl_philox4x32(io.seed, io.key_epoch, io.key_world, io.key_tick, RL_SITE_ACT, io.key_index);
                 const float u = (float)rl_u24(r.x);
                 int a = 0;
                 if (KIND == RL_PPO) {  // Categorical(prob).sample() as inverse CDF

@@ -17,8 +17,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from reinlife_amd import _lib  # noqa: E402
 
-NAMES = ["entry -> rows known (counts, row list)", "input layer (weights, 80 MFMA)", "relu + publish + barrier",
-         "hidden adv (65 MFMA)", "head adv (VALU)", "hidden val (65 MFMA)", "head val", "partials + barrier",
+NAMES = ["entry -> rows known (counts, row list)", "observation rows staged (HBM reads, scale, split, barrier)",
+         "input layer (30 MFMA)", "relu + row maxima + publish + 2 barriers", "hidden adv (24 MFMA)", "epilogue + head adv (6 MFMA)",
+         "hidden val (24 MFMA)", "epilogue + head val (6 MFMA)", "partials + barrier",
          "epilogue (wave 0: dueling, argmax, Philox, store)"]
 
 
@@ -28,7 +29,7 @@ def main():
     a = ap.parse_args()
     args = argparse.Namespace(worlds=a.worlds, workload="c4", seed=1)
     dw = bench.make_worlds(args, 0, "cuda:0")
-    stamps = torch.zeros(64, dtype=torch.int64, device="cuda:0")
+    stamps = torch.zeros(128, dtype=torch.int64, device="cuda:0")
     lib = _lib.lib()
     for blocks in (0, 150, 330):
         acc, ends = [], []
@@ -38,8 +39,9 @@ def main():
             dw.act()
             dw.tick_refill(70, 100)
             torch.cuda.synchronize()
-            st = stamps.cpu().numpy()[48:58]
-            if t >= 10 and st[0] and st[9]:
+            raw = stamps.cpu().numpy()
+            st = np.concatenate([raw[100:102], raw[110:111], raw[102:110]])  # entry, rows known, staged (mark 10), marks 2..9
+            if t >= 10 and st.all():
                 acc.append(np.diff(st))
         m = np.mean(acc, axis=0)
         print("policy workgroup %d (wave 0), mean of %d launches, total %.0f cycles" % (blocks, len(acc), m.sum()))
