@@ -115,9 +115,10 @@ def test_hip_fused_tick_refill_matches_oracle():
     assert refills > 20 and int(hb.dw.refill_count.item()) == refills
 
 
-@pytest.mark.parametrize("static", [True, False], ids=["static", "nonstatic"])
+@pytest.mark.parametrize("static,limit,incentive", [(True, False, True), (False, False, True), (True, True, True), (False, True, False)],
+                         ids=["static", "nonstatic", "static-limit", "nonstatic-limit-noincentive"])
 @pytest.mark.parametrize("generic", [False, True], ids=["specialised", "generic"])
-def test_hip_lean_tick_matches_oracle(static, generic, monkeypatch):
+def test_hip_lean_tick_matches_oracle(static, limit, incentive, generic, monkeypatch):
     """The launch bench.py times: the lean fused tick (no tape, no tracker, no capture outputs) on the reference's default
     30x30 / 100-agent shape -- the shape-specialised kernel and, with RL_WORLD_GENERIC set, the generic code for the same
     worlds -- against the oracle: state, rewards, done flags, both permutations and both observation passes, every tick."""
@@ -128,8 +129,8 @@ def test_hip_lean_tick_matches_oracle(static, generic, monkeypatch):
     else:
         monkeypatch.delenv("RL_WORLD_GENERIC", raising=False)
     R = 32
-    cfg = dict(width=30, height=30, max_agents=100, n_brains=2, static_families=static, limit_reproduction=False,
-               incentivize_killing=True)
+    cfg = dict(width=30, height=30, max_agents=100, n_brains=2, static_families=static, limit_reproduction=limit,
+               incentivize_killing=incentive)
     dw = DeviceWorlds(n_worlds=R, seed=777, world_base=64, **cfg)
     assert dw.cap == 256
 
