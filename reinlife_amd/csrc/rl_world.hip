@@ -856,11 +856,16 @@ __device__ void reproduce_wave0(const KParams& p, Smem& s, int w, int n1, int ns
         if (tid == 0) { s.tgt[slots] = (unsigned short)cell; s.gene[slots] = gene; s.brain[slots] = brain; }
         ++slots;
     };
+    // the parents' gene / brain are fetched by one lane each up front (two LDS trips in all, not two per birth on the
+    // serial path); newborn slots lie behind every parent slot, so parking the newborns' data cannot alias them
+    int par_gene = 0, par_brain = 0;
+    if (tid < npar) { const int par = s.plist[tid]; par_gene = s.gene[par]; par_brain = s.brain[par]; }
     for (int b = 0; b < npar; ++b) {
         if (P.n_empty <= 0) continue;  // full grid: randint raises, no draw, no offspring (grid.py:82-83)
-        const int par = s.plist[b];
-        const int g = s.gene[par];
-        place_birth(g, p.static_families ? g : s.brain[par], b);
+        int g, br;
+        if (b < 64) { g = read_lane(par_gene, b); br = read_lane(par_brain, b); }
+        else { const int par = s.plist[b]; g = s.gene[par]; br = s.brain[par]; }
+        place_birth(g, p.static_families ? g : br, b);
     }
     RL_MARK(41);
     // _produce
