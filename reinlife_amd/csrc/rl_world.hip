@@ -34,7 +34,7 @@ constexpr uint8_t kPadCell = 0xFF;  // grid padding up to a multiple of 64 cells
 
 // scalar slots in LDS
 enum { S_ALIVE = 0, S_NFOOD, S_NPOISON, S_NSUPER, S_NSLOTS, S_N1, S_N2, S_NPARENTS, S_NELIG, S_BESTK, S_ERR, S_TICK, S_EPOCH,
-       S_NEXT_UID, S_MAX_GENE, S_ANYFLAG0, S_ANYFLAG1, S_NPLACED, S_COUNT = 24 };
+       S_NEXT_UID, S_MAX_GENE, S_ANYFLAG0, S_ANYFLAG1, S_NPLACED, S_SPEC_NF, S_SPEC_NP, S_SPEC_DONE, S_COUNT = 24 };
 
 struct KParams {
     int W, H, C, Cp, nW;
@@ -83,6 +83,7 @@ struct Smem {
     double *fitness, *reward, *trk_rew;                // [cap]
     unsigned short *pos, *tgt, *hslot;                 // [cap]
     short *newidx, *order, *src, *plist;               // [cap]
+    unsigned short* spec;         // [Cp]  a refill generated ahead of time: cell type | gene << 8 (spec_refill_stage)
     uint8_t *flags, *aux;                              // [cap]
     signed char* action;                               // [cap]
 };
@@ -139,6 +140,7 @@ __host__ __device__ inline size_t carve(Smem& s, char* base, int Cp, int cap, in
     CARVE(order, short, cap)
     CARVE(src, short, cap)
     CARVE(plist, short, cap)
+    CARVE(spec, unsigned short, Cp)
     CARVE(type, uint8_t, Cp)
     CARVE(flags, uint8_t, cap)
     CARVE(aux, uint8_t, cap)
@@ -274,10 +276,155 @@ __device__ inline void flag_error(const KParams& p, Smem& s, int code, int w, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Speculative refill.  A launch lasts as long as its slowest world, and with the refill-below-threshold rule a dozen of
+// the 256 worlds regenerate themselves in every tick: ~8,000 cycles of generator (one Philox block per cell + a counting
+// sort, nine barrier intervals) on top of a full tick.  But the new world depends only on (seed, epoch + 1, world), not on
+// the state -- so a world whose population is close to the threshold lets its IDLE waves (2..15; the agents live on waves 0
+// and 1) run the generator -- the Philox blocks while load_world waits for HBM, the counting sort in four existing barrier
+// intervals of the step phase -- into scratch that is free there
+// (keys = the gene plane, sorted keys = the health plane, bucket counters = the reward array, cleared by load_world), and
+// parks the result in s.spec[cell] = type | gene << 8.  If the refill then happens, apply_spec_refill only unpacks it
+// (two barrier intervals, no Philox); if the world was not prepared, the in-line generator runs as before.
+// Same rule, same arithmetic as reset_world_lds: both are checked against the oracle.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSpecFirst = 128;   // first thread that takes part (waves 0 and 1 carry the agents)
+constexpr int kSpecMargin = 40;   // worlds with fewer than threshold + margin agents prepare a refill
+__device__ inline bool spec_refill_wanted(const KParams& p, int n0, int& lg)
+{
+    lg = 6;
+    while ((2 << lg) <= p.Cp) ++lg;  // NB = largest power of two <= Cp (reset_world_lds)
+    return p.refill_threshold >= 0 && n0 < p.refill_threshold + kSpecMargin && n0 <= kSpecFirst && (1 << lg) <= 2 * p.cap;
+}
+struct SpecState {
+    bool on;     // this world prepares a refill in this tick (uniform per workgroup)
+    int lg;      // log2 of the bucket count
+    int nf, np;  // this WAVE's food / poison coins (spec_refill_keys)
+};
+// The Philox block of every cell (key, coins, gene): runs inside load_world, while the world's loads are in flight.
+template <int T>
+__device__ inline void spec_refill_keys(const KParams& p, Smem& s, int w, uint32_t epoch, SpecState& st)
+{
+    const int tid = threadIdx.x;
+    st.nf = st.np = 0;
+    if (tid < kSpecFirst) return;
+    const int sp = tid - kSpecFirst;
+    constexpr int NS = T - kSpecFirst;
+    unsigned* keys = (unsigned*)s.genev;
+    for (int c = sp; c < p.Cp; c += NS) {   // (whole waves per iteration: NS and Cp are multiples of 64)
+        bool f = false, q = false;
+        if (c < p.C) {
+            const rl_u4 r = rl_philox4x32(p.seed, epoch, (uint32_t)(p.world_base + w), 0u, RL_SITE_RESET_AGENT, (uint32_t)c);
+            keys[c] = (r.x & ~0xFFFu) | (unsigned)c;
+            f = rl_u24(r.z) < 0.1; q = rl_u24(r.w) < 0.05;
+            s.spec[c] = (unsigned short)(rl_mulhi(r.y, (unsigned)p.n_brains) << 8);  // the gene, should the cell get an agent
+        }
+        st.nf += __popcll(__ballot(f)); st.np += __popcll(__ballot(q));
+    }
+}
+// stage 0: histogram, 1: scan (one wave), 2: scatter, 3: rank + classify.  One barrier between stages.
+template <int T>
+__device__ inline void spec_refill_stage(const KParams& p, Smem& s, int w, const SpecState& st, int stage)
+{
+    const int tid = threadIdx.x;
+    const int lg = st.lg;
+    if (tid < kSpecFirst) return;
+    const int sp = tid - kSpecFirst;
+    constexpr int NS = T - kSpecFirst;
+    unsigned* keys = (unsigned*)s.genev;
+    unsigned* cum = (unsigned*)s.reward;
+    unsigned* sorted = (unsigned*)s.healthv;
+    const int NB = 1 << lg, sh = 32 - lg;
+    if (stage == 0) {   // histogram of the key prefixes + the coin counts of spec_refill_keys
+        for (int c = sp; c < p.C; c += NS) atomicAdd(&cum[keys[c] >> sh], 1u);
+        if (lane_id() == 0) {
+            if (st.nf) atomicAdd(&s.scal[S_SPEC_NF], st.nf);
+            if (st.np) atomicAdd(&s.scal[S_SPEC_NP], st.np);
+        }
+    } else if (stage == 1) {
+        if (sp < 64) {  // exclusive scan of the NB bucket counts by one wave: lane l owns NB/64 consecutive buckets
+            const int per = NB >> 6, b0 = sp * per;
+            unsigned local = 0;
+            for (int i = 0; i < per; ++i) local += cum[b0 + i];
+            unsigned base = (unsigned)(wave_incl_scan((int)local) - (int)local);
+            for (int i = 0; i < per; ++i) { const unsigned c = cum[b0 + i]; cum[b0 + i] = base; base += c; }
+        }
+    } else if (stage == 2) {
+        for (int c = sp; c < p.C; c += NS) {
+            const unsigned key = keys[c];
+            sorted[atomicAdd(&cum[key >> sh], 1u)] = key;  // afterwards cum[b] = END of bucket b
+        }
+    } else {
+        const int na = min(p.reset_n_agents, p.C);
+        const int k1 = na, k2 = na + s.scal[S_SPEC_NF], k3 = k2 + s.scal[S_SPEC_NP];
+        for (int c = sp; c < p.Cp; c += NS) {
+            unsigned v = kPadCell;
+            if (c < p.C) {
+                const unsigned key = keys[c];
+                const unsigned b = key >> sh;
+                const int start = b ? (int)cum[b - 1] : 0, end = (int)cum[b];
+                int rank = start;
+                for (int j = start; j < end; ++j) rank += sorted[j] < key;
+                const unsigned t = rank < k1 ? RL_AGENT : rank < k2 ? RL_FOOD : rank < k3 ? RL_POISON : rank == k3 ? (unsigned)kSuper : RL_EMPTY;
+                v = t | (s.spec[c] & 0xFF00u);
+            }
+            s.spec[c] = (unsigned short)v;
+        }
+        if (sp == 0) s.scal[S_SPEC_DONE] = 1;
+    }
+}
+
+__device__ inline void init_newborn(Smem& s, int idx, int cell, int W, int gene, int brain, int uid);
+
+// The prepared world replaces the old one: what reset_world_lds leaves behind, from s.spec.  Returns the agent count.
+template <int T>
+__device__ int apply_spec_refill(const KParams& p, Smem& s, int w, uint32_t epoch)
+{
+    const int tid = threadIdx.x;
+    lds_barrier();
+    if (tid < S_COUNT) s.scal[tid] = 0;
+    for (int c = tid; c < p.Cp; c += T) {
+        const unsigned t = s.spec[c] & 0xFFu;
+        s.type[c] = (uint8_t)t;
+        s.occ[c] = -1;
+        const unsigned long long m = __ballot(t == RL_AGENT);
+        if (lane_id() == 0) s.agbits[c >> 6] = m;
+    }
+    lds_barrier();
+    if (tid < 64) {
+        const int cntw = tid < p.nW ? __popcll(s.agbits[tid]) : 0;
+        const int incl = wave_incl_scan(cntw);
+        s.wordbase[tid] = incl - cntw;
+    }
+    lds_barrier();
+    for (int c = tid; c < p.C; c += T) {
+        const unsigned v = s.spec[c];
+        if ((v & 0xFFu) == RL_AGENT) {
+            const int idx = s.wordbase[c >> 6] + __popcll(s.agbits[c >> 6] & lowmask(c & 63));
+            const int gene = (int)(v >> 8);
+            init_newborn(s, idx, c, p.W, gene, gene, idx);
+            s.order[idx] = (short)idx; s.newidx[idx] = (short)idx;
+        }
+    }
+    const int na = min(p.reset_n_agents, p.C);
+    if (tid < RL_N_BEST) {
+        s.best_uid[tid] = -1; s.best_fit[tid] = 0.0; s.best_brain[tid] = 0;
+        p.st.best_uid[(size_t)w * RL_N_BEST + tid] = -1;
+        p.st.best_fit[(size_t)w * RL_N_BEST + tid] = 0.0;
+        p.st.best_brain[(size_t)w * RL_N_BEST + tid] = 0;
+    }
+    if (tid == 0) {
+        p.st.next_uid[w] = na; p.st.max_gene[w] = p.n_brains; p.st.tick[w] = 0; p.st.epoch[w] = (int)epoch;
+        if (p.refill_count) atomicAdd(p.refill_count, 1);
+    }
+    lds_barrier();
+    return na;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // phases
 // ---------------------------------------------------------------------------------------------------------------
-template <int T>
-__device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
+template <int T, bool SPEC = false>
+__device__ void load_world(const KParams& p, Smem& s, int w, int& n0, SpecState& spec)
 {
     const int tid = threadIdx.x;
     KParamsC* q = kernargs();
@@ -327,8 +474,14 @@ __device__ void load_world(const KParams& p, Smem& s, int w, int& n0)
     for (int c = tid; c < p.Cp; c += T) { s.occ[c] = -1; ((unsigned*)s.foodv)[c] = 0u; }
     for (int i = tid; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
     if (tid < RL_MAX_BRAINS) s.present[tid] = 0;
+    if (SPEC) for (int i = tid; i < 2 * p.cap; i += T) ((unsigned*)s.reward)[i] = 0u;  // bucket counters of a speculative refill
     __builtin_amdgcn_sched_barrier(0);
     RL_MARK(31);
+    spec.on = false; spec.lg = 0; spec.nf = spec.np = 0;
+    if (SPEC) {  // needs only the two scalars: the vector loads are still in flight
+        spec.on = spec_refill_wanted(p, n0, spec.lg);
+        if (spec.on) spec_refill_keys<T>(p, s, w, (uint32_t)v_epoch + 1u, spec);
+    }
     // ---- consume the loads
     if (tid < S_COUNT) s.scal[tid] = tid == S_NSLOTS ? n0 : sc_val;
     if (tid < RL_N_BEST) { s.best_uid[tid] = bu; s.best_fit[tid] = bf; s.best_brain[tid] = bb; }
@@ -549,11 +702,12 @@ __device__ inline void precompute_draws(const KParams& p, Smem& s, int w, int n0
 }
 
 // Environment.step up to (not including) the observation pass
-template <int T, bool LEAN, bool PLANES_EARLY>
-__device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
+template <int T, bool LEAN, bool PLANES_EARLY, bool SPEC = false>
+__device__ void phase_step(const KParams& p, Smem& s, int w, int n0, const SpecState& spec_state)
 {
     const int tid = threadIdx.x;
     const int W = p.W, H = p.H;
+    const bool spec = SPEC && spec_state.on;  // uniform per workgroup
     unsigned* cnt = (unsigned*)s.foodv;
     // ---- _act prologue + _attack (closed form) + _prepare_movement ------------------------------------------------
     for (int a = tid; a < n0; a += T) {
@@ -591,6 +745,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
         atomicAdd(&cnt[tg], 1u);
     }
     if (LEAN) precompute_draws<T>(p, s, w, n0);
+    if (SPEC && spec) spec_refill_stage<T>(p, s, w, spec_state, 0);
     lds_barrier();
     RL_MARK(2);
     // ---- _execute_movement: Jacobi fixed point (environment.py:637-644) --------------------------------------------
@@ -633,12 +788,14 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
         }
         s.aux[a] = ax;
     }
+    if (SPEC && spec) spec_refill_stage<T>(p, s, w, spec_state, 1);
     lds_barrier();
     RL_MARK(35);
     for (int a = tid; a < n0; a += T) {
         const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
         if (s.tgt[a] != cx) { s.type[cx] = RL_EMPTY; s.occ[cx] = -1; }
     }
+    if (SPEC && spec) spec_refill_stage<T>(p, s, w, spec_state, 2);
     lds_barrier();
     RL_MARK(36);
     // (per-wave counts are taken with ballots and added by one lane: a per-lane atomicAdd on one LDS word is turned by the
@@ -670,6 +827,7 @@ __device__ void phase_step(const KParams& p, Smem& s, int w, int n0)
     }
     RL_MARK(37);
     if (alive_wave && lane_id() == 0) atomicAdd(&s.scal[S_ALIVE], alive_wave);
+    if (SPEC && spec) spec_refill_stage<T>(p, s, w, spec_state, 3);
     lds_barrier();
     RL_MARK(4);
     // ---- _get_rewards over the _act list incl. vanished agents (environment.py:291-311) ------------------------------
@@ -1247,7 +1405,10 @@ __global__ __launch_bounds__(T) void k_world(const KParams p_in)
     if (p.prof && (int)blockIdx.x == p.prof_world && threadIdx.x == 0) p.prof[23] = (long long)t_entry;
 #endif
     if (RL_ABL(32768)) return;
-    load_world<T>(p, s, w, n0);
+    // (speculative refill: lean fused tick, 1024-thread workgroups -- the latency-bound regime of one world per CU)
+    constexpr bool kSpec = LEAN && MODE == MODE_TICK && T == 1024;
+    SpecState spec_state;
+    load_world<T, kSpec>(p, s, w, n0, spec_state);
     RL_MARK(1);
     if (RL_ABL(65536)) return;
     int nslots = n0;
@@ -1307,7 +1468,7 @@ __global__ __launch_bounds__(T) void k_world(const KParams p_in)
         constexpr bool kPlanesEarly = T >= 256 && MODE == MODE_TICK;  // (a split step returns before the placement interval)
         if (!RL_ABL(512)) {
             // leaves the agent bitmap, its prefix and scal[S_N1] of the new ordering -- and, kPlanesEarly, the planes
-            phase_step<T, LEAN, kPlanesEarly>(p, s, w, n0);
+            phase_step<T, LEAN, kPlanesEarly, kSpec>(p, s, w, n0, spec_state);
             RL_MARK(8);
             assign_order<T>(p, s, nslots);     // same barrier interval as the planes: they do not read the ordering
             if (kPlanesEarly) patch_placed_planes(s);
@@ -1383,7 +1544,9 @@ __global__ __launch_bounds__(T) void k_world(const KParams p_in)
         const bool refill = p.refill_threshold >= 0 && n2 < p.refill_threshold;  // uniform per workgroup
         RL_MARK(19);
         if (refill) {
-            n2 = reset_world_lds<T>(p, s, w, (uint32_t)s.scal[S_EPOCH] + 1u);
+            const bool prepared = kSpec && s.scal[S_SPEC_DONE] != 0;  // (read before the barrier inside either path clears the slots)
+            const uint32_t new_epoch = (uint32_t)s.scal[S_EPOCH] + 1u;
+            n2 = prepared ? apply_spec_refill<T>(p, s, w, new_epoch) : reset_world_lds<T>(p, s, w, new_epoch);
             rebuild_gene_counts<T>(p, s, n2);
         } else {
             assign_order<T>(p, s, nslots);

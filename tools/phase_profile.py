@@ -34,10 +34,13 @@ def main():
     lib = _lib.lib()
     acc = {}
     totals = []
+    pops = []
+    refilled = []
     order = []
     for t in range(a.ticks):
         world = t % a.worlds
         _lib.check(lib.rl_bind_phase_profile(dw.handle, C.c_void_p(stamps.data_ptr()), world), "bind")
+        epoch_before = int(dw.s["epoch"][world].item())
         stamps.zero_()
         dw.act()
         dw.tick_refill(70, 100)
@@ -62,6 +65,8 @@ def main():
         for prev, k in zip(keys[:-1], keys[1:]):
             acc.setdefault(k, []).append(int(st[k] - st[prev]))
         totals.append(int(st[keys[-1]] - st[keys[0]]))
+        pops.append(int(dw.s["n_agents"][world].item()))
+        refilled.append(int(dw.s["epoch"][world].item()) != epoch_before)
     print("phase cycles (shader clock, thread 0 of the sampled world), mean over %d ticks" % len(totals))
     tot = np.mean(totals)
     for k in [k for k in order if k in acc] + [100, 143, 144, 146, 147, 148, 149, 150, 151, 152, 153, 154, 155, 156]:
@@ -70,6 +75,13 @@ def main():
         m = np.mean(acc[k])
         print("  %2d %-34s %9.0f  %5.1f%%" % (k, NAMES.get(k, "?"), m, 100 * m / tot))
     print("  total %.0f cycles" % tot)
+    tt, pp = np.asarray(totals), np.asarray(pops)
+    rf = np.asarray(refilled)
+    if rf.any():
+        print("  sampled worlds that were refilled in their tick: %d of %d, total cycles mean %d (others: mean %d, max %d)"
+              % (rf.sum(), len(rf), tt[rf].mean(), tt[~rf].mean(), tt[~rf].max()))
+    print("  per sampled world: total cycles min %d / median %d / p90 %d / max %d; agents after the tick min %d / median %d / max %d; corr(total, agents) %.2f"
+          % (tt.min(), np.median(tt), np.percentile(tt, 90), tt.max(), pp.min(), np.median(pp), pp.max(), np.corrcoef(tt, pp)[0, 1]))
     if 2000 in acc:
         print("  per-wave arrival at the barrier ending the overlapped interval (from mark 10):", np.mean(acc.pop(2000), axis=0).astype(int).tolist())
         print("  per-wave release:", np.mean(acc.pop(2001), axis=0).astype(int).tolist())
