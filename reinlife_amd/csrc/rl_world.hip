@@ -288,7 +288,7 @@ __device__ inline void flag_error(const KParams& p, Smem& s, int code, int w, in
 // Same rule, same arithmetic as reset_world_lds: both are checked against the oracle.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kSpecFirst = 128;   // first thread that takes part (waves 0 and 1 carry the agents)
-constexpr int kSpecMargin = 40;   // worlds with fewer than threshold + margin agents prepare a refill
+constexpr int kSpecMargin = 20;   // worlds with fewer than threshold + margin agents prepare a refill
 __device__ inline bool spec_refill_wanted(const KParams& p, int n0, int& lg)
 {
     lg = 6;
