@@ -377,7 +377,7 @@ __device__ inline void init_newborn(Smem& s, int idx, int cell, int W, int gene,
 
 // The prepared world replaces the old one: what reset_world_lds leaves behind, from s.spec.  Returns the agent count.
 template <int T>
-__device__ int apply_spec_refill(const KParams& p, Smem& s, int w, uint32_t epoch)
+__device__ __forceinline__ int apply_spec_refill(const KParams& p, Smem& s, int w, uint32_t epoch)
 {
     const int tid = threadIdx.x;
     lds_barrier();
@@ -424,7 +424,7 @@ __device__ int apply_spec_refill(const KParams& p, Smem& s, int w, uint32_t epoc
 // phases
 // ---------------------------------------------------------------------------------------------------------------
 template <int T, bool SPEC = false>
-__device__ void load_world(const KParams& p, Smem& s, int w, int& n0, SpecState& spec)
+__device__ __forceinline__ void load_world(const KParams& p, Smem& s, int w, int& n0, SpecState& spec)
 {
     const int tid = threadIdx.x;
     KParamsC* q = kernargs();
@@ -538,7 +538,7 @@ __device__ inline void hash_insert_wave(Smem& s, int mask, bool active, int a, i
 
 // Grid.get_entities order of the current grid: newidx[a] / order[k] for all slots, returns count via scal[slot]
 template <int T>
-__device__ void build_order(const KParams& p, Smem& s, int nslots, int out_slot)
+__device__ __forceinline__ void build_order(const KParams& p, Smem& s, int nslots, int out_slot)
 {
     const int tid = threadIdx.x;
     for (int c = tid; c < p.Cp; c += T) {
@@ -567,7 +567,7 @@ __device__ void build_order(const KParams& p, Smem& s, int nslots, int out_slot)
 
 // Third part of build_order alone (agbits / wordbase / scal[slot] already there); no trailing barrier
 template <int T>
-__device__ void assign_order(const KParams& p, Smem& s, int nslots)
+__device__ __forceinline__ void assign_order(const KParams& p, Smem& s, int nslots)
 {
     for (int a = threadIdx.x; a < nslots; a += T) {
         const int cell = (s.pos[a] & 255) * p.W + (s.pos[a] >> 8);
@@ -590,7 +590,7 @@ __device__ inline void scan_order_wave(const KParams& p, Smem& s, int lane, int 
 
 // _prepare_observations (environment.py:377-404) into LDS planes
 template <int T>
-__device__ void build_planes(const KParams& p, Smem& s, int t0 = threadIdx.x, int nt = T)
+__device__ __forceinline__ void build_planes(const KParams& p, Smem& s, int t0 = threadIdx.x, int nt = T)
 {
     if (RL_ABL(2)) return;
     const bool float_mode = s.type[0] == RL_AGENT;  // np.vectorize dtype inference from cell (0,0)
@@ -618,7 +618,7 @@ __device__ void build_planes(const KParams& p, Smem& s, int t0 = threadIdx.x, in
 // _get_observations (environment.py:349-375): n agents in order[] -> obs rows (coalesced 49-float runs).  Executed by NT
 // threads, `t` = this thread's index among them (the fused tick lets wave 0 run _reproduce meanwhile).
 template <int NT>
-__device__ void write_observations(const KParams& p, Smem& s, int w, int n, float* obs, int t)
+__device__ __forceinline__ void write_observations(const KParams& p, Smem& s, int w, int n, float* obs, int t)
 {
     if (!obs || RL_ABL(1)) return;
     float* base = obs + (size_t)w * p.cap * RL_OBS_DIM;
@@ -703,7 +703,7 @@ __device__ inline void precompute_draws(const KParams& p, Smem& s, int w, int n0
 
 // Environment.step up to (not including) the observation pass
 template <int T, bool LEAN, bool PLANES_EARLY, bool SPEC = false>
-__device__ void phase_step(const KParams& p, Smem& s, int w, int n0, const SpecState& spec_state)
+__device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int n0, const SpecState& spec_state)
 {
     const int tid = threadIdx.x;
     const int W = p.W, H = p.H;
@@ -952,7 +952,7 @@ __device__ inline void init_newborn(Smem& s, int idx, int cell, int W, int gene,
 // the occupancy grid, the new slots and (limit_reproduction) the parents' flags, so a fused tick runs it next to the
 // state_prime observation pass of the other waves.
 template <int T, bool LEAN>
-__device__ void reproduce_wave0(const KParams& p, Smem& s, int w, int n1, int nslots)
+__device__ __forceinline__ void reproduce_wave0(const KParams& p, Smem& s, int w, int n1, int nslots)
 {
     const int tid = threadIdx.x;
     const bool room = n1 <= p.max_agents;
@@ -1018,15 +1018,9 @@ __device__ void reproduce_wave0(const KParams& p, Smem& s, int w, int n1, int ns
     // serial path); newborn slots lie behind every parent slot, so parking the newborns' data cannot alias them
     int par_gene = 0, par_brain = 0;
     if (tid < npar) { const int par = s.plist[tid]; par_gene = s.gene[par]; par_brain = s.brain[par]; }
-    for (int b = 0; b < npar; ++b) {
-        if (P.n_empty <= 0) continue;  // full grid: randint raises, no draw, no offspring (grid.py:82-83)
-        int g, br;
-        if (b < 64) { g = read_lane(par_gene, b); br = read_lane(par_brain, b); }
-        else { const int par = s.plist[b]; g = s.gene[par]; br = s.brain[par]; }
-        place_birth(g, p.static_families ? g : br, b);
-    }
-    RL_MARK(41);
-    // _produce
+    // _produce's decision (environment.py:519-547) does not depend on the births; its placement comes after them
+    int prod_gene = -1, prod_brain = 0;
+    bool prod_place = false;
     if (room) {
         double u; unsigned x1 = 0;
         if (tape) u = p.tape.produce_u[w];
@@ -1054,8 +1048,63 @@ __device__ void reproduce_wave0(const KParams& p, Smem& s, int w, int n1, int ns
                 brain = (c >= 0 && c < RL_N_BEST) ? s.best_brain[c] : 0;
                 if (c < 0 || c >= RL_N_BEST) { if (tid == 0) flag_error(p, s, 4, w, c, 0); }
             }
-            if (P.n_empty > 0 && gene >= 0) place_birth(gene, brain, -1);
+            prod_gene = gene; prod_brain = brain; prod_place = gene >= 0;
         }
+    }
+    // All placements of the tick AT ONCE (lean tick: in-kernel draws).  Placement b takes the k_b-th empty cell of the grid
+    // left by placements 0..b-1, k_b = floor(u_b * (E - b)): sequential by definition, ~450 cycles each through the wave's
+    // bitmap -- and a cohort that comes of age together gives one world 20 births in a tick, which then holds up the whole
+    // launch.  But "k-th element of the complement of a sorted set C" is k + |{j : C_j - j <= k}|, so the ranks r_b in the
+    // ORIGINAL list of empty cells follow from a short scalar recurrence (two ballots per placement on a sorted register
+    // across the lanes), and all cells are then selected in parallel: lane b looks its word up in the prefix of the empty
+    // counts and picks the bit with a six-step popcount search.
+    const int n_empty0 = P.n_empty;
+    const int nb_births = min(npar, n_empty0);  // a parent whose turn finds the grid full draws nothing (grid.py:82-83)
+    const bool batch = LEAN && !tape && npar < 64 && nslots + npar + 1 <= p.cap;
+    if (batch) {
+        const bool prod_now = prod_place && n_empty0 - nb_births > 0;
+        const int total = nb_births + (prod_now ? 1 : 0);
+        const unsigned x = dc.w[32 + tid];                                 // birth draw `tid` (the cache holds 64 of them)
+        const int k = tid < total ? (int)rl_mulhi(x, (unsigned)(n_empty0 - tid)) : 0;
+        int chosen = 0x7fffffff, rsel = 0;                                    // lane j: j-th smallest rank chosen so far
+        for (int b = 0; b < total; ++b) {
+            const int kb = read_lane(k, b);
+            const int r = kb + __popcll(__ballot(tid < b && chosen - tid <= kb));
+            const int pos = __popcll(__ballot(tid < b && chosen < r));
+            const int up = __builtin_amdgcn_update_dpp(chosen, chosen, 0x138, 0xF, 0xF, false);  // wave_shr:1 -- lane j takes lane j-1's
+            chosen = tid > pos ? up : (tid == pos ? r : chosen);
+            if (tid == b) rsel = r;
+        }
+        s.wordbase[tid] = P.incl;  // (free here: the orderings that use it are built before / after this section)
+        int L = 0;
+        for (int wd = 0; wd < p.nW; ++wd) L += s.wordbase[wd] <= rsel;
+        L = min(L, p.nW - 1);
+        unsigned long long zz = ~s.occbits[L];
+        int kk = rsel - (L ? s.wordbase[L - 1] : 0), bit = 0;
+#pragma unroll
+        for (int sft = 32; sft; sft >>= 1) {
+            const int c = __popcll(zz & ((1ull << sft) - 1ull));
+            if (kk >= c) { kk -= c; zz >>= sft; bit += sft; }
+        }
+        if (tid < total) {
+            const bool is_prod = tid >= nb_births;
+            const int slot = nslots + tid;
+            s.tgt[slot] = (unsigned short)(L * 64 + bit);
+            s.gene[slot] = is_prod ? prod_gene : par_gene;
+            s.brain[slot] = is_prod ? prod_brain : (p.static_families ? par_gene : par_brain);
+        }
+        slots = nslots + total; n_birth = total;
+        RL_MARK(41);
+    } else {
+        for (int b = 0; b < npar; ++b) {
+            if (P.n_empty <= 0) continue;  // full grid: randint raises, no draw, no offspring (grid.py:82-83)
+            int g, br;
+            if (b < 64) { g = read_lane(par_gene, b); br = read_lane(par_brain, b); }
+            else { const int par = s.plist[b]; g = s.gene[par]; br = s.brain[par]; }
+            place_birth(g, p.static_families ? g : br, b);
+        }
+        RL_MARK(41);
+        if (prod_place && P.n_empty > 0) place_birth(prod_gene, prod_brain, -1);
     }
     RL_MARK(42);
     // newborns (entities.py:145-159), initialised in parallel: lane i -> slot nslots + i
@@ -1103,7 +1152,7 @@ __device__ inline void best_agents_wave(Smem& s, int n1)
 
 // Environment.update_env up to (not including) the observation pass.  order[0..n1) is the grid list.
 template <int T, bool LEAN>
-__device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslots, bool fresh_bitmap)
+__device__ __forceinline__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslots, bool fresh_bitmap)
 {
     const int tid = threadIdx.x;
     // ---- _update_best_agents (environment.py:728-739) ----------------------------------------------------------------
@@ -1149,7 +1198,7 @@ __device__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslo
 
 // on-grid gene counts for the observation's percent_genes (environment.py:357)
 template <int T>
-__device__ void rebuild_gene_counts(const KParams& p, Smem& s, int n)
+__device__ __forceinline__ void rebuild_gene_counts(const KParams& p, Smem& s, int n)
 {
     for (int i = threadIdx.x; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
     lds_barrier();
@@ -1198,7 +1247,7 @@ __device__ inline double np_pairwise_sum<0>(const double* a, int n) { return np_
 
 // Tracker._track_results over the post-step list (Helpers/tracker.py:178-266), executed by wave 0 without atomics:
 // lane g owns group g (gene g with static families, everybody otherwise).
-__device__ void track_world_wave0(const KParams& p, Smem& s, int w, int n1)
+__device__ __forceinline__ void track_world_wave0(const KParams& p, Smem& s, int w, int n1)
 {
     const int lane = lane_id();
     const int G = p.static_families ? p.n_brains : 1;
@@ -1314,7 +1363,7 @@ __device__ inline void emit_brain_lists_wave0(const KParams& p, int w, int n, F 
 }
 
 template <int T>
-__device__ void store_world(const KParams& p, Smem& s, int w, int n)
+__device__ __forceinline__ void store_world(const KParams& p, Smem& s, int w, int n)
 {
     const int tid = threadIdx.x;
     KParamsC* q = kernargs();
@@ -1350,7 +1399,7 @@ __device__ void store_world(const KParams& p, Smem& s, int w, int n)
 }
 
 template <int T>
-__device__ int reset_world_lds(const KParams& p, Smem& s, int w, uint32_t epoch);
+__device__ __forceinline__ int reset_world_lds(const KParams& p, Smem& s, int w, uint32_t epoch);
 
 enum { MODE_STEP = 0, MODE_UPDATE = 1, MODE_TICK = 2, MODE_OBSERVE = 3, MODE_FOOD = 4 };
 
@@ -1589,7 +1638,7 @@ __global__ __launch_bounds__(T) void k_world(const KParams p_in)
 // ---------------------------------------------------------------------------------------------------------------
 // Leaves LDS holding the new world: type/occ, agents in slots 0..n-1 in row-major order, order[k] = k.  Returns n.
 template <int T>
-__device__ int reset_world_lds(const KParams& p, Smem& s, int w, uint32_t epoch)
+__device__ __forceinline__ int reset_world_lds(const KParams& p, Smem& s, int w, uint32_t epoch)
 {
     const int tid = threadIdx.x;
     // LDS scratch (the observation planes are rebuilt afterwards): key per cell, bucket counters, keys grouped by bucket

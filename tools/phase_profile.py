@@ -35,6 +35,7 @@ def main():
     acc = {}
     totals = []
     pops = []
+    samples = []
     refilled = []
     order = []
     for t in range(a.ticks):
@@ -65,6 +66,7 @@ def main():
         for prev, k in zip(keys[:-1], keys[1:]):
             acc.setdefault(k, []).append(int(st[k] - st[prev]))
         totals.append(int(st[keys[-1]] - st[keys[0]]))
+        samples.append({k: int(st[k] - st[prev]) for prev, k in zip(keys[:-1], keys[1:])})
         pops.append(int(dw.s["n_agents"][world].item()))
         refilled.append(int(dw.s["epoch"][world].item()) != epoch_before)
     print("phase cycles (shader clock, thread 0 of the sampled world), mean over %d ticks" % len(totals))
@@ -80,6 +82,11 @@ def main():
     if rf.any():
         print("  sampled worlds that were refilled in their tick: %d of %d, total cycles mean %d (others: mean %d, max %d)"
               % (rf.sum(), len(rf), tt[rf].mean(), tt[~rf].mean(), tt[~rf].max()))
+    slow = np.argsort(tt)[-8:]
+    print("  the 8 slowest samples against the mean, by phase (cycles):")
+    for k in [k for k in order if k in acc]:
+        print("    %2d %-34s mean %6.0f | slowest: %s" % (k, NAMES.get(k, "?"), np.mean(acc[k]), " ".join("%6d" % samples[i].get(k, 0) for i in slow)))
+    print("       agents after the tick / refilled: %s" % " ".join("%d%s" % (pp[i], "R" if rf[i] else "") for i in slow))
     print("  per sampled world: total cycles min %d / median %d / p90 %d / max %d; agents after the tick min %d / median %d / max %d; corr(total, agents) %.2f"
           % (tt.min(), np.median(tt), np.percentile(tt, 90), tt.max(), pp.min(), np.median(pp), pp.max(), np.corrcoef(tt, pp)[0, 1]))
     if 2000 in acc:
