@@ -84,6 +84,8 @@ struct Smem {
     unsigned short *pos, *tgt, *hslot;                 // [cap]
     short *newidx, *order, *src, *plist;               // [cap]
     unsigned short* spec;         // [Cp]  a refill generated ahead of time: cell type | gene << 8 (spec_refill_stage)
+    unsigned long long* spec_agbits;  // [64] its agent cells ...
+    int* spec_wordbase;               // [64] ... and their exclusive prefix per bitmap word
     uint8_t *flags, *aux;                              // [cap]
     signed char* action;                               // [cap]
 };
@@ -110,12 +112,14 @@ __host__ __device__ inline size_t carve(Smem& s, char* base, int Cp, int cap, in
 #define CARVE(field, type, count) s.field = (type*)(base + o); o = align16(o + sizeof(type) * (size_t)(count));
     CARVE(occbits, unsigned long long, 64)
     CARVE(agbits, unsigned long long, 64)
+    CARVE(spec_agbits, unsigned long long, 64)
     CARVE(best_fit, double, 16)
     CARVE(wred_f, double, 16)
     CARVE(fitness, double, cap)
     CARVE(reward, double, cap)
     CARVE(trk_rew, double, cap)
     CARVE(wordbase, int, 64)
+    CARVE(spec_wordbase, int, 64)
     CARVE(scal, int, S_COUNT)
     CARVE(best_uid, int, 16)
     CARVE(best_brain, int, 16)
@@ -321,7 +325,8 @@ __device__ inline void spec_refill_keys(const KParams& p, Smem& s, int w, uint32
         st.nf += __popcll(__ballot(f)); st.np += __popcll(__ballot(q));
     }
 }
-// stage 0: histogram, 1: scan (one wave), 2: scatter, 3: rank + classify.  One barrier between stages.
+// stage 0: histogram, 1: scan (one wave), 2: scatter, 3: rank + classify, 4: agent bitmap + prefix (one wave).  One barrier
+// between stages.
 template <int T>
 __device__ inline void spec_refill_stage(const KParams& p, Smem& s, int w, const SpecState& st, int stage)
 {
@@ -353,7 +358,7 @@ __device__ inline void spec_refill_stage(const KParams& p, Smem& s, int w, const
             const unsigned key = keys[c];
             sorted[atomicAdd(&cum[key >> sh], 1u)] = key;  // afterwards cum[b] = END of bucket b
         }
-    } else {
+    } else if (stage == 3) {
         const int na = min(p.reset_n_agents, p.C);
         const int k1 = na, k2 = na + s.scal[S_SPEC_NF], k3 = k2 + s.scal[S_SPEC_NP];
         for (int c = sp; c < p.Cp; c += NS) {
@@ -369,7 +374,18 @@ __device__ inline void spec_refill_stage(const KParams& p, Smem& s, int w, const
             }
             s.spec[c] = (unsigned short)v;
         }
-        if (sp == 0) s.scal[S_SPEC_DONE] = 1;
+    } else if (stage == 4) {   // agent bitmap of the prepared world, scanned by the wave that holds it
+        if (sp < 64) {
+            unsigned long long mine = 0ull;
+            for (int wd = 0; wd < p.nW; ++wd) {
+                const unsigned long long m = __ballot((s.spec[wd * 64 + sp] & 0xFFu) == RL_AGENT);
+                if (sp == wd) mine = m;
+            }
+            const int cntw = __popcll(mine);
+            s.spec_agbits[sp] = mine;
+            s.spec_wordbase[sp] = wave_incl_scan(cntw) - cntw;
+            if (sp == 0) s.scal[S_SPEC_DONE] = 1;
+        }
     }
 }
 
@@ -382,29 +398,21 @@ __device__ __forceinline__ int apply_spec_refill(const KParams& p, Smem& s, int 
     const int tid = threadIdx.x;
     lds_barrier();
     if (tid < S_COUNT) s.scal[tid] = 0;
+    // one pass: the bitmap and its prefix were prepared too, and a cell's occ / type are written by its own thread only
     for (int c = tid; c < p.Cp; c += T) {
-        const unsigned t = s.spec[c] & 0xFFu;
+        const unsigned v = s.spec[c];
+        const unsigned t = v & 0xFFu;
         s.type[c] = (uint8_t)t;
         s.occ[c] = -1;
-        const unsigned long long m = __ballot(t == RL_AGENT);
-        if (lane_id() == 0) s.agbits[c >> 6] = m;
-    }
-    lds_barrier();
-    if (tid < 64) {
-        const int cntw = tid < p.nW ? __popcll(s.agbits[tid]) : 0;
-        const int incl = wave_incl_scan(cntw);
-        s.wordbase[tid] = incl - cntw;
-    }
-    lds_barrier();
-    for (int c = tid; c < p.C; c += T) {
-        const unsigned v = s.spec[c];
-        if ((v & 0xFFu) == RL_AGENT) {
-            const int idx = s.wordbase[c >> 6] + __popcll(s.agbits[c >> 6] & lowmask(c & 63));
+        if (t == RL_AGENT) {
+            const int idx = s.spec_wordbase[c >> 6] + __popcll(s.spec_agbits[c >> 6] & lowmask(c & 63));
             const int gene = (int)(v >> 8);
             init_newborn(s, idx, c, p.W, gene, gene, idx);
             s.order[idx] = (short)idx; s.newidx[idx] = (short)idx;
         }
     }
+    if (tid < 64) { s.agbits[tid] = s.spec_agbits[tid]; s.wordbase[tid] = s.spec_wordbase[tid]; }
+    for (int i = tid; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }  // the gene table of the new world starts empty
     const int na = min(p.reset_n_agents, p.C);
     if (tid < RL_N_BEST) {
         s.best_uid[tid] = -1; s.best_fit[tid] = 0.0; s.best_brain[tid] = 0;
@@ -862,6 +870,7 @@ __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int
         if (np_) atomicAdd(&s.scal[S_NPOISON], np_);
         if (ns) atomicAdd(&s.scal[S_NSUPER], ns);
     }
+    if (SPEC && spec) spec_refill_stage<T>(p, s, w, spec_state, 4);
     lds_barrier();
     RL_MARK(6);
     if (tid >= 64 && tid < 128) scan_order_wave(p, s, tid - 64, S_N1);
@@ -1595,8 +1604,14 @@ __global__ __launch_bounds__(T) void k_world(const KParams p_in)
         if (refill) {
             const bool prepared = kSpec && s.scal[S_SPEC_DONE] != 0;  // (read before the barrier inside either path clears the slots)
             const uint32_t new_epoch = (uint32_t)s.scal[S_EPOCH] + 1u;
-            n2 = prepared ? apply_spec_refill<T>(p, s, w, new_epoch) : reset_world_lds<T>(p, s, w, new_epoch);
-            rebuild_gene_counts<T>(p, s, n2);
+            if (prepared) {  // unpack, then count the genes in the same interval as the planes below
+                n2 = apply_spec_refill<T>(p, s, w, new_epoch);
+                const int np2 = (n2 + 63) & ~63;
+                for (int k = tid; k < np2; k += T) hash_insert_wave(s, p.hash_mask, k < n2, k, k < n2 ? s.gene[k] : 0, 1u << 16);  // order[k] == k
+            } else {
+                n2 = reset_world_lds<T>(p, s, w, new_epoch);
+                rebuild_gene_counts<T>(p, s, n2);
+            }
         } else {
             assign_order<T>(p, s, nslots);
             const int nsp = (nslots + 63) & ~63;  // whole waves take part in the gene aggregation
