@@ -291,13 +291,13 @@ __device__ inline void flag_error(const KParams& p, Smem& s, int code, int w, in
 // (two barrier intervals, no Philox); if the world was not prepared, the in-line generator runs as before.
 // Same rule, same arithmetic as reset_world_lds: both are checked against the oracle.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kSpecFirst = 128;   // first thread that takes part (waves 0 and 1 carry the agents)
+constexpr int kSpecFirst = 64;    // first thread that takes part: 960 threads, one cell each for a 30x30 grid (wave 0 runs the serial sections)
 constexpr int kSpecMargin = 20;   // worlds with fewer than threshold + margin agents prepare a refill
 __device__ inline bool spec_refill_wanted(const KParams& p, int n0, int& lg)
 {
     lg = 6;
     while ((2 << lg) <= p.Cp) ++lg;  // NB = largest power of two <= Cp (reset_world_lds)
-    return p.refill_threshold >= 0 && n0 < p.refill_threshold + kSpecMargin && n0 <= kSpecFirst && (1 << lg) <= 2 * p.cap;
+    return p.refill_threshold >= 0 && n0 < p.refill_threshold + kSpecMargin && n0 <= 128 && (1 << lg) <= 2 * p.cap;
 }
 struct SpecState {
     bool on;     // this world prepares a refill in this tick (uniform per workgroup)

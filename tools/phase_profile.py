@@ -35,6 +35,7 @@ def main():
     acc = {}
     totals = []
     pops = []
+    n_before = []
     samples = []
     refilled = []
     order = []
@@ -42,6 +43,7 @@ def main():
         world = t % a.worlds
         _lib.check(lib.rl_bind_phase_profile(dw.handle, C.c_void_p(stamps.data_ptr()), world), "bind")
         epoch_before = int(dw.s["epoch"][world].item())
+        n_before.append(int(dw.s["n_agents"][world].item()))
         stamps.zero_()
         dw.act()
         dw.tick_refill(70, 100)
@@ -82,6 +84,15 @@ def main():
     if rf.any():
         print("  sampled worlds that were refilled in their tick: %d of %d, total cycles mean %d (others: mean %d, max %d)"
               % (rf.sum(), len(rf), tt[rf].mean(), tt[~rf].mean(), tt[~rf].max()))
+    nb = np.asarray(n_before[-len(tt):])
+    lo, hi = (nb < 90) & ~rf, (nb >= 90) & ~rf
+    if lo.any() and hi.any():
+        print("  not refilled, by population before the tick (< 90 prepares a refill on its idle waves): %d worlds mean %d cycles | %d worlds mean %d cycles"
+              % (lo.sum(), tt[lo].mean(), hi.sum(), tt[hi].mean()))
+        for k in [k for k in order if k in acc]:
+            a_ = np.mean([samples[i].get(k, 0) for i in np.nonzero(lo)[0]]); b_ = np.mean([samples[i].get(k, 0) for i in np.nonzero(hi)[0]])
+            if abs(a_ - b_) > 150:
+                print("    %2d %-34s %6.0f | %6.0f" % (k, NAMES.get(k, "?"), a_, b_))
     slow = np.argsort(tt)[-8:]
     print("  the 8 slowest samples against the mean, by phase (cycles):")
     for k in [k for k in order if k in acc]:
