@@ -167,6 +167,38 @@ def test_hip_lean_tick_matches_oracle(static, limit, incentive, generic, monkeyp
     assert refills > 5
 
 
+@pytest.mark.parametrize("width,height,max_agents,thr,n_new", [(20, 15, 60, 45, 50), (7, 5, 12, 9, 10), (64, 64, 100, 90, 100),
+                                                               (30, 30, 200, 150, 180)])
+def test_hip_lean_tick_refills_on_other_shapes(width, height, max_agents, thr, n_new):
+    """Lean fused tick + refill on shapes the specialised kernel does not cover (generic code, prepared and in-line refills):
+    thresholds close to the population so that worlds refill every few ticks."""
+    from oracle import oracle as orc
+    from reinlife_amd.worlds import DeviceWorlds
+    R = 12
+    cfg = dict(width=width, height=height, max_agents=max_agents, n_brains=3, static_families=True, limit_reproduction=False,
+               incentivize_killing=True)
+    dw = DeviceWorlds(n_worlds=R, seed=31, **cfg)
+
+    class _HB:
+        pass
+    hb = _HB(); hb.dw = dw
+    ow = orc.OracleWorlds(n_worlds=R, seed=31, **cfg)
+    dw.reset_synthetic(n_new); ow.reset_synthetic(n_new)
+    rng = np.random.RandomState(3)
+    refills = 0
+    for t in range(40):
+        acts = rng.randint(0, 8, size=(R, dw.cap)).astype(np.int8)
+        ow.step(acts); ow.update()
+        refills += ow.refill(thr, n_new)
+        dw.set_actions(acts)
+        dw.tick_refill(thr, n_new)
+        dw.check_error_flag()
+        _compare_states(hb, ow, "tick %d" % t)
+        _compare_rows(dw.obs_state().cpu().numpy(), ow.obs2, ow.s["n_agents"], "tick %d obs2" % t)
+    assert refills >= 3, refills
+    assert int(dw.refill_count.item()) == refills
+
+
 def test_hip_small_and_rect_grids_match_oracle():
     from hip_backend import HipBackend
     from oracle import oracle as orc
