@@ -1380,8 +1380,10 @@ __device__ __forceinline__ void store_world(const KParams& p, Smem& s, int w, in
     auto gt = RL_G(q->st.cell_type) + (size_t)w * p.C;
     if (!RL_ABL(1024)) for (int c = tid; c < p.C; c += T) gt[c] = s.type[c];
     const size_t b = (size_t)w * p.cap;
+    // (agents are dealt from the TOP thread down: in the fused tick the low waves go on to the row lists and the first
+    // observation rows)
     if (!RL_ABL(2048))
-    for (int k = tid; k < n; k += T) {
+    for (int k = T - 1 - tid; k < n; k += T) {
         const int a = s.order[k];
         if (!RL_ABL(4096)) {
         RL_G(q->st.a_i)[b + k] = (uint8_t)(s.pos[a] & 255);
@@ -1623,6 +1625,14 @@ __global__ __launch_bounds__(T) void k_world(const KParams p_in)
         build_planes<T>(p, s);
         lds_barrier();
         RL_MARK(20);
+        // the world's state goes out FIRST (a few dependent LDS reads per thread, then stores): issued behind the observation
+        // rows it would queue after ~27 KB of row stores per wave at the very end of the launch
+        if (p.uo.src) {
+            const size_t b = (size_t)w * p.cap;
+            for (int k = tid; k < n2; k += T) p.uo.src[b + k] = s.src[s.order[k]];
+        }
+        store_world<T>(p, s, w, n2);
+        RL_MARK(22);
         if (LEAN && MODE == MODE_TICK && T > 64 && p.lists && !RL_ABL(128)) {
             // wave 0 reserves and fills the per-brain row lists (an atomic round trip) while the others write the rows
             if (tid < 64) emit_brain_lists_wave0(p, w, n2, [&](int k) { return s.brain[s.order[k]]; });
@@ -1636,12 +1646,6 @@ __global__ __launch_bounds__(T) void k_world(const KParams p_in)
             if (p.lists && tid < 64 && !RL_ABL(128)) emit_brain_lists_wave0(p, w, n2, [&](int k) { return s.brain[s.order[k]]; });
         }
         RL_MARK(21);
-        if (p.uo.src) {
-            const size_t b = (size_t)w * p.cap;
-            for (int k = tid; k < n2; k += T) p.uo.src[b + k] = s.src[s.order[k]];
-        }
-        store_world<T>(p, s, w, n2);
-        RL_MARK(22);
         if (tid == 0 && !refill) p.st.tick[w] = s.scal[S_TICK] + 1;
     }
 }
