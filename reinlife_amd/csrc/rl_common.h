@@ -52,8 +52,11 @@ __host__ __device__ inline rl_u4 rl_philox4x32(uint64_t seed, uint32_t epoch, ui
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (epoch * 0x9E3779B9u);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t h0 = rl_mulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const uint32_t h1 = rl_mulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        // one 32x32->64 product per multiplier (v_mad_u64_u32 on the device: both halves from ONE quarter-rate instruction
+        // instead of v_mul_hi_u32 + v_mul_lo_u32)
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
+        const uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
         const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
