@@ -20,7 +20,7 @@ from reinlife_amd import _lib  # noqa: E402
 NAMES = {1: "load", 2: "act+attack+prep", 3: "conflict loop", 4: "eat/move/death/hash", 5: "rewards", 6: "food count+bitmap",
          8: "food placement", 9: "order1", 10: "planes1", 11: "obs1 write", 12: "step outputs", 13: "best agents",
          14: "repro gates+parents+bitmap", 15: "births+produce", 17: "remove dead", 18: "order2", 19: "refill (if any)",
-         20: "genes+planes2", 21: "obs2 write", 22: "store", 30: "load: all global loads issued", 31: "load: LDS clear done", 32: "load: scalars + grid consumed", 33: "load: agent arrays issued", 34: "load: barrier", 35: "eat+vanish flags (+bar)", 36: "clear old cells (+bar)", 37: "place+death+hash", 38: "elig bitmap+scan", 39: "gates+parents bitmap", 40: "parents compaction", 41: "birth placements", 42: "produce", 100: "  (of load: kernarg + n_agents fetch)", 143: "  writer wave: obs1 rows", 144: "  writer wave: step outputs", 146: "  writer wave: obs2 rows", 147: "  wave 1 starts after mark 10", 148: "  wave 8 obs1 rows", 149: "  wave 8 step outputs", 150: "  wave 8 starts after mark 10", 151: "  wave 14 obs1 rows", 152: "  wave 14 step outputs", 153: "  wave 14 starts after mark 10", 154: "  wave 1 done -> mark 12", 155: "  wave 8 done -> mark 12", 156: "  wave 14 done -> mark 12"}
+         20: "genes+planes2", 21: "obs2 write", 22: "store (before the last observation pass)", 30: "load: all global loads issued", 31: "load: LDS clear done", 32: "load: scalars + grid consumed", 33: "load: agent arrays issued", 34: "load: barrier", 35: "eat+vanish flags (+bar)", 36: "clear old cells (+bar)", 37: "place+death+hash", 38: "elig bitmap+scan", 39: "gates+parents bitmap", 40: "parents compaction", 41: "birth placements", 42: "produce", 100: "  (of load: kernarg + n_agents fetch)", 143: "  writer wave: obs1 rows", 144: "  writer wave: step outputs", 146: "  writer wave: obs2 rows", 147: "  wave 1 starts after mark 10", 148: "  wave 8 obs1 rows", 149: "  wave 8 step outputs", 150: "  wave 8 starts after mark 10", 151: "  wave 14 obs1 rows", 152: "  wave 14 step outputs", 153: "  wave 14 starts after mark 10", 154: "  wave 1 done -> mark 12", 155: "  wave 8 done -> mark 12", 156: "  wave 14 done -> mark 12"}
 
 
 def main():
@@ -54,7 +54,7 @@ def main():
         if st[23]:
             acc.setdefault(100, []).append(int(st[23] - st[0]))
             st[23] = 0
-        order = [0, 30, 31, 32, 33, 34, 1, 2, 3, 35, 36, 37, 4, 5, 6, 8, 9, 10, 11, 12, 13, 38, 39, 40, 14, 41, 42, 15, 17, 18, 19, 20, 21, 22]
+        order = [0, 30, 31, 32, 33, 34, 1, 2, 3, 35, 36, 37, 4, 5, 6, 8, 9, 10, 11, 12, 13, 38, 39, 40, 14, 41, 42, 15, 17, 18, 19, 20, 22, 21]
         for a_, b_, nm in ((43, 44, 143), (44, 45, 144), (46, 47, 146), (10, 43, 147), (48, 49, 148), (49, 50, 149), (10, 48, 150), (51, 52, 151), (52, 53, 152), (10, 51, 153), (45, 12, 154), (50, 12, 155), (53, 12, 156)):  # stamped by thread 64 (a writer wave)
             if st[a_] and st[b_]:
                 acc.setdefault(nm, []).append(int(st[b_] - st[a_]))
