@@ -42,7 +42,7 @@ struct BrainSlot {
     const int* rowlist;    // row ids (world*cap + k) of the agents using this brain; nullptr = dense rows 0..n_rows-1
     const int* count_ptr;  // device count of rowlist entries (nullptr = n_rows)
     float eps;
-    int pad;
+    int kind;              // RL_DQN .. RL_PPO (read by the mixed-kind launch only)
 };
 
 struct PolicyArgs {
@@ -117,6 +117,70 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : (DEEP ? 3 : 4))) void k_
         if (io.actions && io.valid && v == 0 && lane < 32) io.actions[io.row] = (int8_t)(io.key_tick & 7);
 #else
         policy_tile<KIND, DEEP>(io, lds_h, lds_aux, lds_part, lane, v);
+#endif
+    }
+}
+
+// Brains of DIFFERENT kinds in one launch (mixed populations, BASELINE configs[4]): one launch per kind ran them back to
+// back (PPO 16 us + PERD3QN 13.5 us for the two halves of 680 tiles); here every workgroup picks its brain's tile code at run
+// time, so the kinds overlap on the chip.  Register budget and LDS are the widest kind's (PPO: 2 waves per SIMD).
+__global__ __launch_bounds__(256, 2) void k_policy_mixed(const PolicyArgs A)
+{
+    __shared__ __attribute__((aligned(16))) f32x4 lds_h[policy_lds_units(RL_PPO)];
+    __shared__ __attribute__((aligned(16))) float lds_aux[kAuxFloats];  // row scales
+    __shared__ float lds_part[4][32][9];                        // per-wave head partials
+    const int lane = threadIdx.x & 63, j = lane & 31, v = threadIdx.x >> 6;
+    {   // one batch of scalar loads touches every 64-byte line of the argument block (the brain table is read entry by
+        // entry below: each first touch of a line would be a scalar-cache miss on the way to the row list)
+        auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+        int t0, t1, t2, t3, t4, t5;
+        asm volatile("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\t"
+                     "s_load_dword %3, %6, 0xc0\n\ts_load_dword %4, %6, 0x100\n\ts_load_dword %5, %6, 0x140\n\ts_waitcnt lgkmcnt(0)"
+                     : "=s"(t0), "=s"(t1), "=s"(t2), "=s"(t3), "=s"(t4), "=s"(t5) : "s"(ka) : "memory");
+        static_assert(sizeof(PolicyArgs) >= 0x140 + 4 && sizeof(PolicyArgs) <= 0x180, "the warm-up loads must cover the argument block");
+    }
+#ifdef RL_PHASE_PROFILE
+    if (A.prof && (int)blockIdx.x == A.prof_block && blockIdx.y == 0 && threadIdx.x == 0) A.prof[100] = (long long)clock64();
+#endif
+    // grid = (tiles a brain can have at most, brains of this launch): the brain and the tile follow from the block index,
+    // so the row-list entry is requested together with the brain's row count instead of after it (one dependent round
+    // trip less at the head of every workgroup).  Entries beyond the count are stale or zero row ids: still valid rows.
+    typedef const int __attribute__((address_space(4))) cint;
+    {
+        const int bi = blockIdx.y, tile = blockIdx.x;
+        const BrainSlot B = A.b[bi];
+        const int li = tile * 32 + j;
+        // list entries are (world << 12) | slot (rl_common.h): world and slot without a division, row = world * cap + slot
+        const int entry = B.rowlist ? B.rowlist[li] : 0;
+        const int e_w = rl_list_world(entry), e_k = rl_list_slot(entry);
+        const int64_t listed = B.rowlist ? (int64_t)e_w * A.cap + e_k : (int64_t)li;
+        const int n = B.count_ptr ? ((cint*)B.count_ptr)[0] : (int)A.n_rows;
+        if (tile * 32 >= n) return;
+        TileIO io;
+        io.packed = (gfloat*)B.packed;
+        io.obs = A.obs;
+        io.valid = li < n;
+        io.row = (io.valid || B.rowlist) ? listed : (int64_t)tile * 32;  // dense mode: rows past the end do not exist
+        io.eps = B.eps; io.out = A.out; io.actions = A.actions; io.seed = A.seed;
+        io.key_world = io.key_tick = io.key_epoch = io.key_index = 0;
+        // the draw's Philox key needs the world's tick / epoch: fetch them now, not in the epilogue's dependent chain
+        if (A.actions && v == 0 && lane < 32) {  // rl_policy_act always passes row lists
+            io.key_world = (uint32_t)(A.world_base + e_w); io.key_index = (uint32_t)e_k;
+            io.key_tick = (uint32_t)A.tick[e_w]; io.key_epoch = (uint32_t)A.epoch[e_w];
+        }
+#ifdef RL_PHASE_PROFILE
+        io.prof = (A.prof && (int)blockIdx.x == A.prof_block && blockIdx.y == 0) ? A.prof : nullptr;
+        if (io.prof && threadIdx.x == 0) io.prof[101] = (long long)clock64();
+#endif
+#ifdef RL_ABL_TILE  // tuning experiment: front end only
+        if (io.actions && io.valid && v == 0 && lane < 32) io.actions[io.row] = (int8_t)(io.key_tick & 7);
+#else
+        switch (B.kind) {  // uniform per workgroup
+            case RL_DQN: policy_tile<RL_DQN, true>(io, lds_h, lds_aux, lds_part, lane, v); break;
+            case RL_D3QN: policy_tile<RL_D3QN, true>(io, lds_h, lds_aux, lds_part, lane, v); break;
+            case RL_PERD3QN: policy_tile<RL_PERD3QN, true>(io, lds_h, lds_aux, lds_part, lane, v); break;
+            default: policy_tile<RL_PPO, false>(io, lds_h, lds_aux, lds_part, lane, v); break;
+        }
 #endif
     }
 }
@@ -370,17 +434,41 @@ int rl_policy_act_impl(rl_world* h, const rl_brain* brains, int n_brains, const 
     // every live agent: populations are bounded by 2*max_agents+1 (environment.py:501 snapshot rule)
     const int64_t bound = (int64_t)R * (int64_t)(2 * h->cfg.max_agents + 2 < cap ? 2 * h->cfg.max_agents + 2 : cap);
     const int64_t expected = (int64_t)R * h->cfg.max_agents;  // populations hover around max_agents
-    for (int kind = RL_DQN; kind <= RL_PPO; ++kind) {
+    auto base_args = [&]() {
         PolicyArgs a{};
         a.obs = obs; a.out = out_q; a.actions = actions; a.seed = h->cfg.seed; a.cap = cap; a.world_base = h->cfg.world_base;
         a.tick = h->st.tick; a.epoch = h->st.epoch;
 #ifdef RL_PHASE_PROFILE
         a.prof = h->prof; a.prof_block = h->prof_world;
 #endif
+        return a;
+    };
+    auto slot_of = [&](int b) {
+        BrainSlot s{};
+        s.packed = brains[b].packed; s.rowlist = lists + b * stride; s.count_ptr = counts + b; s.eps = brains[b].epsilon;
+        s.kind = brains[b].kind;
+        return s;
+    };
+    unsigned kinds = 0;
+    for (int b = 0; b < n_brains; ++b) {
+        if (brains[b].kind < RL_DQN || brains[b].kind > RL_PPO) { rl_set_error("unknown brain kind %d", brains[b].kind); return RL_E_INVALID; }
+        kinds |= 1u << brains[b].kind;
+    }
+    if ((kinds & (kinds - 1)) != 0 && n_brains <= kMaxBrainsPerLaunch && !getenv("RL_POLICY_PER_KIND")) {
+        // several kinds: ONE launch, the tile code picked per workgroup (k_policy_mixed)
+        PolicyArgs a = base_args();
+        for (int b = 0; b < n_brains; ++b) a.b[a.nb++] = slot_of(b);
+        const dim3 grid(policy_grid(bound), a.nb), block(256);
+        hipLaunchKernelGGL(k_policy_mixed, grid, block, 0, st, a);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { rl_set_error("policy kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
+        return RL_OK;
+    }
+    for (int kind = RL_DQN; kind <= RL_PPO; ++kind) {
+        PolicyArgs a = base_args();
         for (int b = 0; b < n_brains; ++b) {
             if (brains[b].kind != kind) continue;
-            BrainSlot& s = a.b[a.nb++];
-            s.packed = brains[b].packed; s.rowlist = lists + b * stride; s.count_ptr = counts + b; s.eps = brains[b].epsilon;
+            a.b[a.nb++] = slot_of(b);
             if (a.nb == kMaxBrainsPerLaunch) {
                 if (int rc = launch_policy(kind, a, bound, expected, st)) return rc;
                 a.nb = 0;
