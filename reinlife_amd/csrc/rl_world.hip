@@ -284,8 +284,8 @@ __device__ inline void flag_error(const KParams& p, Smem& s, int code, int w, in
 // the 256 worlds regenerate themselves in every tick: ~8,000 cycles of generator (one Philox block per cell + a counting
 // sort, nine barrier intervals) on top of a full tick.  But the new world depends only on (seed, epoch + 1, world), not on
 // the state -- so a world whose population is close to the threshold lets its IDLE waves (2..15; the agents live on waves 0
-// and 1) run the generator -- the Philox blocks while load_world waits for HBM, the counting sort in four existing barrier
-// intervals of the step phase -- into scratch that is free there
+// and 1) run the generator -- the Philox blocks and the counting sort in five existing barrier intervals of the step phase --
+// into scratch that is free there
 // (keys = the gene plane, sorted keys = the health plane, bucket counters = the reward array, cleared by load_world), and
 // parks the result in s.spec[cell] = type | gene << 8.  If the refill then happens, apply_spec_refill only unpacks it
 // (two barrier intervals, no Philox); if the world was not prepared, the in-line generator runs as before.
@@ -304,7 +304,7 @@ struct SpecState {
     int lg;      // log2 of the bucket count
     int nf, np;  // this WAVE's food / poison coins (spec_refill_keys)
 };
-// The Philox block of every cell (key, coins, gene): runs inside load_world, while the world's loads are in flight.
+// The Philox block of every cell (key, coins, gene).
 template <int T>
 __device__ inline void spec_refill_keys(const KParams& p, Smem& s, int w, uint32_t epoch, SpecState& st)
 {
@@ -432,7 +432,7 @@ __device__ __forceinline__ int apply_spec_refill(const KParams& p, Smem& s, int 
 // phases
 // ---------------------------------------------------------------------------------------------------------------
 template <int T, bool SPEC = false>
-__device__ __forceinline__ void load_world(const KParams& p, Smem& s, int w, int& n0, SpecState& spec)
+__device__ __forceinline__ void load_world(const KParams& p, Smem& s, int w, int& n0)
 {
     const int tid = threadIdx.x;
     KParamsC* q = kernargs();
@@ -485,11 +485,6 @@ __device__ __forceinline__ void load_world(const KParams& p, Smem& s, int w, int
     if (SPEC) for (int i = tid; i < 2 * p.cap; i += T) ((unsigned*)s.reward)[i] = 0u;  // bucket counters of a speculative refill
     __builtin_amdgcn_sched_barrier(0);
     RL_MARK(31);
-    spec.on = false; spec.lg = 0; spec.nf = spec.np = 0;
-    if (SPEC) {  // needs only the two scalars: the vector loads are still in flight
-        spec.on = spec_refill_wanted(p, n0, spec.lg);
-        if (spec.on) spec_refill_keys<T>(p, s, w, (uint32_t)v_epoch + 1u, spec);
-    }
     // ---- consume the loads
     if (tid < S_COUNT) s.scal[tid] = tid == S_NSLOTS ? n0 : sc_val;
     if (tid < RL_N_BEST) { s.best_uid[tid] = bu; s.best_fit[tid] = bf; s.best_brain[tid] = bb; }
@@ -711,11 +706,13 @@ __device__ inline void precompute_draws(const KParams& p, Smem& s, int w, int n0
 
 // Environment.step up to (not including) the observation pass
 template <int T, bool LEAN, bool PLANES_EARLY, bool SPEC = false>
-__device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int n0, const SpecState& spec_state)
+__device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int n0)
 {
     const int tid = threadIdx.x;
     const int W = p.W, H = p.H;
-    const bool spec = SPEC && spec_state.on;  // uniform per workgroup
+    SpecState spec_state;
+    spec_state.on = SPEC && spec_refill_wanted(p, n0, spec_state.lg);
+    const bool spec = spec_state.on;  // uniform per workgroup
     unsigned* cnt = (unsigned*)s.foodv;
     // ---- _act prologue + _attack (closed form) + _prepare_movement ------------------------------------------------
     for (int a = tid; a < n0; a += T) {
@@ -753,7 +750,9 @@ __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int
         atomicAdd(&cnt[tg], 1u);
     }
     if (LEAN) precompute_draws<T>(p, s, w, n0);
-    if (SPEC && spec) spec_refill_stage<T>(p, s, w, spec_state, 0);
+    // (the cells' Philox blocks run here, next to the first agent phase of waves 0 and 1, not in load_world's wait for HBM:
+    // the world's loads come back from L2 / MALL in ~800 cycles, the blocks take ~1,300 -- measured 21.0 vs 21.2 us)
+    if (SPEC && spec) { spec_refill_keys<T>(p, s, w, (uint32_t)s.scal[S_EPOCH] + 1u, spec_state); spec_refill_stage<T>(p, s, w, spec_state, 0); }
     lds_barrier();
     RL_MARK(2);
     // ---- _execute_movement: Jacobi fixed point (environment.py:637-644) --------------------------------------------
@@ -1467,8 +1466,7 @@ __global__ __launch_bounds__(T) void k_world(const KParams p_in)
     if (RL_ABL(32768)) return;
     // (speculative refill: lean fused tick, 1024-thread workgroups -- the latency-bound regime of one world per CU)
     constexpr bool kSpec = LEAN && MODE == MODE_TICK && T == 1024;
-    SpecState spec_state;
-    load_world<T, kSpec>(p, s, w, n0, spec_state);
+    load_world<T, kSpec>(p, s, w, n0);
     RL_MARK(1);
     if (RL_ABL(65536)) return;
     int nslots = n0;
@@ -1528,7 +1526,7 @@ __global__ __launch_bounds__(T) void k_world(const KParams p_in)
         constexpr bool kPlanesEarly = T >= 256 && MODE == MODE_TICK;  // (a split step returns before the placement interval)
         if (!RL_ABL(512)) {
             // leaves the agent bitmap, its prefix and scal[S_N1] of the new ordering -- and, kPlanesEarly, the planes
-            phase_step<T, LEAN, kPlanesEarly, kSpec>(p, s, w, n0, spec_state);
+            phase_step<T, LEAN, kPlanesEarly, kSpec>(p, s, w, n0);
             RL_MARK(8);
             assign_order<T>(p, s, nslots);     // same barrier interval as the planes: they do not read the ordering
             if (kPlanesEarly) patch_placed_planes(s);
