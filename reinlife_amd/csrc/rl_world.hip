@@ -722,24 +722,31 @@ __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int
         const bool dead = fl & RL_F_DEAD;
         const int h0 = min(200, s.health[a] - 10);
         s.age[a] = min(s.max_age[a], s.age[a] + 1);
+        // The four neighbours are looked up with UNCONDITIONAL loads in two batches (who stands there; then its flags,
+        // action and gene): written with && chains the compiler keeps every load behind its guard -- twelve dependent LDS
+        // round trips per agent instead of two (this phase: 2,640 -> 1,740 cycles).
+        int nc[4], y[4], yfl[4], yact[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) nc[d] = neighbour_cell(i, j, d, W, H);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) y[d] = s.occ[nc[d]];
+        const int tdir = (act >= 4 && act <= 7) ? act - 4 : 0;
+        const int t = tdir == 0 ? y[0] : tdir == 1 ? y[1] : tdir == 2 ? y[2] : y[3];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { const int yc = max(y[d], 0); yfl[d] = s.flags[yc]; yact[d] = s.action[yc]; }
+        const int tgene = s.gene[max(t, 0)], mygene = s.gene[a];
         // own attack: succeeds iff the adjacent cell holds an agent (environment.py:692)
         bool own = false;
         int nfl = fl;
-        if (!dead && act >= 4 && act <= 7) {
-            const int t = s.occ[neighbour_cell(i, j, act - 4, W, H)];
-            if (t >= 0) {
-                own = true;
-                nfl |= RL_F_KILLED | (s.gene[t] == s.gene[a] ? RL_F_INTER_KILLED : RL_F_INTRA_KILLED);
-            }
+        if (!dead && act >= 4 && act <= 7 && t >= 0) {
+            own = true;
+            nfl |= RL_F_KILLED | (tgene == mygene ? RL_F_INTER_KILLED : RL_F_INTRA_KILLED);
         }
         // successful attackers of this agent: the neighbour in direction d attacking in direction d^2
         int zmax = -1;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const int nc = neighbour_cell(i, j, d, W, H);
-            const int y = s.occ[nc];
-            if (y >= 0 && !(s.flags[y] & RL_F_DEAD) && s.action[y] == 4 + (d ^ 2)) zmax = max(zmax, nc);
-        }
+        for (int d = 0; d < 4; ++d)
+            if (y[d] >= 0 && !(yfl[d] & RL_F_DEAD) && yact[d] == 4 + (d ^ 2)) zmax = max(zmax, nc[d]);
         int h;
         if (own) h = zmax > cx ? 0 : (zmax >= 0 ? 100 : min(200, h0 + 100));
         else h = zmax >= 0 ? 0 : h0;
