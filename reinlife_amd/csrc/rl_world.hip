@@ -756,7 +756,6 @@ __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int
         s.tgt[a] = (unsigned short)tg;
         atomicAdd(&cnt[tg], 1u);
     }
-    if (LEAN) precompute_draws<T>(p, s, w, n0);
     // (the cells' Philox blocks run here, next to the first agent phase of waves 0 and 1, not in load_world's wait for HBM:
     // the world's loads come back from L2 / MALL in ~800 cycles, the blocks take ~1,300 -- measured 21.0 vs 21.2 us)
     if (SPEC && spec) { spec_refill_keys<T>(p, s, w, (uint32_t)s.scal[S_EPOCH] + 1u, spec_state); spec_refill_stage<T>(p, s, w, spec_state, 0); }
@@ -802,6 +801,9 @@ __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int
         }
         s.aux[a] = ax;
     }
+    // (the tick's draws: first needed by _add_food below.  Not in the first agent phase, where a preparing world's idle
+    // waves are busy with their cells' Philox blocks)
+    if (LEAN) precompute_draws<T>(p, s, w, n0);
     if (SPEC && spec) spec_refill_stage<T>(p, s, w, spec_state, 1);
     lds_barrier();
     RL_MARK(35);
