@@ -767,7 +767,9 @@ __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int
         int conflict = 0;
         for (int a = tid; a < n0; a += T) {
             const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
-            const bool c = s.tgt[a] != cx && cnt[s.tgt[a]] > 1u;
+            const int tg = s.tgt[a];
+            const unsigned ct = cnt[tg];  // unconditional: behind `tg != cx &&` it would be a third dependent LDS trip
+            const bool c = tg != cx && ct > 1u;
             s.aux[a] = c ? 0x80 : 0;
             conflict |= c;
         }
@@ -786,18 +788,19 @@ __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int
     for (int a = tid; a < n0; a += T) {
         const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
         const int tg = s.tgt[a], act = s.action[a];
+        // everything the rule may need, in one batch (guarded loads would each be a dependent LDS trip)
+        const int tt = s.type[tg], oc = s.occ[tg], hp = s.health[a], ma = s.max_age[a], fl = s.flags[a];
         uint8_t ax = 0;
         if (act >= 0 && act <= 3) {
-            const int tt = s.type[tg];
-            if (tt == RL_FOOD) s.health[a] = min(200, s.health[a] + 40);
-            else if (tt == RL_POISON) s.health[a] = min(200, s.health[a] - 40);
+            if (tt == RL_FOOD) s.health[a] = min(200, hp + 40);
+            else if (tt == RL_POISON) s.health[a] = min(200, hp - 40);
             else if (tt == kSuper) {
-                s.health[a] = min(200, s.health[a] + 40);
-                s.max_age[a] = (int)((double)s.max_age[a] * 1.2);
-                s.flags[a] |= RL_F_ATE_SUPER;
+                s.health[a] = min(200, hp + 40);
+                s.max_age[a] = (int)((double)ma * 1.2);
+                s.flags[a] = (uint8_t)(fl | RL_F_ATE_SUPER);
             }
             // entering the cell of a later-ordered agent that is itself leaving: erased by its grid[old]=Empty
-            if (tg != cx && s.occ[tg] >= 0 && tg > cx) ax = AUX_VANISH;
+            if (tg != cx && oc >= 0 && tg > cx) ax = AUX_VANISH;
         }
         s.aux[a] = ax;
     }
@@ -832,7 +835,8 @@ __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int
             }
             // _update_death_status (environment.py:789-793)
             int fl = s.flags[a];
-            if (s.health[a] <= 0 || s.age[a] == s.max_age[a]) fl |= RL_F_DEAD;
+            const int hp = s.health[a], ag = s.age[a], ma = s.max_age[a];  // one batch
+            if (hp <= 0 || ag == ma) fl |= RL_F_DEAD;
             s.flags[a] = (uint8_t)fl;
             alive = (fl & RL_F_DEAD) ? 0u : 1u;
             ongrid = (s.aux[a] & AUX_VANISH) ? 0u : 1u;
