@@ -558,9 +558,11 @@ __device__ __forceinline__ void build_order(const KParams& p, Smem& s, int nslot
     lds_barrier();
     for (int a = tid; a < nslots; a += T) {
         const int cell = (s.pos[a] & 255) * p.W + (s.pos[a] >> 8);
+        const int oc = s.occ[cell], wb = s.wordbase[cell >> 6];  // one batch (the list is a handful of agents per lane:
+        const unsigned long long ab = s.agbits[cell >> 6];       // the chain's latency is what counts)
         short ni = -1;
-        if (s.occ[cell] == a) {
-            ni = (short)(s.wordbase[cell >> 6] + __popcll(s.agbits[cell >> 6] & lowmask(cell & 63)));
+        if (oc == a) {
+            ni = (short)(wb + __popcll(ab & lowmask(cell & 63)));
             s.order[ni] = (short)a;
         }
         s.newidx[a] = ni;
@@ -574,9 +576,11 @@ __device__ __forceinline__ void assign_order(const KParams& p, Smem& s, int nslo
 {
     for (int a = threadIdx.x; a < nslots; a += T) {
         const int cell = (s.pos[a] & 255) * p.W + (s.pos[a] >> 8);
+        const int oc = s.occ[cell], wb = s.wordbase[cell >> 6];  // one batch (the list is a handful of agents per lane:
+        const unsigned long long ab = s.agbits[cell >> 6];       // the chain's latency is what counts)
         short ni = -1;
-        if (s.occ[cell] == a) {
-            ni = (short)(s.wordbase[cell >> 6] + __popcll(s.agbits[cell >> 6] & lowmask(cell & 63)));
+        if (oc == a) {
+            ni = (short)(wb + __popcll(ab & lowmask(cell & 63)));
             s.order[ni] = (short)a;
         }
         s.newidx[a] = ni;
@@ -885,14 +889,16 @@ __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int
     // ---- _get_rewards over the _act list incl. vanished agents (environment.py:291-311) ------------------------------
     const int alive = s.scal[S_ALIVE];
     for (int a = tid; a < n0; a += T) {
+        const int fl = s.flags[a];
+        const double fit = s.fitness[a];
         const int kin = max(0, (int)(s.hcnt[s.hslot[a]] & 0xFFFFu) - 1);
         double r;
-        if (s.flags[a] & RL_F_DEAD) r = (double)(kin - alive);
+        if (fl & RL_F_DEAD) r = (double)(kin - alive);
         else if (alive == 1) r = 0.0;
         else r = (double)kin / (double)alive;
-        if ((s.flags[a] & RL_F_KILLED) && p.incentivize_killing) r += 0.2;
+        if ((fl & RL_F_KILLED) && p.incentivize_killing) r += 0.2;
         s.reward[a] = r;
-        s.fitness[a] += r;
+        s.fitness[a] = fit + r;
         if (!p.static_families && s.uid[a] >= 0)  // best_agents are references: their fitness tracks the live agent
             for (int b = 0; b < RL_N_BEST; ++b)
                 if (s.best_uid[b] == s.uid[a]) s.best_fit[b] = s.fitness[a];
@@ -1019,9 +1025,9 @@ __device__ __forceinline__ void reproduce_wave0(const KParams& p, Smem& s, int w
         const int k = base + lane;
         const bool act = k < n1;
         const int a = act ? s.order[k] : 0;
-        const int fl = act ? s.flags[a] : 0;
-        const bool e = act && room && !(fl & (RL_F_DEAD | RL_F_REPRODUCED)) && s.age[a] > 5;  // can_reproduce, entities.py:244
-        if (act && p.static_families && s.gene[a] >= 0 && s.gene[a] < RL_MAX_BRAINS) s.present[s.gene[a]] = 1;
+        const int fl = s.flags[a], age = s.age[a], ge = s.gene[a];  // one batch (slot 0 is always valid)
+        const bool e = act && room && !(fl & (RL_F_DEAD | RL_F_REPRODUCED)) && age > 5;  // can_reproduce, entities.py:244
+        if (act && p.static_families && ge >= 0 && ge < RL_MAX_BRAINS) s.present[ge] = 1;
         const unsigned long long em = __ballot(e);
         bool par = false;
         if (e) {
@@ -1171,8 +1177,9 @@ __device__ __forceinline__ void reproduce_wave0(const KParams& p, Smem& s, int w
     // see their cells as occupied; same wave, so no barrier in between
     for (int k = lane; k < n1; k += 64) {
         const int a = s.order[k];
-        if (s.flags[a] & RL_F_DEAD) {
-            const int cell = (s.pos[a] & 255) * p.W + (s.pos[a] >> 8);
+        const int fl = s.flags[a], ps = s.pos[a];  // one batch
+        if (fl & RL_F_DEAD) {
+            const int cell = (ps & 255) * p.W + (ps >> 8);
             s.type[cell] = RL_FOOD; s.occ[cell] = -1;
         }
     }
@@ -1661,8 +1668,10 @@ __global__ __launch_bounds__(T) void k_world(const KParams p_in)
             assign_order<T>(p, s, nslots);
             const int nsp = (nslots + 63) & ~63;  // whole waves take part in the gene aggregation
             for (int a = tid; a < nsp; a += T) {
-                const bool on = a < nslots && s.occ[(s.pos[a] & 255) * p.W + (s.pos[a] >> 8)] == a;
-                hash_insert_wave(s, p.hash_mask, on, a, on ? s.gene[a] : 0, 1u << 16);
+                const int aa = a < nslots ? a : 0;
+                const int ps = s.pos[aa], ge = s.gene[aa];  // one batch
+                const bool on = a < nslots && s.occ[(ps & 255) * p.W + (ps >> 8)] == a;
+                hash_insert_wave(s, p.hash_mask, on, a, on ? ge : 0, 1u << 16);
             }
         }
         build_planes<T>(p, s);
