@@ -17,7 +17,13 @@
 //   movement  Jacobi fixed point on an LDS target-count grid (one __syncthreads_or per iteration)
 //   vanish    a mover entering the cell of a later-ordered mover is erased (sequential grid overwrite)
 //   ordering  Grid.get_entities == rank of the agent's cell in a 64-bit-per-wave ballot bitmap (popcount prefix)
-//   set_random  k-th empty cell == select on the ballot bitmap of occupied cells, held in wave 0's registers
+//   set_random  k-th empty cell == select on the ballot bitmap of occupied cells, held in wave 0's registers; all births of
+//               a tick at once (ranks in the original list of empty cells by a recurrence, cells selected in parallel)
+//
+// Kernel variants (k_world<T, MODE, LEAN, FIXED>): LEAN = the fused inference tick (wave 0 runs the update's serial section
+// next to the other waves' observation pass, Philox draws precomputed by idle waves, a refill prepared ahead of time on
+// idle waves); FIXED = LEAN with the reference's default world shape (30x30, 100 agents) folded into constants.  A launch
+// lasts as long as its slowest world, so the tail of the per-world time matters as much as its mean.
 #include <stdlib.h>
 
 #include "rl_common.h"
