@@ -172,8 +172,10 @@ def cpu_baseline(args, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    # defaults: long enough to be past the start-up transient (every world starts with one cohort of 100 agents, so the first
+    # refills come in waves; the worlds drift apart within a few hundred ticks); 2,300 steps are ~80 ms of GPU time
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--worlds", type=int, default=256, help="worlds per GPU")
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=20260928)
