@@ -2,7 +2,10 @@
 """bench.py -- ReinLife hot-path throughput on MI355X: agent-steps/s (policy forward + env.step + update_env).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1: one process per GPU over RCCL.  Under torchrun (WORLD_SIZE set: python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N ... bench.py --gpus N ...) this process is one rank; started plainly with --gpus N > 1 it re-executes
+    itself under torch.distributed.run with N ranks.  The JSON carries `rccl_ranks` = the world size RCCL saw; a mismatch with
+    --gpus is an error, never a silent single-rank run.
 
 One "step" = one trainer-loop tick (Helpers/trainer.py:85-99 minus learn) of EVERY world on the GPU:
     policy forward + action selection for all agents  ->  rl_tick (step + update_env, fused)  ->  rl_refill
@@ -12,14 +15,19 @@ the Philox generator, a world is re-generated when its population drops below 70
 with NO data-path collective (weak scaling); RCCL is used once, for the final counter reduction.
 An agent-step = one live agent receiving an action and being advanced by one step().
 
+Before the warm-up the worlds are brought to their steady regime in untimed set-up (`--burnin`, 300 ticks: every world
+starts with one cohort of 100 agents, so without it the first refills come in synchronized waves), so any --steps window
+measures the same thing.
+
 Prints ONE JSON line (rank 0).  `value` counts the full tick (update_env included: more work than the metric's
-literal "env.step + policy fwd", never less).
+literal "env.step + policy fwd", never less); `variant_policy_plus_step` is the literal variant (i) of BASELINE.md 3
+(get_action + step, update_env untimed), measured with HIP events.  `cpu_baseline` = oracle/cpu_bench.py.
 """
 import argparse
 import json
 import os
 import sys
-import threading
+import subprocess
 import time
 
 import numpy as np
@@ -122,51 +130,29 @@ class StreamGroups:
             dw.check_error_flag()
 
 
-def cpu_baseline(args, seconds_target=12.0):
-    """The oracle (a CPU port of the reference path: policy forward + step + update_env) on the host cores, one
-    world range per thread, on a bounded sample of the same workload."""
-    from oracle import oracle as orc
+def cpu_baseline(args):
+    """The CPU port of the same path on the host cores (oracle/cpu_bench.py): one process per core, C world tick + batched
+    sgemm policy; world_only / policy_only / full_tick, single-thread and all-core, ~15 s in all."""
+    from oracle import cpu_bench
     wl = WORKLOADS[args.workload]
-    cores = max(1, min(os.cpu_count() or 1, 32))
-    R = cores
-    ow = orc.OracleWorlds(n_worlds=R, n_brains=len(wl["brains"]), static_families=wl["static_families"], seed=args.seed)
-    ow.reset_synthetic(100)
-    weights = [brain_weights(n, 100 + k) for k, n in enumerate(wl["brains"])]
-    kinds = [orc.KIND_BY_NAME[n] for n in wl["brains"]]
-    acts = np.zeros((R, ow.cap), np.int8)
-    counts = [0] * R
+    return cpu_bench.run(wl["brains"], wl["static_families"], args.seed, [brain_weights(n, 100 + k) for k, n in enumerate(wl["brains"])],
+                         cores=max(1, min(os.cpu_count() or 1, 64)))
 
-    def work(w, n_ticks):
-        for _ in range(n_ticks):
-            n = int(ow.s["n_agents"][w])
-            if n < 70:
-                ow.refill(70, 100, w, w + 1)
-                n = int(ow.s["n_agents"][w])
-            br = ow.s["a_brain"][w, :n]
-            for b, (kind, wts) in enumerate(zip(kinds, weights)):
-                idx = np.nonzero(br == b)[0]
-                if len(idx):
-                    q = orc.policy_forward(kind, wts, ow.obs2[w, idx])
-                    acts[w, idx] = q.argmax(1)
-            ow.step(acts, None, w, w + 1)
-            ow.update(None, w, w + 1)
-            counts[w] += n
 
-    t0 = time.time()
-    work(0, 3)  # calibrate
-    per_tick = (time.time() - t0) / 3
-    n_ticks = max(5, int(seconds_target / max(per_tick, 1e-6)))
-    counts = [0] * R
-    threads = [threading.Thread(target=work, args=(w, n_ticks)) for w in range(R)]
-    t0 = time.time()
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    dt = time.time() - t0
-    return {"value": round(sum(counts) / dt, 1), "unit": "agent-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d worlds (one per host thread) x %d ticks of the same workload through oracle/rl_oracle.c "
-                      "(policy forward + step + update_env), %.1f s" % (R, n_ticks, dt)}
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: run N ranks of this script, one per GPU."""
+    n_vis = torch.cuda.device_count()
+    if n_vis < args.gpus:
+        raise SystemExit("bench.py: --gpus %d but only %d GPUs are visible" % (args.gpus, n_vis))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -180,11 +166,16 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=20260928)
     ap.add_argument("--groups", type=int, default=1, help="split the GPU's worlds into this many stream groups (overlap)")
+    ap.add_argument("--burnin", type=int, default=300, help="untimed set-up ticks that de-synchronise the worlds' cohorts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world_size))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -198,6 +189,9 @@ def main():
             raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPUs visible" % (local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: RCCL sees %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
+    rccl_ranks = dist.get_world_size() if dist is not None else 1
     device = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)
 
@@ -209,6 +203,9 @@ def main():
         grp = None
         dw = make_worlds(args, rank, device)
         step_all = lambda: one_step(dw)  # noqa: E731
+    for _ in range(args.burnin):   # set-up, untimed: past the start-up transient (see the module docstring)
+        step_all()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step_all()
     torch.cuda.synchronize()
@@ -287,6 +284,26 @@ def main():
                     "agent_steps_per_launch": round(per_launch, 1)}
         roofline = tick_roof if t_tick >= t_act else pol_roof
         extra = {"roofline_tick": tick_roof, "roofline_policy": pol_roof}
+        # variant (i) of BASELINE.md 3 / SURVEY.md 8d: "get_action + step" only.  The loop still runs update_env + refill (the
+        # world must go on), but only policy + rl_step lie between the event pairs.
+        if args.groups == 1:
+            n_var = 40
+            ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(n_var)]
+            for i in range(3 + n_var):
+                k = i - 3
+                if k >= 0:
+                    ev2[k][0].record()
+                dw.act(); dw.step()
+                if k >= 0:
+                    ev2[k][1].record()
+                dw.update(); dw.refill(70, 100)
+            torch.cuda.synchronize()
+            n_act = dw.n_acted.sum().item()  # agents of the last step (steady regime: the per-step count varies by < 1 %)
+            t_ps = float(np.median([e[0].elapsed_time(e[1]) for e in ev2])) * 1e-3
+            extra["variant_policy_plus_step"] = {
+                "value": round(n_act / t_ps, 1), "unit": "agent-steps/s", "us_per_step": round(t_ps * 1e6, 2),
+                "what": "rl_policy_act + rl_step (Environment.step, un-fused kernel) between HIP events; update_env + refill run untimed "
+                        "between the pairs; 1 GPU (rank 0)"}
 
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
@@ -299,6 +316,7 @@ def main():
             "value": round(total_agent_steps / elapsed, 1),
             "unit": "agent-steps/s",
             "n_gpus": args.gpus,
+            "rccl_ranks": rccl_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
@@ -309,7 +327,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["name"], "worlds_per_gpu": args.worlds, "worlds_total": args.worlds * max(1, world_size),
                        "stream_groups": args.groups, "grid": "30x30", "max_agents": 100, "brains": wl["brains"], "static_families": wl["static_families"],
-                       "refill_below": 70, "includes_update_env": True,
+                       "refill_below": 70, "includes_update_env": True, "burn_in_ticks": args.burnin,
                        "mean_agents_per_world": round(total_agent_steps / (args.steps * args.worlds * max(1, world_size)), 2),
                        "world_refills": int(refills), "parallelism": "replica-sharded x%d, no data-path collective" % max(1, world_size)},
             "roofline": roofline,

@@ -2,7 +2,11 @@
 
 The loop is the reference's (get_action -> step -> learn -> update_env, trainer.py:85-99) with get_action batched on the
 GPU through env.act().  A single world (rng="reference", the default for n_worlds == 1) makes every random draw of the
-loop exactly as the reference does, so the same seeds give the same run; replicated worlds draw in-kernel.  learn() is accepted but inference-only brains ignore it (training is outside this build's scope)."""
+loop exactly as the reference does, so the same seeds give the same run; replicated worlds draw in-kernel.
+
+INFERENCE ONLY: training=True (the reference's default) keeps the loop, the epsilon schedules and the Tracker, but the brains
+of this build do not learn -- Environment warns about it, and save=True writes the weights as they were loaded / initialised
+(settings.json says so).  Training is outside this build's scope (BASELINE.json north_star)."""
 from ..World.environment import Environment
 
 

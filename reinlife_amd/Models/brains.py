@@ -58,7 +58,10 @@ class _HipBrain(BasicBrain):
         return np.concatenate([p.detach().cpu().numpy().astype(np.float32).reshape(-1) for p in self._net().state_dict().values()])
 
     def packed_weights(self, device="cuda:0"):
-        key = (str(device),)
+        """Packed MFMA layout of the current parameters on `device`, cached.  The cache key carries every parameter's storage
+        address and in-place version counter, so load_state_dict(), optimizer steps, target/eval syncs or a replaced module
+        repack automatically at the next use."""
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self._net().state_dict().values())
         if getattr(self, "_packed_key", None) != key:
             from ..worlds import pack_brain_weights
             self._packed = pack_brain_weights(self.kind, self.state_dict_flat(), device)

@@ -21,16 +21,32 @@ from ..worlds import DeviceWorlds
 from .utils import Actions, EntityTypes
 
 
-class AgentView:
-    """One entry of env.agents: the reference's Agent attributes (entities.py:131-170) read from the device state."""
+class _WorldMirror:
+    """Host copy of ONE world's agent list and per-agent outputs, in env.agents order (refreshed after every step / update)."""
 
-    def __init__(self, env, k):
+    def __init__(self, world):
+        self.world = world
+        self.host = None            # {"a_i": ..., ...}
+        self.state = None           # [n,153] float64: Agent.state
+        self.state_prime = None     # [n,153] or None (between update_env and the next step)
+        self.reward = self.done = None
+        self.actions = None         # [cap] int8
+        self.dirty = False          # actions were set through AgentView.action and are not on the device yet
+        self.views = None           # the AgentView list handed out by agents_of()
+
+
+class AgentView:
+    """One entry of env.agents / env.agents_of(world): the reference's Agent attributes (entities.py:131-170) read from the
+    device state of that world."""
+
+    def __init__(self, env, k, mirror=None):
         self._env, self._k = env, k
+        self._m = mirror if mirror is not None else env._mirror0
         self.prob = None
         self.info = ""
 
     def _f(self, name):
-        return self._env._host["a_" + name][self._k]
+        return self._m.host["a_" + name][self._k]
 
     i = property(lambda s: int(s._f("i")))
     j = property(lambda s: int(s._f("j")))
@@ -50,28 +66,28 @@ class AgentView:
 
     @property
     def action(self):
-        return int(self._env._actions_host[self._k])
+        return int(self._m.actions[self._k])
 
     @action.setter
     def action(self, a):
-        self._env._actions_host[self._k] = int(a)
-        self._env._actions_dirty = True
+        self._m.actions[self._k] = int(a)
+        self._m.dirty = True
 
     @property
     def state(self):
-        return self._env._state_host[self._k]
+        return self._m.state[self._k]
 
     @property
     def state_prime(self):
-        return self._env._state_prime_host[self._k] if self._env._state_prime_host is not None else self.state
+        return self._m.state_prime[self._k] if self._m.state_prime is not None else self.state
 
     @property
     def reward(self):
-        return float(self._env._reward_host[self._k]) if self._env._reward_host is not None else None
+        return float(self._m.reward[self._k]) if self._m.reward is not None else None
 
     @property
     def done(self):
-        return bool(self._env._done_host[self._k]) if self._env._done_host is not None else False
+        return bool(self._m.done[self._k]) if self._m.done is not None else False
 
     def get_action(self, n_epi, out=None):  # entities.py:215-222
         b = self.brain
@@ -81,9 +97,20 @@ class AgentView:
         else:
             self.action = b.get_action(self.state, n_epi, out=out)
 
-    def learn(self, **kwargs):  # entities.py:194-208: training is outside this build's scope
+    def learn(self, **kwargs):
+        """entities.py:194-208: the keyword set the reference hands to brain.learn, per brain method (caller kwargs such as
+        n_epi only reach the brains the reference forwards them to).  The brains of this build ignore learn() (training is
+        outside its scope); a subclass that overrides learn() receives the reference's arguments."""
         if self.age > 1:
-            self.brain.learn(**kwargs)
+            common = dict(age=self.age, dead=self.dead, action=self.action, state=self.state, reward=self.reward,
+                          state_prime=self.state_prime, done=self.done)
+            method = self.brain.method
+            if method == "PPO":
+                self.brain.learn(prob=self.prob, **common)
+            elif method in ("DQN", "A2C", "PERDQN"):
+                self.brain.learn(**common)
+            else:  # DRQN, D3QN, PERD3QN, ...
+                self.brain.learn(**common, **kwargs)
 
 
 class Environment:
@@ -126,11 +153,21 @@ class Environment:
         self.tracker = Tracker(update_interval=update_interval, interactive=False, print_results=print_results, nr_genes=len(brains),
                                static_families=static_families, brains=brains, worlds=self.worlds if training else None)
         self.agents = []
-        self._host = None
-        self._state_prime_host = self._reward_host = self._done_host = None
-        self._actions_host = np.full(self.worlds.cap, -1, np.int8)
-        self._actions_dirty = False
+        self._mirror0 = _WorldMirror(0)
+        self._mirror0.actions = np.full(self.worlds.cap, -1, np.int8)
+        self._mirrors = {}          # world -> _WorldMirror of replicas other than 0, built on demand (agents_of)
+        self._phase = "update"
         self._brains_bound = False
+        if training:
+            warn_inference_only()
+
+    # world 0's mirror under the names the rest of this class (and older callers) use
+    _host = property(lambda s: s._mirror0.host)
+    _state_host = property(lambda s: s._mirror0.state, lambda s, v: setattr(s._mirror0, "state", v))
+    _state_prime_host = property(lambda s: s._mirror0.state_prime, lambda s, v: setattr(s._mirror0, "state_prime", v))
+    _reward_host = property(lambda s: s._mirror0.reward, lambda s, v: setattr(s._mirror0, "reward", v))
+    _done_host = property(lambda s: s._mirror0.done, lambda s, v: setattr(s._mirror0, "done", v))
+    _actions_host = property(lambda s: s._mirror0.actions, lambda s, v: setattr(s._mirror0, "actions", v))
 
     # -- brains -------------------------------------------------------------------------------------------------
     def _bind_brains(self):
@@ -139,12 +176,15 @@ class Environment:
 
     # -- reference protocol ---------------------------------------------------------------------------------------
     def reset(self):
-        """environment.py:133-158.  World 0 (and every replica when n_worlds == 1) follows the reference's np.random
-        draw order exactly; further replicas come from the Philox generator."""
-        if self.n_worlds > 1:  # replicas 1..: Philox generator worlds with len(brains) agents (random genes)
-            self.worlds.reset_synthetic(len(self.brains))
+        """environment.py:133-158.  World 0 follows the reference's np.random draw order exactly; further replicas are built
+        by the same rule from their own generators."""
         snap = host_reset(self.width, self.height, len(self.brains))
         self.worlds.load_world(0, snap)
+        # replicas 1..: the same construction (one agent per brain, gene = its index; environment.py:147-149), each from its
+        # own generator keyed by (seed, global replica id) so that world 0 alone consumes the process-global np.random
+        for w in range(1, self.n_worlds):
+            rs = np.random.RandomState((int(self.worlds.cfg.seed) * 1_000_003 + int(self.worlds.cfg.world_base) + w) % (2 ** 32))
+            self.worlds.load_world(w, host_reset(self.width, self.height, len(self.brains), rng=rs))
         self.max_gene = len(self.brains)
         self.worlds.observe()
         self._refresh(after="update")
@@ -171,16 +211,21 @@ class Environment:
             b.update_epsilon(n_epi)
         self._bind_brains()
         self.worlds.act()
-        self._actions_host = self.worlds.actions[0].cpu().numpy().copy()
-        self._actions_dirty = False
+        self._mirror0.actions = self.worlds.actions[0].cpu().numpy().copy()
+        self._mirror0.dirty = False
+        for w, m in self._mirrors.items():
+            m.actions = self.worlds.actions[w].cpu().numpy().copy()
+            m.dirty = False
 
     def step(self):
         """environment.py:160-186"""
-        if self._actions_dirty:
+        dirty = [m for m in [self._mirror0] + list(self._mirrors.values()) if m.dirty]
+        if dirty:
             full = self.worlds.actions.cpu().numpy()
-            full[0] = self._actions_host
+            for m in dirty:
+                full[m.world] = m.actions
+                m.dirty = False
             self.worlds.set_actions(full)
-            self._actions_dirty = False
         if self.rng == "reference":
             nf, npo, ns, ne = self.worlds.step_split()[0].tolist()
             self.worlds.step_food(self.worlds.make_tape([self._draw_add_food(nf, npo, ns, ne)]))
@@ -275,7 +320,9 @@ class Environment:
         """environment.py:233-256: brains + parameters + results.json + settings.json in the reference's layout."""
         from ..Helpers.saver import SavedAgent, Saver
         settings = {"Update interval": self.tracker.update_interval, "Width": self.width, "Height": self.height,
-                    "Max agents": self.max_agents, "Families": self.static_families}
+                    "Max agents": self.max_agents, "Families": self.static_families,
+                    # (extra key, not in the reference's file) this build never updates weights: say so next to them
+                    "Weights": "as loaded / initialised -- reinlife_amd runs inference only, learn() is a no-op"}
         if self.static_families:
             agents = [SavedAgent(g, b) for g, b in enumerate(self.brains)]
         else:  # the brains the best agents descend from (inference-time copies share their weights)
@@ -284,12 +331,40 @@ class Environment:
         return Saver(main_folder, google_colab=self.google_colab).save(agents, self.static_families, self.tracker.results, settings)
 
     # -- host mirror of world 0 --------------------------------------------------------------------------------------
+    def agents_of(self, world):
+        """env.agents of replica `world` (row-major list of AgentView): the same protocol as env.agents, which is world 0's.
+        Views are valid until the next step() / update_env()."""
+        if world == 0:
+            return self.agents
+        if not 0 <= world < self.n_worlds:
+            raise IndexError("world %d of %d" % (world, self.n_worlds))
+        m = self._mirrors.get(world)
+        if m is None:
+            w = self.worlds
+            m = _WorldMirror(world)
+            n = int(w.s["n_agents"][world].item())
+            m.host = {k: w.s[k][world, :n].cpu().numpy() for k in w.s if k.startswith("a_")}
+            if self._phase == "step":   # Agent.state is still the observation the policy read, in the pre-step order
+                src = w.src1[world, :n].cpu().numpy().astype(np.int64)
+                m.state = w.obs_state()[world].cpu().numpy().astype(np.float64)[src]
+                m.state_prime = w.obs_state_prime()[world, :n].cpu().numpy().astype(np.float64)
+                m.reward = w.reward[world, :n].cpu().numpy()
+                m.done = w.done[world, :n].cpu().numpy()
+            else:
+                m.state = w.obs_state()[world, :n].cpu().numpy().astype(np.float64)
+            m.actions = np.concatenate([m.host["a_action"], np.full(w.cap - n, -1, np.int8)])
+            m.views = [AgentView(self, k, m) for k in range(n)]
+            self._mirrors[world] = m
+        return m.views
+
     def _refresh(self, after):
         w = self.worlds
         torch.cuda.synchronize(w.device)
         w.check_error_flag()
+        self._phase = after
+        self._mirrors = {}
         n = int(w.s["n_agents"][0].item())
-        self._host = {k: w.s[k][0, :n].cpu().numpy() for k in w.s if k.startswith("a_")}
+        self._mirror0.host = {k: w.s[k][0, :n].cpu().numpy() for k in w.s if k.startswith("a_")}
         self.max_gene = int(w.s["max_gene"][0].item())
         self.grid = w.s["cell_type"][0].cpu().numpy().reshape(self.height, self.width)
         if after == "step":
@@ -307,9 +382,19 @@ class Environment:
         self.agents = [AgentView(self, k) for k in range(n)]
 
 
-def host_reset(width, height, n_brains):
+def warn_inference_only():
+    import warnings
+    warnings.warn("reinlife_amd runs ReinLife's per-tick path (world tick + policy inference) only: training=True keeps the "
+                  "reference's loop, epsilon schedules and Tracker, but brain.learn() is a no-op and the brains' weights are NOT "
+                  "updated; results saved from such a run hold the initial (untrained) weights.  Train with the reference, or feed "
+                  "DeviceWorlds.enable_capture() / capture_transitions() to your own learner.", stacklevel=3)
+
+
+def host_reset(width, height, n_brains, rng=None):
     """Environment.reset's world construction with the reference's exact global-np.random draw order
-    (environment.py:147-154 -> _add_agent :483-484 -> Grid.set_random grid.py:69-83; _init_food :741-761)."""
+    (environment.py:147-154 -> _add_agent :483-484 -> Grid.set_random grid.py:69-83; _init_food :741-761).  `rng`: a
+    np.random.RandomState to draw from instead of the process-global generator (replicas other than world 0)."""
+    rnd = rng if rng is not None else np.random
     C = width * height
     grid = np.zeros(C, np.uint8)
     agents = []
@@ -318,8 +403,8 @@ def host_reset(width, height, n_brains):
         empties = np.nonzero(grid == _lib.EMPTY)[0]  # row-major, like np.where on the 2-D grid
         if len(empties) == 0:
             return None
-        k = np.random.randint(0, len(empties))
-        if np.random.random() < p:
+        k = rnd.randint(0, len(empties))
+        if rnd.random_sample() < p:
             grid[empties[k]] = kind
             return int(empties[k])
         return None
@@ -330,7 +415,7 @@ def host_reset(width, height, n_brains):
             agents.append((cell, g))
     for kind, prob in ((_lib.FOOD, 0.1), (_lib.POISON, 0.05)):
         for _ in range(C):
-            if np.random.random() < prob:
+            if rnd.random_sample() < prob:
                 set_random(kind, 1)
     set_random(_lib.SUPER_FOOD, 1)
     order = sorted(range(len(agents)), key=lambda a: agents[a][0])

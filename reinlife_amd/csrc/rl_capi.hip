@@ -27,6 +27,25 @@ int rl_policy_act_impl(rl_world*, const rl_brain*, int, const float*, int8_t*, f
 
 static thread_local char g_err[512] = "";
 
+// The device a handle's buffers live on (taken from the state pointers in rl_bind_state).  Every launching entry point
+// makes it current for the duration of the call, so a caller whose current device is another GPU (several handles on
+// several GPUs in one process) still launches in the right context.
+static int device_of_pointer(const void* p)
+{
+    hipPointerAttribute_t a;
+    if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged ? a.device : -1;
+}
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev)
+    {
+        int cur = -1;
+        if (dev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 void rl_set_error(const char* fmt, ...)
 {
     va_list ap;
@@ -85,6 +104,7 @@ int rl_bind_state(rl_world* h, const rl_state* s)
     for (size_t i = 0; i < sizeof(rl_state) / sizeof(void*); ++i)
         if (!p[i]) { rl_set_error("rl_bind_state: state pointer #%zu is null", i); return RL_E_INVALID; }
     h->st = *s;
+    h->device = device_of_pointer(s->cell_type);  // -1 (no guard) when it cannot be determined
     h->bound = 1;
     h->lists_valid = 0;  // the caller may have rewritten the state
     return RL_OK;
@@ -113,7 +133,8 @@ int rl_bind_policy_work(rl_world* h, void* work)
 
 #define RL_CHECK_BOUND(fn)                                                              \
     if (!h) { rl_set_error(fn ": null handle"); return RL_E_INVALID; }                 \
-    if (!h->bound) { rl_set_error(fn ": rl_bind_state was not called"); return RL_E_UNBOUND; }
+    if (!h->bound) { rl_set_error(fn ": rl_bind_state was not called"); return RL_E_UNBOUND; }  \
+    DeviceGuard rl_guard_(h->device);
 
 int rl_reset_synthetic(rl_world* h, int n_agents, float* obs, void* stream)
 {
@@ -231,6 +252,7 @@ int rl_policy_forward(int kind, const float* packed, const float* obs, int64_t n
     if (!packed || !obs || !out || n_rows < 0) { rl_set_error("rl_policy_forward: bad argument"); return RL_E_INVALID; }
     if (kind < RL_DQN || kind > RL_PPO) { rl_set_error("rl_policy_forward: unknown brain kind %d", kind); return RL_E_INVALID; }
     if (n_rows == 0) return RL_OK;
+    DeviceGuard guard(device_of_pointer(obs));
     return rl_policy_forward_impl(kind, packed, obs, n_rows, out, (hipStream_t)stream);
 }
 

@@ -9,6 +9,7 @@ struct rl_world {
     rl_config cfg;
     rl_state st;
     int bound;
+    int device;          // HIP device the state buffers live on (-1: unknown)
     int32_t* err_flag;   // device, optional
     int cells;           // width*height
     int cpad;            // cells rounded up to 64

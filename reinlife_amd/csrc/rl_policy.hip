@@ -11,22 +11,18 @@
 // chain per tile and 4x more waves than one-wave-per-tile, which is what matters at 256 worlds = ~700 tiles on
 // 1024 SIMDs), activations cross waves through LDS once per layer:
 //
-//   * fp32 results from the bf16 matrix pipe ("3 x bf16"): every f32 operand is split into three bf16 parts
-//     x = hi + mid + lo (8 + 8 + 8 mantissa bits, each part the round-to-nearest bf16 of the remaining residual, so the
-//     three parts carry the whole 24-bit f32 mantissa) and a product is the sum of the six partial products of weight
-//     2^-16 or more (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi), each EXACT in the f32 accumulator of
-//     v_mfma_f32_32x32x16_bf16.  The dropped terms are below 2^-23 relative -- the size of f32's own rounding -- so the
-//     result is f32-grade (measured error vs torch ~1e-6, the bar is 1e-5) at 6 x 32 cycles per 16 k instead of
-//     8 x 64 with v_mfma_f32_32x32x2_f32: 2.7x the f32 matrix rate.  Weights are split once when packed, activations
-//     once where they are produced (observation staging / layer output), so the split costs a few VALU ops per value.
+//   * f32-grade results from the f16 matrix pipe ("2 x f16, block-scaled"): every operand row is scaled by a power of two,
+//     split into two f16 parts x = hi + lo, and a product is hi.hi + hi.lo + lo.hi -- three v_mfma_f32_32x32x16_f16 per 16 k
+//     with f32 accumulation.  The scheme, its error bound and its history are described in rl_policy_dev.h.
 //   * transposed formulation  H_out[feature][row] = W[feature][k] . H_in[k][row]: the WEIGHTS are the MFMA A operand
 //     and the ACTIVATIONS the B operand.  The 32x32 f32 accumulator layout (lane = row, register r of half h =
 //     feature (r&3) + 8(r>>2) + 4h) is dtype-independent, so a lane's registers 8c..8c+7 are exactly its 8 B-operand
 //     values of K-chunk (tile, c) of the next layer when the next layer's weights are packed in that k order:
 //     activations are never transposed; the weights are pre-packed so every A fragment is one coalesced
 //     16-byte-per-lane load (rl_policy_pack_weights).
-//   * the narrow heads (8 / 1 outputs) run on the VALU (an MFMA tile would be 75-97 % padding), followed by the
-//     dueling combine / softmax and the epsilon-greedy / categorical draw (Philox) in the same kernel.
+//   * the narrow heads (8 / 1 outputs) also run on the matrix pipe (head rows = A operand padded to 32, the wave's own
+//     activation registers = B operand), followed by the dueling combine / softmax and the epsilon-greedy / categorical
+//     draw (Philox) in the same kernel.
 #include "rl_policy_dev.h"
 #include <math.h>
 #include <string.h>
@@ -431,8 +427,11 @@ int rl_policy_act_impl(rl_world* h, const rl_brain* brains, int n_brains, const 
         if (e != hipSuccess) { rl_set_error("bucket kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
         if (h->work == work) { h->lists_valid = 1; h->lists_parity = cur; }
     }
-    // every live agent: populations are bounded by 2*max_agents+1 (environment.py:501 snapshot rule)
-    const int64_t bound = (int64_t)R * (int64_t)(2 * h->cfg.max_agents + 2 < cap ? 2 * h->cfg.max_agents + 2 : cap);
+    // One brain can own every slot of every world: the reference bounds a RUNNING population by 2*max_agents+1
+    // (environment.py:501 snapshot rule), but rl_reset_synthetic / a state written by the caller may hold up to slot_cap agents
+    // of one brain, and a tile beyond the grid would silently keep its stale action.  Workgroups beyond a brain's row count
+    // exit at once (~0.1 us per thousand).
+    const int64_t bound = (int64_t)R * (int64_t)cap;
     const int64_t expected = (int64_t)R * h->cfg.max_agents;  // populations hover around max_agents
     auto base_args = [&]() {
         PolicyArgs a{};

@@ -28,8 +28,8 @@
 //     values of K-chunk (tile, c) of the next layer when the next layer's weights are packed in that k order:
 //     activations are never transposed; the weights are pre-packed so every A fragment is one coalesced
 //     16-byte-per-lane load (rl_policy_pack_weights).
-//   * the narrow heads (8 / 1 outputs) run on the VALU (an MFMA tile would be 75-97 % padding), followed by the
-//     dueling combine / softmax and the epsilon-greedy / categorical draw (Philox) in the same kernel.
+//   * the narrow heads (8 / 1 outputs) also run on the matrix pipe (head_mfma), followed by the dueling combine / softmax
+//     and the epsilon-greedy / categorical draw (Philox) in the same kernel.
 #pragma once
 #include "rl_common.h"
 

@@ -1842,7 +1842,8 @@ __global__ __launch_bounds__(T) void k_reset(const KParams p)
 // (throughput-bound: several worlds per CU hide each other's barriers).
 inline int pick_block(const rl_world* h)
 {
-    static const int forced = getenv("RL_WORLD_BLOCK") ? atoi(getenv("RL_WORLD_BLOCK")) : 0;
+    const char* env = getenv("RL_WORLD_BLOCK");  // read at every launch (like RL_WORLD_GENERIC): tests and A/B runs switch it
+    const int forced = env ? atoi(env) : 0;
     if (forced == 256 || forced == 512 || forced == 1024) return forced;
     return h->cfg.n_worlds <= 768 ? 1024 : 256;
 }
@@ -1988,8 +1989,14 @@ int rl_world_block() { return 1024; }
 
 int rl_world_prepare_bytes(size_t bytes)
 {
-    // worlds that need more than the default 64 KB dynamic-LDS window opt in (160 KB per CU on gfx950)
-    static size_t granted = 64 * 1024;
+    // worlds that need more than the default 64 KB dynamic-LDS window opt in (160 KB per CU on gfx950); the attribute
+    // belongs to the device's copy of the kernel, so the grant is remembered per device
+    constexpr int kMaxDev = 64;
+    static size_t granted_dev[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
+    size_t& granted = granted_dev[dev];
+    if (granted < 64 * 1024) granted = 64 * 1024;
     if (bytes <= granted) return RL_OK;
     hipError_t e = hipSuccess;
 #define RL_ATTR(K) e = e != hipSuccess ? e : hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -2061,7 +2068,9 @@ int rl_world_launch_reset(rl_world* h, int n_agents, int threshold, float* obs, 
     set_list_production(h, p, true);
     p.reset_n_agents = n_agents; p.refill_threshold = threshold; p.obs_only = obs; p.refill_count = refill_count;
     if (int rc = rl_world_prepare_bytes(h->smem_bytes)) return rc;
-    if (pick_block(h) == 1024) hipLaunchKernelGGL((k_reset<1024>), dim3(h->cfg.n_worlds), dim3(1024), h->smem_bytes, st, p);
+    const int blk = pick_block(h);
+    if (blk == 1024) hipLaunchKernelGGL((k_reset<1024>), dim3(h->cfg.n_worlds), dim3(1024), h->smem_bytes, st, p);
+    else if (blk == 512) hipLaunchKernelGGL((k_reset<512>), dim3(h->cfg.n_worlds), dim3(512), h->smem_bytes, st, p);
     else hipLaunchKernelGGL((k_reset<256>), dim3(h->cfg.n_worlds), dim3(256), h->smem_bytes, st, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rl_set_error("reset kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }

@@ -102,3 +102,22 @@ def test_oracle_synthetic_reset_and_free_run():
             assert (ow.s["cell_type"][w].reshape(-1)[cells] == orc.AGENT).all()
             assert (ow.s["cell_type"][w] == orc.AGENT).sum() == n
     assert ow.refill(70, 100) >= 0
+
+
+def test_oracle_forward_matches_the_reference_on_its_pretrained_brains():
+    """The reference's own trained brains (pretrained/All/*, loaded by the real reference through load_model= in
+    oracle/gen_golden_pretrained.py): f32 forward within 1e-5 of the output scale (trained Q values reach ~30), and the
+    batched numpy forward of the CPU baseline agrees too."""
+    import json
+    from oracle import cpu_bench
+    p = np.load(golden_io.GOLDEN_DIR + "/pretrained.npz")
+    meta = json.loads(bytes(p["meta"]).decode())
+    keys = json.load(open(golden_io.GOLDEN_DIR + "/state_dict_keys.json"))
+    for name in ("DQN", "D3QN", "PERD3QN", "PPO"):
+        assert meta[name]["keys"] == keys[name], name   # the .pt files carry exactly the key names / shapes the brains expose
+        want = p[name + "_out"]
+        scale = max(1.0, float(np.abs(want).max()))
+        out = orc.policy_forward(orc.KIND_BY_NAME[name], p[name + "_weights"], p["obs"])
+        np.testing.assert_allclose(out / scale, want / scale, rtol=0, atol=1e-5, err_msg=name)
+        out2 = cpu_bench.forward(name, cpu_bench.unpack(name, p[name + "_weights"]), p["obs"])
+        np.testing.assert_allclose(out2 / scale, want / scale, rtol=0, atol=1e-5, err_msg=name + " (numpy)")
