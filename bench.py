@@ -329,7 +329,7 @@ def main():
                        "stream_groups": args.groups, "grid": "30x30", "max_agents": 100, "brains": wl["brains"], "static_families": wl["static_families"],
                        "refill_below": 70, "includes_update_env": True, "burn_in_ticks": args.burnin,
                        "mean_agents_per_world": round(total_agent_steps / (args.steps * args.worlds * max(1, world_size)), 2),
-                       "world_refills": int(refills), "parallelism": "replica-sharded x%d, no data-path collective" % max(1, world_size)},
+                       "world_refills": int(refills), "agent_steps": int(round(total_agent_steps)), "parallelism": "replica-sharded x%d, no data-path collective" % max(1, world_size)},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -185,6 +185,27 @@ int rl_tick(rl_world* h, const int8_t* actions, const rl_tape* tape, const rl_st
 int rl_tick_refill(rl_world* h, const int8_t* actions, const rl_step_out* sout, const rl_update_out* uout,
                    int threshold, int n_agents, int32_t* refill_count, void* stream);
 
+/* n_ticks iterations of the inference loop of Helpers/trainer.py:85-99 (minus learn) in ONE launch:
+ *     for agent in env.agents: agent.get_action(n_epi)   (= rl_policy_act)      trainer.py:88-89
+ *     env.step(); env.update_env(n_epi)                  (= rl_tick_refill)     trainer.py:92,99
+ * Every world stays in its workgroup's LDS for the whole launch; the results are those of n_ticks calls of rl_policy_act +
+ * rl_tick_refill (same Philox streams), and every per-tick output is written every tick, so after the call the buffers hold
+ * the LAST tick's values:
+ *   actions     [R][cap]      the actions chosen in the last tick (its pre-step list order)
+ *   sout        reward / done / src / obs (state_prime) / n_acted / acted_total as in rl_tick (tracker and capture outputs
+ *               are not supported here: RL_E_UNSUPPORTED)
+ *   obs[2]      Agent.state ping-pong pair: tick i READS obs[(first_obs + i) & 1] (the policy's input; for i = 0 it must hold
+ *               the current Agent.state rows) and WRITES the other one; after the call the current rows are in
+ *               obs[(first_obs + n_ticks) & 1] and the rows the policy read for the last tick in the other buffer
+ *   update_src  [R][cap] or NULL: rl_update_out.src of the last tick
+ *   threshold   < 0: no re-generation; else worlds below `threshold` agents are re-generated with n_agents (rl_refill)
+ * Supported (rl_run_supported() != 0): brains all of the dueling kinds (RL_D3QN / RL_PERD3QN), n_brains <= 8, slot_cap <= the
+ * workgroup size (1024; 256 when n_worlds > 768).  Otherwise RL_E_UNSUPPORTED: loop over rl_policy_act + rl_tick_refill. */
+int rl_run_supported(const rl_world* h, const rl_brain* brains, int n_brains);
+int rl_run(rl_world* h, const rl_brain* brains, int n_brains, int n_ticks, int8_t* actions, const rl_step_out* sout,
+           float* const obs[2], int first_obs, int16_t* update_src, int threshold, int n_agents, int32_t* refill_count,
+           void* stream);
+
 /* trainer.py:95-96 for every world: agents of the post-step list with age > 1 append (state, action, reward,
  * state_prime, done[, prob]) to the replay ring of their brain.
  *   state      [R][cap][153] the observation buffer the policy read for this tick (keep it: ping-pong rl_update_out.obs)

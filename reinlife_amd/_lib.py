@@ -76,6 +76,8 @@ ABI = [
     ("rl_update", C.c_int, [_P, C.POINTER(Tape), C.POINTER(UpdateOut), _P]),
     ("rl_tick", C.c_int, [_P, _P, C.POINTER(Tape), C.POINTER(StepOut), C.POINTER(UpdateOut), _P]),
     ("rl_tick_refill", C.c_int, [_P, _P, C.POINTER(StepOut), C.POINTER(UpdateOut), C.c_int, C.c_int, _P, _P]),
+    ("rl_run_supported", C.c_int, [_P, C.POINTER(Brain), C.c_int]),
+    ("rl_run", C.c_int, [_P, C.POINTER(Brain), C.c_int, C.c_int, _P, C.POINTER(StepOut), C.POINTER(_P), C.c_int, _P, C.c_int, C.c_int, _P, _P]),
     ("rl_capture_transitions", C.c_int, [_P, _P, _P, _P, C.POINTER(StepOut), C.POINTER(Replay), C.c_int, _P]),
     ("rl_policy_n_params", C.c_int64, [C.c_int]),
     ("rl_policy_packed_floats", C.c_int64, [C.c_int]),

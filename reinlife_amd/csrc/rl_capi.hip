@@ -18,6 +18,8 @@ int rl_world_launch_tick(rl_world*, const int8_t*, const rl_tape*, const rl_step
 int rl_world_launch_observe(const rl_world*, float*, hipStream_t);
 int rl_world_launch_reset(rl_world*, int, int, float*, int32_t*, hipStream_t);
 int rl_world_launch_capture(rl_world*, const float*, const int8_t*, const float*, const rl_step_out*, const rl_replay*, int, hipStream_t);
+int rl_world_run_supported(const rl_world*, const rl_brain*, int);
+int rl_world_launch_run(rl_world*, const rl_brain*, int, int, int8_t*, const rl_step_out*, float* const*, int, int16_t*, int, int, int32_t*, hipStream_t);
 int64_t rl_policy_n_params_impl(int);
 int64_t rl_policy_packed_floats_impl(int);
 int rl_policy_pack_impl(int, const float*, float*);
@@ -223,6 +225,30 @@ int rl_tick_refill(rl_world* h, const int8_t* actions, const rl_step_out* sout, 
     if (threshold < 0 || n_agents < 0 || n_agents > h->cfg.slot_cap || n_agents > h->cells) { rl_set_error("rl_tick_refill: bad arguments"); return RL_E_INVALID; }
     if (int rc = check_step_out(sout, "rl_tick_refill")) return rc;
     return rl_world_launch_tick(h, actions, nullptr, sout, uout, threshold, n_agents, refill_count, (hipStream_t)stream);
+}
+
+int rl_run_supported(const rl_world* h, const rl_brain* brains, int n_brains)
+{
+    if (!h || !brains) return 0;
+    return rl_world_run_supported(h, brains, n_brains);
+}
+
+int rl_run(rl_world* h, const rl_brain* brains, int n_brains, int n_ticks, int8_t* actions, const rl_step_out* sout,
+           float* const obs[2], int first_obs, int16_t* update_src, int threshold, int n_agents, int32_t* refill_count, void* stream)
+{
+    RL_CHECK_BOUND("rl_run")
+    if (!brains || !actions || !obs || !obs[0] || !obs[1]) { rl_set_error("rl_run: null argument"); return RL_E_INVALID; }
+    if (n_brains != h->cfg.n_brains) { rl_set_error("rl_run: n_brains %d != config %d", n_brains, h->cfg.n_brains); return RL_E_INVALID; }
+    if (n_ticks < 0 || (first_obs != 0 && first_obs != 1)) { rl_set_error("rl_run: bad n_ticks / first_obs"); return RL_E_INVALID; }
+    if (threshold >= 0 && (n_agents < 0 || n_agents > h->cfg.slot_cap || n_agents > h->cells)) { rl_set_error("rl_run: bad refill arguments"); return RL_E_INVALID; }
+    if (sout && (sout->trk_tick || sout->trk_sum || sout->trk_cnt || sout->trk_pop || sout->n_post || sout->age || sout->brain)) {
+        rl_set_error("rl_run: tracker / capture outputs are not produced by the multi-tick launch (use rl_policy_act + rl_tick)");
+        return RL_E_UNSUPPORTED;
+    }
+    for (int b = 0; b < n_brains; ++b)
+        if (brains[b].kind < RL_DQN || brains[b].kind > RL_PPO || !brains[b].packed) { rl_set_error("rl_run: brain %d invalid", b); return RL_E_INVALID; }
+    if (n_ticks == 0) return RL_OK;
+    return rl_world_launch_run(h, brains, n_brains, n_ticks, actions, sout, obs, first_obs, update_src, threshold, n_agents, refill_count, (hipStream_t)stream);
 }
 
 int rl_capture_transitions(rl_world* h, const float* state, const int8_t* actions, const float* policy_out, const rl_step_out* step,

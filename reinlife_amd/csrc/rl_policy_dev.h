@@ -101,10 +101,12 @@ __host__ __device__ inline void row_scale(float mx, float& s, float& r)
 // ---------------------------------------------------------------------------------------------------------------
 // LDS-only workgroup barrier: lds_barrier() would also wait vmcnt(0), i.e. drain the weight-prefetch ring at every
 // layer boundary; waves only exchange activations / partial sums through LDS.
+#ifndef RL_HAVE_LDS_BARRIER  /* rl_world.hip defines the same barrier before including this header */
 #ifdef RL_FULL_FENCE
 __device__ inline void lds_barrier() { __syncthreads(); }
 #else
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 #endif
 
 __device__ inline f32x16 mfma16(const f32x4& a, const f32x4& b, f32x16 c)
@@ -165,7 +167,9 @@ constexpr int kXsUnits = kPlanes * kXPlane;
 // per load instruction, four times over).  Every row gets its power-of-two scale here (row maximum by DPP); 1 / scale
 // goes to row_unscale[row] for the input layer's epilogue.
 // `row_of_lane`: observation row id of tile row (lane & 31).
-template <typename WHILE_IN_FLIGHT>
+// COHERENT: the rows were written earlier in the SAME launch (the multi-tick kernel of rl_world.hip): read them with sc1
+// (served by L2, never by a line this CU's vector L1 kept from an older pass over the same buffer).
+template <bool COHERENT, typename WHILE_IN_FLIGHT>
 __device__ inline void stage_x(f32x4* __restrict__ xs, float* __restrict__ row_unscale, const float* __restrict__ obs,
                                int64_t row_of_lane, int lane, int v, WHILE_IN_FLIGHT&& while_in_flight)
 {
@@ -182,12 +186,19 @@ __device__ inline void stage_x(f32x4* __restrict__ xs, float* __restrict__ row_u
 #ifdef RL_ABL_X  // tuning experiment: no observation reads (results are WRONG)
         val[rr] = f32x4{(float)r, 1.0f, 2.0f, 3.0f};
 #else
-        val[rr] = *(const f32x4u*)(obs + r * RL_OBS_DIM + off);
+        if (COHERENT) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)obs, 0, 0x7fffffff, 0x00027000);
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(r * (RL_OBS_DIM * 4)) + off * 4, 0, 16 /* sc1 */);
+            val[rr] = __builtin_bit_cast(f32x4, raw);
+        } else
+            val[rr] = *(const f32x4u*)(obs + r * RL_OBS_DIM + off);
 #endif
     }
     __builtin_amdgcn_sched_barrier(0);
     while_in_flight();  // independent work for the HBM round trip of the rows (the action draw)
     __builtin_amdgcn_sched_barrier(0);
+
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
         f32x4 t = val[rr];
@@ -412,6 +423,8 @@ struct TileIO {
     int8_t* actions;       // [row] selected action, or nullptr
     uint64_t seed;         // Philox key of this lane's row: (seed, epoch; world, tick, RL_SITE_ACT, index)
     uint32_t key_world, key_tick, key_epoch, key_index;
+    int lds_actions_off;   // optional (multi-tick kernel): byte offset of the world's action array in the DYNAMIC LDS region
+    int lds_slot;          // (-1 = none), and the slot of tile row (lane & 31) in it
 #ifdef RL_PHASE_PROFILE
     long long* prof;       // tuning build: shader-clock stamps (slots 48..), non-null in the profiled workgroup only
 #endif
@@ -444,7 +457,7 @@ __device__ inline float row_max_get(const float* aux, int j)
 // DEEP: the variant for launches of a few tiles per CU (256 worlds): five K-chunks of weights in flight per wave (latency),
 // 3 waves per SIMD; otherwise three chunks and 4 waves per SIMD (throughput).  Measured: 18.4 vs 19.8 us at 256 worlds,
 // 217 vs 201 us at 4096.
-template <int KIND, bool DEEP>
+template <int KIND, bool DEEP, bool COHERENT = false>
 __device__ inline void policy_tile(const TileIO& io, f32x4* __restrict__ lds_h, float* __restrict__ lds_aux,
                                    float (*__restrict__ lds_part)[32][9], int lane, int v)
 {
@@ -471,7 +484,7 @@ __device__ inline void policy_tile(const TileIO& io, f32x4* __restrict__ lds_h, 
         HeadW<1, 1> wh;
         float q4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         w1.start(packed + L.l1, lane, v);
-        stage_x(lds_h, lds_aux, io.obs, io.row, lane, v, early_draw);
+        stage_x<COHERENT>(lds_h, lds_aux, io.obs, io.row, lane, v, early_draw);
         lds_barrier();
         k_loop<kInChunks>(w1, lds_h + xb, kXPlane, 2 * kXGroup, h1);
         if (v < 2) { w2.start(packed + L.l2a, lane, v); wh.start(packed + L.ha, 2, lane, v); }
@@ -495,13 +508,15 @@ __device__ inline void policy_tile(const TileIO& io, f32x4* __restrict__ lds_h, 
         WRing<4, 1, 1, DEEP ? 5 : 3> w1, w2;
         HeadW<1, 1> wh;
         EpiConsts e1, e2;
+        RL_PMARK(22);
         w1.start(packed + L.l1, lane, v);
         if (EARLY && v == 0) {  // wave 0 finishes the tile: its head biases are asked for now, not after the last barrier
             const gf32x4* ba = (const gf32x4*)(packed + L.ha + head_consts_off(4) + 8);
             duel_ba0 = ba[0]; duel_ba1 = ba[1];
             duel_bv = packed[L.hb + head_consts_off(4) + 8];
         }
-        stage_x(lds_h, lds_aux, io.obs, io.row, lane, v, early_draw);
+        stage_x<COHERENT>(lds_h, lds_aux, io.obs, io.row, lane, v, early_draw);
+        RL_PMARK(23);
         lds_barrier();
         RL_PMARK(10);
         k_loop<kInChunks>(w1, lds_h + xb, kXPlane, 2 * kXGroup, h1, DEEP ? &e1 : nullptr, packed + L.l1 + frag_floats(kInChunks, 4), v, h);
@@ -543,7 +558,7 @@ __device__ inline void policy_tile(const TileIO& io, f32x4* __restrict__ lds_h, 
         WRing<8, 2, 4, 3> w1, w2;
         HeadW<2, 4> wh;
         w1.start(packed + L.l1, lane, v);   // tiles v and v+4
-        stage_x(lds_h, lds_aux, io.obs, io.row, lane, v, early_draw);
+        stage_x<COHERENT>(lds_h, lds_aux, io.obs, io.row, lane, v, early_draw);
         lds_barrier();
         k_loop<kInChunks>(w1, lds_h + xb, kXPlane, 2 * kXGroup, h1);
         w2.start(packed + L.l2a, lane, v);
@@ -622,6 +637,10 @@ __device__ inline void policy_tile(const TileIO& io, f32x4* __restrict__ lds_h, 
                     for (int i = 1; i < 8; ++i) if (q[i] > q[a]) a = i;  // first maximum
                 }
                 io.actions[io.row] = (int8_t)a;
+                if (io.lds_actions_off >= 0) {
+                    extern __shared__ __attribute__((aligned(16))) char rl_dyn_lds[];
+                    ((signed char*)rl_dyn_lds)[io.lds_actions_off + io.lds_slot] = (signed char)a;
+                }
             }
         }
     }

@@ -28,6 +28,11 @@
 
 #include "rl_common.h"
 
+// The thread index as the multi-tick kernel sees it: opaque, so that nothing derived from it is loop-invariant.  k_run runs
+// policy and tick back to back inside a tick loop; with the plain builtin every per-thread constant of the tick phases (window
+// offsets, row bases, ...) was hoisted out of that loop and kept alive -- i.e. spilled -- across the 126-VGPR tile code.
+__device__ inline int rl_tidx() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+
 int rl_world_prepare_bytes(size_t bytes);
 size_t rl_world_smem_bytes(int cpad, int cap, int hash);
 static int g_ablate = 0;  // tuning only
@@ -100,9 +105,9 @@ enum { AUX_VANISH = 1, AUX_PARENT = 2 };
 
 #ifdef RL_PHASE_PROFILE
 #define RL_ABL(bit) (p.ablate & (bit))  /* tuning build only: skip a section (results are then WRONG) */
-#define RL_MARK(i) do { if (p.prof && (int)blockIdx.x == p.prof_world && threadIdx.x == 0) RL_G(p.prof)[i] = (long long)__builtin_readcyclecounter(); } while (0) /* global (not flat) store: stays off lgkmcnt */
-#define RL_MARK_T(i, t) do { if (p.prof && (int)blockIdx.x == p.prof_world && (int)threadIdx.x == (t)) RL_G(p.prof)[i] = (long long)__builtin_readcyclecounter(); } while (0)
-#define RL_MARK_W(base) do { if (p.prof && (int)blockIdx.x == p.prof_world && (threadIdx.x & 63) == 0) RL_G(p.prof)[(base) + (threadIdx.x >> 6)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define RL_MARK(i) do { if (p.prof && (int)blockIdx.x == p.prof_world && rl_tidx() == 0) RL_G(p.prof)[i] = (long long)__builtin_readcyclecounter(); } while (0) /* global (not flat) store: stays off lgkmcnt */
+#define RL_MARK_T(i, t) do { if (p.prof && (int)blockIdx.x == p.prof_world && rl_tidx() == (t)) RL_G(p.prof)[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#define RL_MARK_W(base) do { if (p.prof && (int)blockIdx.x == p.prof_world && (rl_tidx() & 63) == 0) RL_G(p.prof)[(base) + (rl_tidx() >> 6)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define RL_MARK_W(base) do { } while (0)
 #define RL_ABL(bit) 0
@@ -162,7 +167,7 @@ __host__ __device__ inline size_t carve(Smem& s, char* base, int Cp, int cap, in
 // ---------------------------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------------------------
-__device__ inline int lane_id() { return threadIdx.x & 63; }
+__device__ inline int lane_id() { return rl_tidx() & 63; }
 
 // The kernel argument block (KParams is the only kernel parameter, so it starts at offset 0 of the kernarg segment), made
 // opaque so that every use site re-reads the few pointers it needs with s_load instead of keeping all ~45 pointers alive
@@ -186,6 +191,7 @@ template <typename E> struct rl_global_ptr<E*> { typedef E __attribute__((addres
 // s_waitcnt vmcnt(0), which on gfx950 also waits for every outstanding global STORE (observation rows, outputs) -- an
 // HBM write round trip (~1 us) at each of the ~40 barriers of a tick.  Threads of these kernels only ever exchange data
 // through LDS, so waiting for the LDS queue is sufficient; global stores drain in the background.
+#define RL_HAVE_LDS_BARRIER 1
 #ifdef RL_FULL_FENCE
 __device__ inline void lds_barrier() { __syncthreads(); }
 #else
@@ -200,7 +206,7 @@ __device__ inline bool block_any(int* flags, int& phase, bool pred)
     lds_barrier();
     const bool r = flags[phase] != 0;
     phase ^= 1;
-    if (threadIdx.x == 0) flags[phase] = 0;  // next use of this slot is after at least one more barrier
+    if (rl_tidx() == 0) flags[phase] = 0;  // next use of this slot is after at least one more barrier
     return r;
 }
 __device__ inline unsigned long long shfl_u64(unsigned long long v, int src)
@@ -314,7 +320,7 @@ struct SpecState {
 template <int T>
 __device__ inline void spec_refill_keys(const KParams& p, Smem& s, int w, uint32_t epoch, SpecState& st)
 {
-    const int tid = threadIdx.x;
+    const int tid = rl_tidx();
     st.nf = st.np = 0;
     if (tid < kSpecFirst) return;
     const int sp = tid - kSpecFirst;
@@ -336,7 +342,7 @@ __device__ inline void spec_refill_keys(const KParams& p, Smem& s, int w, uint32
 template <int T>
 __device__ inline void spec_refill_stage(const KParams& p, Smem& s, int w, const SpecState& st, int stage)
 {
-    const int tid = threadIdx.x;
+    const int tid = rl_tidx();
     const int lg = st.lg;
     if (tid < kSpecFirst) return;
     const int sp = tid - kSpecFirst;
@@ -401,7 +407,7 @@ __device__ inline void init_newborn(Smem& s, int idx, int cell, int W, int gene,
 template <int T>
 __device__ __forceinline__ int apply_spec_refill(const KParams& p, Smem& s, int w, uint32_t epoch)
 {
-    const int tid = threadIdx.x;
+    const int tid = rl_tidx();
     lds_barrier();
     if (tid < S_COUNT) s.scal[tid] = 0;
     // one pass: the bitmap and its prefix were prepared too, and a cell's occ / type are written by its own thread only
@@ -440,7 +446,7 @@ __device__ __forceinline__ int apply_spec_refill(const KParams& p, Smem& s, int 
 template <int T, bool SPEC = false>
 __device__ __forceinline__ void load_world(const KParams& p, Smem& s, int w, int& n0)
 {
-    const int tid = threadIdx.x;
+    const int tid = rl_tidx();
     KParamsC* q = kernargs();
     const size_t b = (size_t)w * p.cap;
     // ---- every pointer first, in uniform code (one batch of scalar loads) ...
@@ -549,7 +555,7 @@ __device__ inline void hash_insert_wave(Smem& s, int mask, bool active, int a, i
 template <int T>
 __device__ __forceinline__ void build_order(const KParams& p, Smem& s, int nslots, int out_slot)
 {
-    const int tid = threadIdx.x;
+    const int tid = rl_tidx();
     for (int c = tid; c < p.Cp; c += T) {
         const unsigned long long m = __ballot(s.type[c] == RL_AGENT);
         if (lane_id() == 0) s.agbits[c >> 6] = m;
@@ -580,7 +586,7 @@ __device__ __forceinline__ void build_order(const KParams& p, Smem& s, int nslot
 template <int T>
 __device__ __forceinline__ void assign_order(const KParams& p, Smem& s, int nslots)
 {
-    for (int a = threadIdx.x; a < nslots; a += T) {
+    for (int a = rl_tidx(); a < nslots; a += T) {
         const int cell = (s.pos[a] & 255) * p.W + (s.pos[a] >> 8);
         const int oc = s.occ[cell], wb = s.wordbase[cell >> 6];  // one batch (the list is a handful of agents per lane:
         const unsigned long long ab = s.agbits[cell >> 6];       // the chain's latency is what counts)
@@ -603,7 +609,7 @@ __device__ inline void scan_order_wave(const KParams& p, Smem& s, int lane, int 
 
 // _prepare_observations (environment.py:377-404) into LDS planes
 template <int T>
-__device__ __forceinline__ void build_planes(const KParams& p, Smem& s, int t0 = threadIdx.x, int nt = T)
+__device__ __forceinline__ void build_planes(const KParams& p, Smem& s, int t0 = rl_tidx(), int nt = T)
 {
     if (RL_ABL(2)) return;
     const bool float_mode = s.type[0] == RL_AGENT;  // np.vectorize dtype inference from cell (0,0)
@@ -702,7 +708,7 @@ __device__ __forceinline__ void write_observations(const KParams& p, Smem& s, in
 template <int T>
 __device__ inline void write_observations(const KParams& p, Smem& s, int w, int n, float* obs)
 {
-    write_observations<T>(p, s, w, n, obs, (int)threadIdx.x);
+    write_observations<T>(p, s, w, n, obs, rl_tidx());
 }
 
 // Lean tick: every Philox draw of the tick depends only on (seed, epoch, world, tick, site, index), so the idle upper half of
@@ -731,8 +737,8 @@ __device__ inline void precompute_draws(const KParams& p, Smem& s, int w, int n0
     const uint32_t epoch = (uint32_t)s.scal[S_EPOCH], tick = (uint32_t)s.scal[S_TICK], world = (uint32_t)(p.world_base + w);
     constexpr int kFirst = T > 128 ? 128 : T / 2;  // threads below stay out of it
     const int n_items = 128 + min(c.n_gate, n0);
-    if ((int)threadIdx.x < kFirst) return;
-    for (int item = T - 1 - (int)threadIdx.x; item < n_items; item += T - kFirst) {
+    if (rl_tidx() < kFirst) return;
+    for (int item = T - 1 - rl_tidx(); item < n_items; item += T - kFirst) {
         uint32_t site, idx;
         if (item < RL_FOOD_TRIES) { site = RL_SITE_FOOD; idx = (uint32_t)item; }
         else if (item == 16) { site = RL_SITE_PRODUCE; idx = 0u; }
@@ -750,7 +756,7 @@ __device__ inline void precompute_draws(const KParams& p, Smem& s, int w, int n0
 template <int T, bool LEAN, bool PLANES_EARLY, bool SPEC = false>
 __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int n0)
 {
-    const int tid = threadIdx.x;
+    const int tid = rl_tidx();
     const int W = p.W, H = p.H;
     SpecState spec_state;
     spec_state.on = SPEC && spec_refill_wanted(p, n0, spec_state.lg);
@@ -992,7 +998,7 @@ __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int
 // the planes of the cells _add_food just filled (they were built as empty cells next to the placement)
 __device__ inline void patch_placed_planes(Smem& s)
 {
-    const int tid = threadIdx.x;
+    const int tid = rl_tidx();
     if (tid < s.scal[S_NPLACED]) {
         const int c = s.plist[tid];
         const int t = s.type[c];
@@ -1019,7 +1025,7 @@ __device__ inline void init_newborn(Smem& s, int idx, int cell, int W, int gene,
 template <int T, bool LEAN>
 __device__ __forceinline__ void reproduce_wave0(const KParams& p, Smem& s, int w, int n1, int nslots)
 {
-    const int tid = threadIdx.x;
+    const int tid = rl_tidx();
     const bool room = n1 <= p.max_agents;
     const bool tape = !LEAN && p.tape.food_k != nullptr;
     const uint32_t epoch = (uint32_t)s.scal[S_EPOCH], tick = (uint32_t)s.scal[S_TICK];
@@ -1178,7 +1184,10 @@ __device__ __forceinline__ void reproduce_wave0(const KParams& p, Smem& s, int w
         init_newborn(s, i, cell, p.W, s.gene[i], s.brain[i], next_uid + (i - nslots));
     }
     next_uid += slots - nslots;
-    if (tid == 0) { s.scal[S_NSLOTS] = slots; p.st.next_uid[w] = next_uid; p.st.max_gene[w] = max_gene; }
+    if (tid == 0) {
+        s.scal[S_NSLOTS] = slots; s.scal[S_NEXT_UID] = next_uid; s.scal[S_MAX_GENE] = max_gene;
+        p.st.next_uid[w] = next_uid; p.st.max_gene[w] = max_gene;
+    }
     // _remove_dead_agents (environment.py:795-799): corpses become Food -- after the placements, which must still
     // see their cells as occupied; same wave, so no barrier in between
     for (int k = lane; k < n1; k += 64) {
@@ -1220,7 +1229,7 @@ __device__ inline void best_agents_wave(Smem& s, int n1)
 template <int T, bool LEAN>
 __device__ __forceinline__ void phase_update(const KParams& p, Smem& s, int w, int n1, int& nslots, bool fresh_bitmap)
 {
-    const int tid = threadIdx.x;
+    const int tid = rl_tidx();
     // ---- _update_best_agents (environment.py:728-739) ----------------------------------------------------------------
     if (!p.static_families) {
         double bf = -1.0e300; int bk = 0x7fffffff;
@@ -1266,10 +1275,10 @@ __device__ __forceinline__ void phase_update(const KParams& p, Smem& s, int w, i
 template <int T>
 __device__ __forceinline__ void rebuild_gene_counts(const KParams& p, Smem& s, int n)
 {
-    for (int i = threadIdx.x; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
+    for (int i = rl_tidx(); i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
     lds_barrier();
     const int np2 = (n + 63) & ~63;
-    for (int k = threadIdx.x; k < np2; k += T) {
+    for (int k = rl_tidx(); k < np2; k += T) {
         const bool act = k < n;
         const int a = act ? s.order[k] : 0;
         hash_insert_wave(s, p.hash_mask, act, a, act ? s.gene[a] : 0, 1u << 16);
@@ -1431,7 +1440,7 @@ __device__ inline void emit_brain_lists_wave0(const KParams& p, int w, int n, F 
 template <int T>
 __device__ __forceinline__ void store_world(const KParams& p, Smem& s, int w, int n)
 {
-    const int tid = threadIdx.x;
+    const int tid = rl_tidx();
     KParamsC* q = kernargs();
     if (RL_ABL(64)) return;
     auto gt = RL_G(q->st.cell_type) + (size_t)w * p.C;
@@ -1515,11 +1524,11 @@ __global__ __launch_bounds__(T) void k_world(const KParams p_in)
     if (FIXED) carve(s, smem_raw, kFixCp, kFixCap, kFixHash);
     else carve(s, smem_raw, p.Cp, p.cap, p.hash_size);
     const int w = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int tid = rl_tidx();
     int n0;
     RL_MARK(0);
 #ifdef RL_PHASE_PROFILE
-    if (p.prof && (int)blockIdx.x == p.prof_world && threadIdx.x == 0) p.prof[23] = (long long)t_entry;
+    if (p.prof && (int)blockIdx.x == p.prof_world && rl_tidx() == 0) p.prof[23] = (long long)t_entry;
 #endif
     if (RL_ABL(32768)) return;
     // (speculative refill: lean fused tick, 1024-thread workgroups -- the latency-bound regime of one world per CU)
@@ -1717,7 +1726,7 @@ __global__ __launch_bounds__(T) void k_world(const KParams p_in)
 template <int T>
 __device__ __forceinline__ int reset_world_lds(const KParams& p, Smem& s, int w, uint32_t epoch)
 {
-    const int tid = threadIdx.x;
+    const int tid = rl_tidx();
     // LDS scratch (the observation planes are rebuilt afterwards): key per cell, bucket counters, keys grouped by bucket
     unsigned* keys = (unsigned*)s.genev;
     unsigned* cum = (unsigned*)s.foodv;
@@ -1822,7 +1831,7 @@ __global__ __launch_bounds__(T) void k_reset(const KParams p)
     carve(s, smem_raw, p.Cp, p.cap, p.hash_size);
     const int w = blockIdx.x;
     if (p.refill_threshold >= 0 && p.st.n_agents[w] >= p.refill_threshold) {  // uniform per workgroup: nothing to re-generate
-        if (p.lists && threadIdx.x < 64) {
+        if (p.lists && rl_tidx() < 64) {
             const int32_t* br = p.st.a_brain + (size_t)w * p.cap;
             emit_brain_lists_wave0(p, w, p.st.n_agents[w], [&](int k) { return br[k]; });
         }
@@ -1835,7 +1844,374 @@ __global__ __launch_bounds__(T) void k_reset(const KParams p)
     lds_barrier();
     write_observations<T>(p, s, w, n, p.obs_only);
     store_world<T>(p, s, w, n);
-    if (p.lists && threadIdx.x < 64) emit_brain_lists_wave0(p, w, n, [&](int k) { return s.brain[s.order[k]]; });
+    if (p.lists && rl_tidx() < 64) emit_brain_lists_wave0(p, w, n, [&](int k) { return s.brain[s.order[k]]; });
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_run: n_ticks iterations of the inference loop (Helpers/trainer.py:85-99 minus learn) in ONE launch.
+//
+//   for every tick:  Agent.get_action for the world's agents (policy_tile, rl_policy_dev.h)  ->  Environment.step  ->
+//                    update_env  ->  optional re-generation below the refill threshold
+//
+// A world never leaves its workgroup: the state is loaded once, every tick runs out of LDS (the same phase functions as
+// k_world), the agent list is re-packed in LDS between ticks (recycle_world = what store_world + load_world do through
+// HBM), and the state is stored once at the end.  Every API-visible per-tick output is still written every tick
+// (state_prime / state rows, reward, done, both permutations, actions), so a tick moves the same algorithmic bytes as
+// rl_policy_act + rl_tick_refill; what disappears is two launches, the world's load / store, the row lists, and the trip of
+// the observation rows through the fabric to another CU (the policy reads its own world's rows back from L2, sc1).
+// The 4-wave tile code runs on groups of four waves of the world's workgroup (T / 256 tiles at a time); every group executes
+// the same number of workgroup barriers per round.
+// ---------------------------------------------------------------------------------------------------------------
+#include "rl_policy_dev.h"
+
+#ifndef RL_RUN_COHERENT
+#define RL_RUN_COHERENT true
+#endif
+constexpr int kRunMaxBrains = 8;
+struct RunArgs {
+    const float* packed[kRunMaxBrains];   // device: packed weights per brains-list entry
+    float eps[kRunMaxBrains];
+    float* obs[2];                        // Agent.state ping-pong: tick i reads obs[(first + i) & 1], writes the other
+    int first;
+    int n_ticks;
+    int8_t* actions;                      // [R][cap] chosen actions of the LAST tick (API-visible)
+    int debug;                            // tuning only (env RL_RUN_DEBUG): 1 = skip the policy half, 2 = skip the tick half (results WRONG)
+};
+
+struct PolSmem {
+    char* group0;       // per-group block: lds_h | lds_aux | lds_part, group g at group0 + g * group_bytes
+    int group_bytes;
+    short* prow;        // [cap] list indices grouped by brain
+    int* bstart;        // [64] first entry of brain b in prow
+    int* bcnt;          // [64]
+    int* tstart;        // [64] first tile of brain b
+    int* meta;          // [8]  [0] number of tiles; loop state of k_run: [1] list length, [2] Agent.state parity, [3] ticks done
+};
+template <int KIND>
+__host__ __device__ constexpr int policy_group_bytes()
+{
+    return (int)(align16(sizeof(f32x4) * (size_t)policy_lds_units(KIND)) + align16(sizeof(float) * kAuxFloats) + align16(sizeof(float) * 4 * 32 * 9));
+}
+template <int KIND>
+__host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o, int cap, int groups)
+{
+    o = align16(o);
+    ps.group0 = base + o; ps.group_bytes = policy_group_bytes<KIND>();
+    o += (size_t)groups * policy_group_bytes<KIND>();
+    ps.prow = (short*)(base + o); o = align16(o + sizeof(short) * (size_t)cap);
+    ps.bstart = (int*)(base + o); o = align16(o + sizeof(int) * 64);
+    ps.bcnt = (int*)(base + o); o = align16(o + sizeof(int) * 64);
+    ps.tstart = (int*)(base + o); o = align16(o + sizeof(int) * 64);
+    ps.meta = (int*)(base + o); o = align16(o + sizeof(int) * 8);
+    return o;
+}
+template <int KIND> __device__ inline f32x4* pol_h(const PolSmem& ps, int g) { return (f32x4*)(ps.group0 + g * ps.group_bytes); }
+template <int KIND> __device__ inline float* pol_aux(const PolSmem& ps, int g)
+{
+    return (float*)(ps.group0 + g * ps.group_bytes + align16(sizeof(f32x4) * (size_t)policy_lds_units(KIND)));
+}
+template <int KIND> __device__ inline float (*pol_part(const PolSmem& ps, int g))[32][9]
+{
+    return (float (*)[32][9])(ps.group0 + g * ps.group_bytes + align16(sizeof(f32x4) * (size_t)policy_lds_units(KIND)) + align16(sizeof(float) * kAuxFloats));
+}
+
+// Agent.get_action for the n agents of this world (slot k == list index k): actions into s.action[] and the global
+// `actions` buffer.  Must be called by the whole workgroup; leaves with a barrier behind the last action store.
+// (Per-brain arguments are fetched from the kernel-argument block with a uniform index -- scalar loads; a by-value copy of the
+// argument struct indexed at run time would live in scratch, and at 1024 threads x 256 worlds every dword of scratch per thread
+// is 1 MB of memory traffic per tick.)
+struct RunParams;
+typedef const RunParams __attribute__((address_space(4))) RunParamsC;
+template <int T, int KIND>
+__device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base);
+
+// Between two ticks of k_run: the post-update list becomes slots 0..n-1 (slot == list index, what load_world establishes),
+// and every per-tick scratch is reset to what load_world leaves behind.  slot_cap <= T: one agent per thread.
+template <int T, bool SPEC>
+__device__ __forceinline__ void recycle_world(const KParams& p, Smem& s, int n, int tick, int epoch, int next_uid, int max_gene)
+{
+    const int tid = rl_tidx();
+    const bool mine = tid < n;
+    const int a = mine ? s.order[tid] : 0;
+    const unsigned short r_pos = s.pos[a];
+    const int r_h = s.health[a], r_age = s.age[a], r_ma = s.max_age[a], r_g = s.gene[a], r_b = s.brain[a], r_u = s.uid[a];
+    const uint8_t r_fl = s.flags[a];
+    const signed char r_act = s.action[a];
+    const double r_f = s.fitness[a];
+    lds_barrier();   // every field is in registers; the planes were last read before the barrier that precedes this call
+    if (mine) {
+        s.pos[tid] = r_pos; s.health[tid] = r_h; s.age[tid] = r_age; s.max_age[tid] = r_ma; s.gene[tid] = r_g; s.brain[tid] = r_b;
+        s.uid[tid] = r_u; s.flags[tid] = r_fl; s.action[tid] = r_act; s.fitness[tid] = r_f;
+        s.aux[tid] = 0; s.src[tid] = (short)tid; s.order[tid] = (short)tid; s.newidx[tid] = (short)tid;
+    }
+    for (int c = tid; c < p.Cp; c += T) { s.occ[c] = -1; ((unsigned*)s.foodv)[c] = 0u; }
+    for (int i = tid; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
+    if (tid < RL_MAX_BRAINS) s.present[tid] = 0;
+    if (SPEC) for (int i = tid; i < 2 * p.cap; i += T) ((unsigned*)s.reward)[i] = 0u;
+    if (tid < S_COUNT)
+        s.scal[tid] = tid == S_NSLOTS ? n : tid == S_TICK ? tick : tid == S_EPOCH ? epoch : tid == S_NEXT_UID ? next_uid : tid == S_MAX_GENE ? max_gene : 0;
+    lds_barrier();
+    if (mine) s.occ[(r_pos & 255) * p.W + (r_pos >> 8)] = (short)tid;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tick's observation rows are in L2 before any wave reads them back
+    lds_barrier();
+}
+
+// The kernel's only parameter.  The two halves of a tick are real (noinline) function calls, each with a register allocation
+// of its own (inlined into one body the tile code's ~126 VGPRs and the tick's hoisted loop invariants spill into each other's
+// loops), and the kernel body keeps NOTHING alive across them: the loop state lives in LDS (PolSmem::meta), because whatever a
+// caller holds in registers across a call of a 128-VGPR callee goes through scratch.
+struct RunParams {
+    KParams p;
+    RunArgs ra;
+};
+template <bool FIXED>
+__device__ inline KParams run_params(RunParamsC* ka)
+{
+    // A struct copy out of the CONSTANT address space: every field that is used becomes a scalar load of the kernel-argument
+    // block.  Only the device pass can express it (for the host pass the implicit copy constructor cannot bind an
+    // address-space-qualified reference).
+#if defined(__HIP_DEVICE_COMPILE__)
+    KParams p = *(const KParams __attribute__((address_space(4)))*)&ka->p;
+#else
+    KParams p{};
+#endif
+    if (FIXED) {
+        p.W = kFixW; p.H = kFixH; p.C = kFixC; p.Cp = kFixCp; p.nW = kFixCp / 64;
+        p.cap = kFixCap; p.hash_size = kFixHash; p.hash_mask = kFixHash - 1;
+    }
+    return p;
+}
+template <bool FIXED, int KIND>
+__device__ inline void run_carve(const KParams& p, Smem& s, PolSmem& ps, char* smem_raw, int groups)
+{
+    const size_t o0 = FIXED ? carve(s, smem_raw, kFixCp, kFixCap, kFixHash) : carve(s, smem_raw, p.Cp, p.cap, p.hash_size);
+    carve_policy<KIND>(ps, smem_raw, o0, p.cap, groups);
+}
+
+template <int T, int KIND>
+__device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base)
+{
+    constexpr int GROUPS = T / 256;
+    const int tid = rl_tidx(), lane = tid & 63, wave = tid >> 6, grp = wave >> 2, v = wave & 3, j = lane & 31;
+#ifdef RL_PHASE_PROFILE
+    if (p.prof && (int)blockIdx.x == p.prof_world && rl_tidx() == 0) p.prof[100] = (long long)clock64();
+#endif
+    if (wave == 0) {   // rows grouped by brain (ballots; lane b keeps brain b's count), tiles of 32 rows per brain
+        int cnt = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int k = base + lane;
+            const int b = k < n ? s.brain[k] : -1;
+            for (int bb = 0; bb < p.n_brains; ++bb) { const int c = __popcll(__ballot(b == bb)); if (lane == bb) cnt += c; }
+        }
+        const int mine = lane < p.n_brains ? cnt : 0;
+        const int incl = wave_incl_scan(mine);
+        const int tiles = (mine + 31) >> 5;
+        const int tincl = wave_incl_scan(tiles);
+        if (lane < p.n_brains) { ps.bstart[lane] = incl - mine; ps.bcnt[lane] = mine; ps.tstart[lane] = tincl - tiles; }
+        if (lane == 63) ps.meta[0] = tincl;
+        int pos = incl - mine;
+        for (int base = 0; base < n; base += 64) {
+            const int k = base + lane;
+            const int b = k < n ? s.brain[k] : -1;
+            for (int bb = 0; bb < p.n_brains; ++bb) {
+                const unsigned long long m = __ballot(b == bb);
+                const int start = read_lane(pos, bb);
+                if (b == bb) ps.prow[start + __popcll(m & lowmask(lane))] = (short)k;
+                if (lane == bb) pos += __popcll(m);
+            }
+        }
+    }
+    lds_barrier();
+    const int ntiles = __builtin_amdgcn_readfirstlane(ps.meta[0]);
+    for (int t0 = 0; t0 < ntiles; t0 += GROUPS) {   // uniform trip count: every group runs the same barriers
+        const int ti = t0 + grp;
+        const bool have = ti < ntiles;
+        int b = 0;
+        if (have) for (int bb = 1; bb < p.n_brains; ++bb) if (ps.tstart[bb] <= ti && ps.bcnt[bb] > 0) b = bb;
+        b = __builtin_amdgcn_readfirstlane(b);   // uniform per wave: the brain's arguments come by scalar loads
+        const int cntb = have ? ps.bcnt[b] : 0;
+        const int li = have ? (ti - ps.tstart[b]) * 32 + j : 0;
+        const bool valid = have && li < cntb;
+        const int k = (have && cntb > 0) ? ps.prow[ps.bstart[b] + min(li, cntb - 1)] : 0;
+        TileIO io;
+        io.packed = (gfloat*)((const float* const __attribute__((address_space(4)))*)ka->ra.packed)[b];
+        io.obs = obs_rows;
+        io.row = (int64_t)w * p.cap + k;
+        io.valid = valid;
+        io.eps = ((const float __attribute__((address_space(4)))*)ka->ra.eps)[b];
+        io.out = nullptr;
+        io.actions = *(int8_t* const __attribute__((address_space(4)))*)&ka->ra.actions;
+        io.seed = p.seed;
+        io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
+        io.key_index = (uint32_t)k;
+        io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
+#ifdef RL_PHASE_PROFILE
+        io.prof = (p.prof && (int)blockIdx.x == p.prof_world) ? p.prof : nullptr;
+        if (io.prof && rl_tidx() == 0) io.prof[101] = (long long)clock64();
+#endif
+        policy_tile<KIND, false, RL_RUN_COHERENT>(io, pol_h<KIND>(ps, grp), pol_aux<KIND>(ps, grp), pol_part<KIND>(ps, grp), lane, v);
+    }
+}
+
+// First half of a tick: the policy.  Reads the list length and the Agent.state parity from LDS.
+template <int T, bool FIXED, int KIND>
+__device__ __forceinline__ void run_policy_half(RunParamsC* ka)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const KParams p = run_params<FIXED>(ka);
+    Smem s;
+    PolSmem ps;
+    run_carve<FIXED, KIND>(p, s, ps, smem_raw, T / 256);
+    const int w = blockIdx.x;
+    const int n = __builtin_amdgcn_readfirstlane(ps.meta[1]), cur = __builtin_amdgcn_readfirstlane(ps.meta[2]);
+    const float* obs_in = ((float* const __attribute__((address_space(4)))*)ka->ra.obs)[cur];
+    run_policy<T, KIND>(p, s, ps, ka, w, n, obs_in, smem_raw);
+}
+
+// Second half: Environment.step + update_env (+ re-generation) out of LDS, then recycle_world.  Same sequence as
+// k_world<T, MODE_TICK, LEAN>; writes Agent.state into ra.obs[cur ^ 1] and advances the loop state in LDS.
+template <int T, bool FIXED, int KIND>
+__device__ __forceinline__ void run_tick_body(RunParamsC* ka)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const KParams p = run_params<FIXED>(ka);
+    Smem s;
+    PolSmem ps;
+    run_carve<FIXED, KIND>(p, s, ps, smem_raw, T / 256);
+    const int w = blockIdx.x;
+    const int n0 = __builtin_amdgcn_readfirstlane(ps.meta[1]), cur = __builtin_amdgcn_readfirstlane(ps.meta[2]);
+    const int ticks_done = __builtin_amdgcn_readfirstlane(ps.meta[3]);
+    float* const obs_out = ((float* const __attribute__((address_space(4)))*)ka->ra.obs)[cur ^ 1];
+    const int tid = rl_tidx();
+    constexpr bool kSpec = T == 1024;
+    int nslots = n0;
+    constexpr bool kPlanesEarly = T >= 256;
+    phase_step<T, true, kPlanesEarly, kSpec>(p, s, w, n0);
+    assign_order<T>(p, s, nslots);
+    if (kPlanesEarly) patch_placed_planes(s);
+    const int n1 = s.scal[S_N1];
+    lds_barrier();
+    const bool overlapped = !p.limit_reproduction;
+    const size_t b = (size_t)w * p.cap;
+    auto step_outputs = [&](int t, int nt) {
+        for (int k = t; k < n1; k += nt) {
+            const int a = s.order[k];
+            if (p.so.reward) p.so.reward[b + k] = (float)s.reward[a];
+            if (p.so.done) p.so.done[b + k] = (s.flags[a] & RL_F_DEAD) ? 1 : 0;
+            if (p.so.src) p.so.src[b + k] = (short)a;
+        }
+        if (t == 0 && p.so.n_acted) p.so.n_acted[w] = n0;
+        if (t == 0 && p.so.acted_total && n0) atomicAdd(p.so.acted_total, (unsigned long long)n0);
+    };
+    if (overlapped) {
+        if (tid < 64) {
+            if (!p.static_families) best_agents_wave(s, n1);
+            reproduce_wave0<T, true>(p, s, w, n1, nslots);
+        } else {
+            write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n1, p.so.obs, tid - 64);
+            step_outputs(tid - 64, T - 64);
+        }
+    } else {
+        write_observations<T>(p, s, w, n1, p.so.obs);
+        step_outputs(tid, T);
+    }
+    lds_barrier();
+    for (int a = tid; a < nslots; a += T) s.src[a] = s.newidx[a];
+    if (!overlapped) lds_barrier();
+    else nslots = s.scal[S_NSLOTS];
+    if (!overlapped) phase_update<T, true>(p, s, w, n1, nslots, true);
+    for (int c = tid; c < p.Cp; c += T) {
+        const unsigned long long m = __ballot(s.type[c] == RL_AGENT);
+        if (lane_id() == 0) s.agbits[c >> 6] = m;
+    }
+    for (int i = tid; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
+    lds_barrier();
+    if (tid < 64) scan_order_wave(p, s, tid, S_N2);
+    lds_barrier();
+    int n2 = s.scal[S_N2];
+    int tick_next = s.scal[S_TICK] + 1, epoch_next = s.scal[S_EPOCH];
+    int next_uid = s.scal[S_NEXT_UID], max_gene = s.scal[S_MAX_GENE];
+    const bool refill = p.refill_threshold >= 0 && n2 < p.refill_threshold;
+    if (refill) {
+        const bool prepared = kSpec && s.scal[S_SPEC_DONE] != 0;
+        const uint32_t new_epoch = (uint32_t)epoch_next + 1u;
+        if (prepared) {
+            n2 = apply_spec_refill<T>(p, s, w, new_epoch);
+            const int np2 = (n2 + 63) & ~63;
+            for (int k = tid; k < np2; k += T) hash_insert_wave(s, p.hash_mask, k < n2, k, k < n2 ? s.gene[k] : 0, 1u << 16);
+        } else {
+            n2 = reset_world_lds<T>(p, s, w, new_epoch);
+            rebuild_gene_counts<T>(p, s, n2);
+        }
+        tick_next = 0; epoch_next = (int)new_epoch; next_uid = n2; max_gene = p.n_brains;
+    } else {
+        assign_order<T>(p, s, nslots);
+        const int nsp = (nslots + 63) & ~63;
+        for (int a = tid; a < nsp; a += T) {
+            const int aa = a < nslots ? a : 0;
+            const int ps_ = s.pos[aa], ge = s.gene[aa];
+            const bool on = a < nslots && s.occ[(ps_ & 255) * p.W + (ps_ >> 8)] == a;
+            hash_insert_wave(s, p.hash_mask, on, a, on ? ge : 0, 1u << 16);
+        }
+    }
+    build_planes<T>(p, s);
+    lds_barrier();
+    if (p.uo.src)
+        for (int k = tid; k < n2; k += T) p.uo.src[b + k] = refill ? (short)-1 : s.src[s.order[k]];
+    write_observations<T>(p, s, w, n2, obs_out);
+    if (tid == 0) { ps.meta[1] = n2; ps.meta[2] = cur ^ 1; ps.meta[3] = ticks_done + 1; }
+    recycle_world<T, kSpec>(p, s, n2, tick_next, epoch_next, next_uid, max_gene);
+}
+
+template <int T, int KIND>
+__device__ __forceinline__ void run_tick_call_fixed(RunParamsC* ka) { run_tick_body<T, true, KIND>(ka); }
+template <int T, int KIND>
+__device__ __forceinline__ void run_tick_call_generic(RunParamsC* ka) { run_tick_body<T, false, KIND>(ka); }
+
+template <int T, bool FIXED, int KIND>
+__device__ __forceinline__ void run_load_call(RunParamsC* ka)   // (inlined: load_world reads the kernel-argument segment through the intrinsic)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    typedef const int __attribute__((address_space(4))) cint;
+    const KParams p = run_params<FIXED>(ka);
+    Smem s;
+    PolSmem ps;
+    run_carve<FIXED, KIND>(p, s, ps, smem_raw, T / 256);
+    int n0;
+    load_world<T, (T == 1024)>(p, s, (int)blockIdx.x, n0);
+    if (rl_tidx() == 0) { ps.meta[1] = n0; ps.meta[2] = *(cint*)&ka->ra.first; ps.meta[3] = 0; }
+    lds_barrier();
+}
+template <int T, bool FIXED, int KIND>
+__device__ __forceinline__ void run_store_call(RunParamsC* ka)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const KParams p = run_params<FIXED>(ka);
+    Smem s;
+    PolSmem ps;
+    run_carve<FIXED, KIND>(p, s, ps, smem_raw, T / 256);
+    store_world<T>(p, s, (int)blockIdx.x, ps.meta[1]);
+    if (rl_tidx() == 0) { p.st.tick[blockIdx.x] = s.scal[S_TICK]; p.st.epoch[blockIdx.x] = s.scal[S_EPOCH]; p.st.next_uid[blockIdx.x] = s.scal[S_NEXT_UID]; p.st.max_gene[blockIdx.x] = s.scal[S_MAX_GENE]; }
+}
+
+// Kernel body = the policy half (inlined: a kernel saves no registers, and the tile code gets the 128-VGPR budget of a
+// 1024-thread workgroup to itself); the tick half, the initial load and the final store are callees.
+template <int T, bool FIXED, int KIND>
+__global__ __launch_bounds__(T) void k_run(const RunParams rp)
+{
+    RunParamsC* ka = (RunParamsC*)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef const int __attribute__((address_space(4))) cint;
+    run_load_call<T, FIXED, KIND>(ka);
+    const int n_ticks = *(cint*)&ka->ra.n_ticks;
+    const int dbg = *(cint*)&ka->ra.debug;
+    for (int it = 0; it < n_ticks; ++it) {   // (`it` and the bounds are uniform: SGPRs, which a callee preserves)
+        if (!(dbg & 1)) run_policy_half<T, FIXED, KIND>(ka);
+        if (!(dbg & 2)) {
+            if constexpr (FIXED) run_tick_call_fixed<T, KIND>(ka);
+            else run_tick_call_generic<T, KIND>(ka);
+        }
+    }
+    run_store_call<T, FIXED, KIND>(ka);
 }
 
 // 1024 threads per world when there are few worlds (latency-bound: one world per CU), 256 when there are many
@@ -1909,7 +2285,7 @@ struct CaptureArgs {
 __global__ __launch_bounds__(256) void k_capture(const CaptureArgs A)
 {
     __shared__ int slot[4096];
-    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int w = blockIdx.x, tid = rl_tidx(), lane = tid & 63;
     const int n1 = A.so.n_post[w];
     const size_t b = (size_t)w * A.cap;
     if (tid < 64) {
@@ -2074,6 +2450,70 @@ int rl_world_launch_reset(rl_world* h, int n_agents, int threshold, float* obs, 
     else hipLaunchKernelGGL((k_reset<256>), dim3(h->cfg.n_worlds), dim3(256), h->smem_bytes, st, p);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { rl_set_error("reset kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
+    return RL_OK;
+}
+
+// rl_run: which kernel serves this handle / these brains, or 0
+static int run_kind_of(const rl_brain* brains, int n_brains)
+{
+    if (n_brains < 1 || n_brains > kRunMaxBrains) return -1;
+    bool duel = true;
+    for (int b = 0; b < n_brains; ++b) duel = duel && (brains[b].kind == RL_D3QN || brains[b].kind == RL_PERD3QN);
+    return duel ? RL_PERD3QN : -1;   // (D3QN and PERD3QN are the same network: PERD3QN.py:186-202, D3QN.py:149-165)
+}
+template <int KIND>
+static size_t run_smem_bytes(const rl_world* h, int T)
+{
+    PolSmem ps;
+    return carve_policy<KIND>(ps, nullptr, h->smem_bytes, h->cfg.slot_cap, T / 256);
+}
+int rl_world_run_supported(const rl_world* h, const rl_brain* brains, int n_brains)
+{
+    if (run_kind_of(brains, n_brains) < 0) return 0;
+    const int T = pick_block(h);
+    if (h->cfg.slot_cap > T) return 0;
+    return run_smem_bytes<RL_PERD3QN>(h, T) <= 160 * 1024;
+}
+int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n_ticks, int8_t* actions, const rl_step_out* so,
+                        float* const obs[2], int first, int16_t* upd_src, int refill_threshold, int refill_n_agents,
+                        int32_t* refill_count, hipStream_t st)
+{
+    if (!rl_world_run_supported(h, brains, n_brains)) { rl_set_error("rl_run: unsupported configuration (brain kinds / slot_cap / LDS)"); return RL_E_UNSUPPORTED; }
+    KParams p = make_params(h);
+    set_list_production(h, p, false);   // the row lists describe the state BEFORE this launch
+    p.actions = actions;
+    if (so) p.so = *so;
+    p.uo.src = upd_src; p.uo.obs = obs[first ^ 1];
+    p.refill_threshold = refill_threshold; p.reset_n_agents = refill_n_agents; p.refill_count = refill_count;
+    RunParams rp{};
+    rp.p = p;
+    RunArgs& ra = rp.ra;
+    for (int b = 0; b < n_brains; ++b) { ra.packed[b] = brains[b].packed; ra.eps[b] = brains[b].epsilon; }
+    ra.obs[0] = obs[0]; ra.obs[1] = obs[1]; ra.first = first; ra.n_ticks = n_ticks; ra.actions = actions;
+    ra.debug = getenv("RL_RUN_DEBUG") ? atoi(getenv("RL_RUN_DEBUG")) : 0;
+    const int T = pick_block(h);
+    const size_t bytes = run_smem_bytes<RL_PERD3QN>(h, T);
+    const bool fixed = p.W == kFixW && p.H == kFixH && p.cap == kFixCap && p.hash_size == kFixHash && !getenv("RL_WORLD_GENERIC");
+    const void* fn = T == 1024 ? (fixed ? (const void*)k_run<1024, true, RL_PERD3QN> : (const void*)k_run<1024, false, RL_PERD3QN>)
+                   : T == 512 ? (fixed ? (const void*)k_run<512, true, RL_PERD3QN> : (const void*)k_run<512, false, RL_PERD3QN>)
+                              : (fixed ? (const void*)k_run<256, true, RL_PERD3QN> : (const void*)k_run<256, false, RL_PERD3QN>);
+    if (bytes > 64 * 1024) {   // opt in to the large dynamic-LDS window (per device copy of the kernel: cheap, done every launch)
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) { rl_set_error("hipFuncSetAttribute(%zu bytes of LDS) failed: %s", bytes, hipGetErrorString(e)); return RL_E_LAUNCH; }
+    }
+    const dim3 grid(h->cfg.n_worlds);
+    if (T == 1024) {
+        if (fixed) hipLaunchKernelGGL((k_run<1024, true, RL_PERD3QN>), grid, dim3(1024), bytes, st, rp);
+        else hipLaunchKernelGGL((k_run<1024, false, RL_PERD3QN>), grid, dim3(1024), bytes, st, rp);
+    } else if (T == 512) {
+        if (fixed) hipLaunchKernelGGL((k_run<512, true, RL_PERD3QN>), grid, dim3(512), bytes, st, rp);
+        else hipLaunchKernelGGL((k_run<512, false, RL_PERD3QN>), grid, dim3(512), bytes, st, rp);
+    } else {
+        if (fixed) hipLaunchKernelGGL((k_run<256, true, RL_PERD3QN>), grid, dim3(256), bytes, st, rp);
+        else hipLaunchKernelGGL((k_run<256, false, RL_PERD3QN>), grid, dim3(256), bytes, st, rp);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rl_set_error("run kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
     return RL_OK;
 }
 

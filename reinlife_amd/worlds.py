@@ -256,6 +256,31 @@ class DeviceWorlds:
                                            threshold, n_agents, _ptr(self.refill_count), self._stream()), "rl_tick_refill")
         self._ticked = True
 
+    def run_supported(self):
+        return self._brains is not None and bool(self.lib.rl_run_supported(self.handle, self._brains, self.n_brains))
+
+    def run(self, n_ticks, threshold=-1, n_agents=0):
+        """n_ticks x (act() + tick_refill(threshold, n_agents)) -- or + tick() when threshold < 0 -- in ONE launch when the
+        configuration allows it (rl_run: every world stays in LDS between ticks), else the same loop over the two launches.
+        Either way the buffers afterwards hold the last tick's outputs."""
+        if self._brains is None:
+            raise _lib.ReinLifeHipError("set_brains() was not called")
+        if n_ticks <= 0:
+            return
+        if self.tracking or self.replays is not None or not self.run_supported():
+            for _ in range(n_ticks):
+                self.act()
+                if threshold >= 0:
+                    self.tick_refill(threshold, n_agents)
+                else:
+                    self.tick()
+            return
+        pair = (C.c_void_p * 2)(_ptr(self._obs2[0]), _ptr(self._obs2[1]))
+        _lib.check(self.lib.rl_run(self.handle, self._brains, self.n_brains, n_ticks, _ptr(self.actions), C.byref(self._step_out), pair,
+                                   self._cur, _ptr(self.src2), threshold, n_agents, _ptr(self.refill_count), self._stream()), "rl_run")
+        self._cur = (self._cur + n_ticks) & 1
+        self._ticked = True
+
     def observe(self):
         _lib.check(self.lib.rl_observe(self.handle, _ptr(self.obs2), self._stream()), "rl_observe")
         return self.obs_state()

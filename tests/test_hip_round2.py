@@ -317,10 +317,9 @@ def test_bench_rccl_path_at_world_size_one_reduces_the_same_counters():
     plain = _bench({})
     dist = _bench({"RL_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     assert plain["rccl_ranks"] == 1 and dist["rccl_ranks"] == 1 and dist["n_gpus"] == 1
-    for key in ("mean_agents_per_world", "world_refills", "worlds_total"):
+    for key in ("agent_steps", "mean_agents_per_world", "world_refills", "worlds_total"):
         assert plain["config"][key] == dist["config"][key], key
-    steps = lambda r: round(r["value"] * r["ms_per_step"] * 1e-3 * r["steps"])  # noqa: E731
-    assert abs(steps(plain) - steps(dist)) <= 2 and steps(plain) > 30 * 64 * 60
+    assert plain["config"]["agent_steps"] > 30 * 64 * 60
 
 
 def test_bench_refuses_more_gpus_than_there_are():
@@ -362,3 +361,109 @@ def test_replica_trajectories_do_not_depend_on_the_layout():
                 assert np.array_equal(got[w, : n[w]], want[w, : n[w]]), (key, w)
         else:
             assert np.array_equal(got, want), key
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rl_run: n ticks of policy + step + update_env (+ refill) in ONE launch, worlds resident in LDS
+# ---------------------------------------------------------------------------------------------------------------------
+def _run_pair(R, static, seed, block=None):
+    from reinlife_amd import _lib
+    from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights
+    cfg = dict(width=30, height=30, max_agents=100, n_brains=2, static_families=static, limit_reproduction=False, incentivize_killing=True)
+    names, eps = ["PERD3QN", "D3QN"], [0.0, 0.15]
+    wts = [_weights(n, 100 + k) for k, n in enumerate(names)]
+    out = []
+    for _ in range(2):
+        dw = DeviceWorlds(n_worlds=R, seed=seed, world_base=3, **cfg)
+        dw.set_brains([(_lib.KIND_BY_METHOD[n], e, pack_brain_weights(_lib.KIND_BY_METHOD[n], w)) for n, e, w in zip(names, eps, wts)])
+        dw.reset_synthetic(100)
+        out.append(dw)
+    return out, wts, names, eps, cfg
+
+
+def _same_device_state(a, b, tag):
+    n = a.s["n_agents"].cpu().numpy()
+    assert np.array_equal(n, b.s["n_agents"].cpu().numpy()), tag
+    for key in a.s:
+        x, y = a.s[key].cpu().numpy(), b.s[key].cpu().numpy()
+        if key.startswith("a_"):
+            for w in range(a.R):
+                assert np.array_equal(x[w, : n[w]], y[w, : n[w]]), (tag, key, w)
+        else:
+            assert np.array_equal(x, y), (tag, key)
+    _cmp_rows(a.obs_state().cpu().numpy(), b.obs_state().cpu().numpy(), n, tag + " obs2")
+
+
+@pytest.mark.parametrize("static", [True, False], ids=["static", "nonstatic"])
+@pytest.mark.parametrize("block", [None, 256], ids=["T1024", "T256"])
+def test_multi_tick_launch_equals_the_two_launch_loop(static, block, monkeypatch):
+    """rl_run(n) == n x (rl_policy_act + rl_tick_refill): world state, both observation buffers, the last tick's outputs and
+    actions, the counters -- for chunks of 1, 2, 7 and 30 ticks (odd and even: the Agent.state ping-pong), with refills."""
+    if block:
+        monkeypatch.setenv("RL_WORLD_BLOCK", str(block))
+    (fused, loop), *_ = _run_pair(20, static, 555)
+    assert fused.run_supported()
+    done = 0
+    for chunk in (1, 2, 7, 30, 1, 30, 30):
+        fused.run(chunk, 70, 100)
+        for _ in range(chunk):
+            loop.act(); loop.tick_refill(70, 100)
+        done += chunk
+        fused.check_error_flag(); loop.check_error_flag()
+        tag = "after %d ticks" % done
+        _same_device_state(fused, loop, tag)
+        n = fused.s["n_agents"].cpu().numpy()
+        n1 = None
+        assert np.array_equal(fused.n_acted.cpu().numpy(), loop.n_acted.cpu().numpy()), tag
+        acted = fused.n_acted.cpu().numpy()
+        _cmp_rows(fused.actions.cpu().numpy(), loop.actions.cpu().numpy(), acted, tag + " actions")
+        _cmp_rows(fused.prev_state().cpu().numpy(), loop.prev_state().cpu().numpy(), acted, tag + " policy input of the last tick")
+        assert int(fused.acted_total.item()) == int(loop.acted_total.item()) and int(fused.refill_count.item()) == int(loop.refill_count.item())
+        # post-step outputs of the last tick: the post-step list length is not stored; compare over the rows both paths wrote
+        for name in ("reward", "done", "src1"):
+            x, y = getattr(fused, name).cpu().numpy(), getattr(loop, name).cpu().numpy()
+            assert np.array_equal(x, y), (tag, name)
+        assert np.array_equal(fused.obs_state_prime().cpu().numpy(), loop.obs_state_prime().cpu().numpy()), tag + " obs1"
+        assert np.array_equal(fused.src2.cpu().numpy(), loop.src2.cpu().numpy()), tag + " src2"
+    assert int(fused.refill_count.item()) > 0
+
+
+def test_multi_tick_launch_tracks_the_oracle_tick_by_tick():
+    """run(1) per tick against the oracle fed the chosen actions: rl_run's own policy + tick, not just its agreement with the
+    other path."""
+    from oracle import oracle as orc
+    (fused, _), wts, names, eps, cfg = _run_pair(12, True, 808)
+    ow = orc.OracleWorlds(n_worlds=12, seed=808, world_base=3, **cfg)
+    ow.reset_synthetic(100)
+    for t in range(40):
+        n = ow.s["n_agents"].copy()
+        fused.run(1, 70, 100)
+        acts = fused.actions.cpu().numpy().copy()
+        if t % 8 == 0:   # the actions are the oracle's selection rule applied to an f32 forward (greedy brain: where the top two are apart)
+            ws, ks = np.nonzero((np.arange(fused.cap)[None, :] < n[:, None]) & (ow.s["a_brain"] == 0))
+            q = orc.policy_forward(orc.PERD3QN, wts[0], ow.obs2[ws, ks])
+            srt = np.sort(q, axis=1)
+            clear = srt[:, -1] - srt[:, -2] > 1e-5
+            assert np.array_equal(acts[ws, ks][clear], q.argmax(1)[clear])
+        ow.step(acts); ow.update(); ow.refill(70, 100)
+        fused.check_error_flag()
+        _cmp_state(fused, ow, "tick %d" % t)
+        _cmp_rows(fused.obs_state().cpu().numpy(), ow.obs2, ow.s["n_agents"], "tick %d obs2" % t)
+
+
+def test_multi_tick_launch_falls_back_when_unsupported():
+    """PPO brains (or tracking / capture) are outside rl_run's scope: DeviceWorlds.run loops over the two launches instead."""
+    from reinlife_amd import _lib
+    from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights
+    cfg = dict(width=30, height=30, max_agents=100, n_brains=2, static_families=True)
+    pair = []
+    for _ in range(2):
+        dw = DeviceWorlds(n_worlds=6, seed=4, **cfg)
+        dw.set_brains([(_lib.PPO, 0.0, pack_brain_weights(_lib.PPO, _weights("PPO", 1))), (_lib.PERD3QN, 0.0, pack_brain_weights(_lib.PERD3QN, _weights("PERD3QN", 2)))])
+        dw.reset_synthetic(100)
+        pair.append(dw)
+    assert not pair[0].run_supported()
+    pair[0].run(9, 70, 100)
+    for _ in range(9):
+        pair[1].act(); pair[1].tick_refill(70, 100)
+    _same_device_state(pair[0], pair[1], "fallback")
