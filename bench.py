@@ -8,7 +8,10 @@
     --gpus is an error, never a silent single-rank run.
 
 One "step" = one trainer-loop tick (Helpers/trainer.py:85-99 minus learn) of EVERY world on the GPU:
-    policy forward + action selection for all agents  ->  rl_tick (step + update_env, fused)  ->  rl_refill
+    policy forward + action selection for all agents  ->  step + update_env  ->  re-generation of worlds below 70 agents
+executed either by ONE multi-tick launch (rl_run: every world stays in its workgroup's LDS between ticks; --path fused, the
+default where it is faster: dueling brains, <= 768 worlds per GPU) or by two launches per tick (rl_policy_act + rl_tick_refill;
+--path two-launch).  Both write every per-tick output of the reference's loop every tick; same Philox streams, same worlds.
 Workload (BASELINE.json configs[3]): 256 independent 30x30 worlds per GPU x 100 agents, two
 PERD3QN brains (random-init weights of the reference architecture, greedy), static families, synthetic worlds from
 the Philox generator, a world is re-generated when its population drops below 70.  Worlds are sharded over GPUs
@@ -94,6 +97,21 @@ def one_step(dw):
     dw.tick_refill(70, 100)     # k_world<TICK>: step + update_env (+ re-generation of worlds below 70 agents)
 
 
+FUSED_CHUNK = 500   # ticks per rl_run launch (a launch of 500 ticks lasts ~15 ms)
+
+
+def run_ticks(dw, n, fused):
+    """n trainer-loop ticks of every world of `dw`."""
+    if fused:
+        while n > 0:
+            k = min(n, FUSED_CHUNK)
+            dw.run(k, 70, 100)      # k_run: policy + step + update_env + refill, k ticks in one launch
+            n -= k
+    else:
+        for _ in range(n):
+            one_step(dw)
+
+
 class StreamGroups:
     """--groups G > 1: the GPU's worlds as G independent DeviceWorlds, each on its own HIP stream, so that one group's
     policy launch can overlap another group's tick (both kernels are latency-bound at 256 worlds and leave issue slots
@@ -166,6 +184,8 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=20260928)
     ap.add_argument("--groups", type=int, default=1, help="split the GPU's worlds into this many stream groups (overlap)")
+    ap.add_argument("--path", default="auto", choices=["auto", "fused", "two-launch"],
+                    help="fused = one multi-tick launch (rl_run); two-launch = rl_policy_act + rl_tick_refill per tick")
     ap.add_argument("--burnin", type=int, default=300, help="untimed set-up ticks that de-synchronise the worlds' cohorts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -203,11 +223,20 @@ def main():
         grp = None
         dw = make_worlds(args, rank, device)
         step_all = lambda: one_step(dw)  # noqa: E731
-    for _ in range(args.burnin):   # set-up, untimed: past the start-up transient (see the module docstring)
-        step_all()
+    fused = grp is None and args.path != "two-launch" and dw.run_supported() and (args.worlds <= 768 or args.path == "fused")
+    if args.path == "fused" and not fused:
+        raise SystemExit("bench.py: --path fused is not available for this workload (brain kinds) / --groups")
+
+    def advance(n):
+        if grp:
+            for _ in range(n):
+                step_all()
+        else:
+            run_ticks(dw, n, fused)
+
+    advance(args.burnin)   # set-up, untimed: past the start-up transient (see the module docstring)
     torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step_all()
+    advance(args.warmup)
     torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps, inputs resident in HBM ------------------------------------------------------
@@ -225,8 +254,7 @@ def main():
             pass
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step_all()
+    advance(args.steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -242,6 +270,56 @@ def main():
 
     # ---- per-kernel durations with HIP events on the launch stream (untimed extra steps) ------------------------------
     roofline, extra = None, {}
+    fused_roof = None
+    if rank == 0 and not args.no_kernel_timing and fused:
+        # the multi-tick launch, HIP events around launches of N ticks; then its two halves alone (RL_RUN_DEBUG: the library
+        # skips one half of every tick -- results are then wrong, the work of the remaining half is the same)
+        def timed_run(n, debug=None):
+            if debug:
+                os.environ["RL_RUN_DEBUG"] = debug
+            try:
+                dw.run(20, 70, 100)
+                before = int(dw.acted_total.item())
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); dw.run(n, 70, 100); e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1e-3 / n, (int(dw.acted_total.item()) - before) / n
+            finally:
+                os.environ.pop("RL_RUN_DEBUG", None)
+        t_all, per_tick = timed_run(300)
+        wl = WORKLOADS[args.workload]
+        flop = float(np.mean([POLICY_FLOP_PER_AGENT[n] for n in wl["brains"]]))
+        by = TICK_BYTES_PER_AGENT_STEP + POLICY_BYTES_PER_AGENT
+        fused_roof = {"kernel": "k_run (rl_run: policy + step + update_env + refill, worlds resident in LDS)", "bound": "hbm",
+                      "achieved": round(per_tick * by / t_all / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(per_tick * by / t_all / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                      "avg_tick_us": round(t_all * 1e6, 2), "ticks_per_launch": 300, "agent_steps_per_tick": round(per_tick, 1),
+                      "bytes_per_agent_step": by,
+                      "mfma_tflops": round(per_tick * flop / t_all / 1e12, 2), "mfma_frac": round(per_tick * flop / t_all / 1e12 / MFMA_F32_EQUIV_PEAK_TFLOPS, 5)}
+        tpath = os.path.join(ROOT, "profiles", "run_traffic.json")
+        if os.path.exists(tpath) and args.worlds == 256 and args.workload == "c4":
+            try:
+                fused_roof["traffic"] = json.load(open(tpath)).get("hbm_bytes_per_tick")
+            except Exception:  # noqa: BLE001
+                pass
+        dw_state = {k: v.clone() for k, v in dw.s.items()}   # the half-runs leave wrong worlds behind: restore afterwards
+        obs_keep = [o.clone() for o in dw._obs2]
+        t_tick_half, n_tick_half = timed_run(200, "1")
+        for k, v in dw_state.items():
+            dw.s[k].copy_(v)
+        for o, keep in zip(dw._obs2, obs_keep):
+            o.copy_(keep)
+        t_pol_half, _ = timed_run(200, "2")
+        for k, v in dw_state.items():
+            dw.s[k].copy_(v)
+        for o, keep in zip(dw._obs2, obs_keep):
+            o.copy_(keep)
+        fused_roof["tick_half"] = {"us_per_tick": round(t_tick_half * 1e6, 2), "hbm_GBs": round(n_tick_half * TICK_BYTES_PER_AGENT_STEP / t_tick_half / 1e9, 1),
+                                   "hbm_frac": round(n_tick_half * TICK_BYTES_PER_AGENT_STEP / t_tick_half / 1e9 / HBM_PEAK_GBS, 4),
+                                   "how": "launches with the policy half skipped (RL_RUN_DEBUG=1)"}
+        fused_roof["policy_half"] = {"us_per_tick": round(t_pol_half * 1e6, 2), "mfma_tflops": round(per_tick * flop / t_pol_half / 1e12, 1),
+                                     "mfma_frac": round(per_tick * flop / t_pol_half / 1e12 / MFMA_F32_EQUIV_PEAK_TFLOPS, 4),
+                                     "how": "launches with the tick half skipped (RL_RUN_DEBUG=2)"}
     if rank == 0 and not args.no_kernel_timing:
         # (with --groups G the probe runs group 0 alone: its launches cover worlds/G worlds each)
         # back-to-back launches, no host sync inside the probe (a launch from an idle stream costs ~8 us extra): the event
@@ -284,6 +362,9 @@ def main():
                     "agent_steps_per_launch": round(per_launch, 1)}
         roofline = tick_roof if t_tick >= t_act else pol_roof
         extra = {"roofline_tick": tick_roof, "roofline_policy": pol_roof}
+        if fused_roof is not None:   # the timed region ran the multi-tick launch: that is the dominant kernel of the line
+            roofline = fused_roof
+            extra["two_launch_step_us"] = round((t_act + t_tick) * 1e6, 2)
         # variant (i) of BASELINE.md 3 / SURVEY.md 8d: "get_action + step" only.  The loop still runs update_env + refill (the
         # world must go on), but only policy + rl_step lie between the event pairs.
         if args.groups == 1:
@@ -326,7 +407,7 @@ def main():
             "dtype": "f32-grade policy via block-scaled 2 x f16 split on v_mfma_f32_32x32x16_f16 (f32 accumulate) / int32+u8 world state / f64 rewards",
             "data": "synthetic",
             "config": {"workload": wl["name"], "worlds_per_gpu": args.worlds, "worlds_total": args.worlds * max(1, world_size),
-                       "stream_groups": args.groups, "grid": "30x30", "max_agents": 100, "brains": wl["brains"], "static_families": wl["static_families"],
+                       "stream_groups": args.groups, "loop": "one multi-tick launch (rl_run)" if fused else "two launches per tick (rl_policy_act + rl_tick_refill)", "grid": "30x30", "max_agents": 100, "brains": wl["brains"], "static_families": wl["static_families"],
                        "refill_below": 70, "includes_update_env": True, "burn_in_ticks": args.burnin,
                        "mean_agents_per_world": round(total_agent_steps / (args.steps * args.worlds * max(1, world_size)), 2),
                        "world_refills": int(refills), "agent_steps": int(round(total_agent_steps)), "parallelism": "replica-sharded x%d, no data-path collective" % max(1, world_size)},

@@ -122,21 +122,28 @@ __device__ inline void mfma3(const f32x4 (&a)[kPlanes], const f32x4 (&b)[kPlanes
     cross = mfma16(a[1], b[0], cross);  // lo.hi
 }
 
-// two already-scaled values -> packed f16 pairs: hi = x toward zero (11 bits), lo = x - hi (exact in f32) toward zero.
-// lo of an element m times smaller than the row maximum is an f16 subnormal from m > 2^14 on: what is lost there is
-// below 2^-24 of the row maximum, i.e. below f32's own resolution of the dot product
-__device__ inline void split_pair(float x0, float x1, unsigned& hi, unsigned& lo)
+// Two values and their row's power-of-two scale -> packed f16 pairs: hi = f16(x * s) (round to nearest even), lo = f16(x * s - hi)
+// with x * s - hi evaluated exactly (one fused multiply-add in f32).  Four v_fma_mix instructions per pair -- the mixed-precision
+// FMA reads f32 and f16 sources and writes an f16 half directly; the earlier sequence (2 multiplies, cvt_pkrtz, 2 cvt back, 2
+// subtractions, cvt_pkrtz) was eight, and these splits are a third of the one-wave tile's instruction stream.
+// lo of an element m times smaller than the row maximum is an f16 subnormal from m > 2^14 on: what is lost there is below
+// 2^-24 of the row maximum, i.e. below f32's own resolution of the dot product.
+__device__ inline void split_pair(float x0, float x1, float sc, unsigned& hi, unsigned& lo)
 {
-    const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-    hi = __builtin_bit_cast(unsigned, h);
-    const auto l = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]);
-    lo = __builtin_bit_cast(unsigned, l);
+    unsigned h = 0, l = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(sc));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(sc));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(sc), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(sc), "v"(h));
+#endif
+    hi = h; lo = l;
 }
-__device__ inline void split8(const float (&x)[8], f32x4& hi, f32x4& lo)
+__device__ inline void split8(const float (&x)[8], float sc, f32x4& hi, f32x4& lo)
 {
     unsigned h[4], l[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) split_pair(x[2 * q], x[2 * q + 1], h[q], l[q]);
+    for (int q = 0; q < 4; ++q) split_pair(x[2 * q], x[2 * q + 1], sc, h[q], l[q]);
     hi = f32x4{__builtin_bit_cast(float, h[0]), __builtin_bit_cast(float, h[1]), __builtin_bit_cast(float, h[2]), __builtin_bit_cast(float, h[3])};
     lo = f32x4{__builtin_bit_cast(float, l[0]), __builtin_bit_cast(float, l[1]), __builtin_bit_cast(float, l[2]), __builtin_bit_cast(float, l[3])};
 }
@@ -210,8 +217,8 @@ __device__ inline void stage_x(f32x4* __restrict__ xs, float* __restrict__ row_u
         if (lane == 0) row_unscale[8 * v + rr] = un;
         if (lane < 40) {
             unsigned h0, l0, h1, l1;
-            split_pair(t.x * sc, t.y * sc, h0, l0);
-            split_pair(t.z * sc, t.w * sc, h1, l1);
+            split_pair(t.x, t.y, sc, h0, l0);
+            split_pair(t.z, t.w, sc, h1, l1);
             const int u = (unit0 + rr) * 2 + half;
             x2[u] = f32x2{__builtin_bit_cast(float, h0), __builtin_bit_cast(float, h1)};
             x2[kXPlane * 2 + u] = f32x2{__builtin_bit_cast(float, l0), __builtin_bit_cast(float, l1)};
@@ -355,9 +362,9 @@ __device__ inline void publish_tile(f32x4* lds, int plane_units, int t, int lane
     for (int c = 0; c < 2; ++c) {
         float x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = h[8 * c + e] * sc;
+        for (int e = 0; e < 8; ++e) x[e] = h[8 * c + e];
         f32x4 hi, lo;
-        split8(x, hi, lo);
+        split8(x, sc, hi, lo);
         const int u = (t * 2 + c) * 64 + lane;
         lds[u] = hi;
         lds[plane_units + u] = lo;
@@ -404,9 +411,9 @@ __device__ inline void head_mfma(const HeadW<NT, TSTRIDE>& w, const f32x16 (&hin
         for (int c = 0; c < 2; ++c) {
             float x[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = hin[t][8 * c + e] * sc;
+            for (int e = 0; e < 8; ++e) x[e] = hin[t][8 * c + e];
             f32x4 b[kPlanes];
-            split8(x, b[0], b[1]);
+            split8(x, sc, b[0], b[1]);
             mfma3(w.a[t][c], b, acc, cross);
         }
 #pragma unroll
@@ -645,6 +652,371 @@ __device__ inline void policy_tile(const TileIO& io, f32x4* __restrict__ lds_h, 
         }
     }
     RL_PMARK(9);
+    lds_barrier();  // lds_h / lds_part are reused by the next tile
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One WAVE per 32-row tile (the dueling kinds: D3QN / PERD3QN).
+//
+// The 4-wave tile above spends ~25 instructions per MFMA: every wave stages, scales and splits rows, publishes and re-reads
+// activations through LDS, crosses five workgroup barriers and keeps a weight ring for its quarter of the features -- 9,400
+// instructions per tile, and the launch is bound by instruction issue (SQ counters: profiles/r02a_policy_tick_sq_counters.txt).
+// Here ONE wave owns all four output tiles of every layer, so that
+//   * the accumulator layout IS the next layer's B operand for the wave itself: no LDS, no barrier, no exchange at all;
+//   * a weight fragment chunk (8 KB, contiguous in the packed layout) is requested once per tile instead of once per wave;
+//   * the observation rows are read straight into B-operand order (lane = row, half = k-group: 2 x 16 B per 16-k chunk);
+//   * four independent accumulators take the three partial products in turn (an accumulator is reused every 4th MFMA, beyond
+//     the 16-pass latency), so no separate cross-term accumulator is needed.
+// ~3,000 instructions per tile, 360 of them MFMAs; needs ~230 VGPRs (one or two waves per SIMD), which is what a launch of a
+// few tiles per SIMD wants anyway.  Summation order: per 16-k chunk hi.lo, hi.hi, lo.hi into ONE f32 accumulator.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NS, int D>
+__device__ inline void k_loop_reg4(WRing<4, 4, 1, D>& w, const f32x4 (&B)[NS][kPlanes], f32x16 (&acc)[4])
+{
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        f32x4 ac[4][kPlanes];
+        w.template next<NS>(s, ac);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(ac[t][0], B[s][1], acc[t]);  // hi.lo
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(ac[t][0], B[s][0], acc[t]);  // hi.hi
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(ac[t][1], B[s][0], acc[t]);  // lo.hi
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// head (8 / 1 outputs padded to one 32-row A tile): K = 128 over the wave's own activation fragments; three accumulator
+// chains (one per partial product) keep consecutive MFMAs independent.  out[r] = output 4 * (lane >> 5) + r of row lane & 31.
+template <int D>
+__device__ inline void head_reg(gfloat* __restrict__ hw, const f32x4 (&B)[8][kPlanes], float row_un, int lane, float (&out)[4])
+{
+    WRing<1, 1, 1, D> w;
+    w.start(hw, lane, 0);
+    const f32x4 un4 = ((gf32x4*)(hw + head_consts_off(4)))[lane >> 5];
+    f32x16 a0, a1, a2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; a2[r] = 0.0f; }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        f32x4 ac[1][kPlanes];
+        w.template next<8>(s, ac);
+        a0 = mfma16(ac[0][0], B[s][1], a0);
+        a1 = mfma16(ac[0][0], B[s][0], a1);
+        a2 = mfma16(ac[0][1], B[s][0], a2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = ((a0[r] + a1[r]) + a2[r]) * (un4[r] * row_un);
+}
+
+// epilogue of the four output tiles of a hidden layer (unscale, bias, ReLU), row maximum over all 128 features of the lane's
+// row, and the split of the result into the next layer's eight B fragments (chunk 2t + c = registers 8c .. 8c+7 of tile t)
+__device__ inline void layer_out_to_B(f32x16 (&acc)[4], gfloat* __restrict__ consts, int half, float row_un_in, f32x4 (&B)[8][kPlanes], float& row_un_out)
+{
+    float m = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        EpiConsts k;
+        k.start(consts, t, half);
+        epilogue_tile<true>(acc[t], k, row_un_in);
+        m = fmaxf(m, reg_max(acc[t]));
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));   // both k-halves of a row (lanes j and j + 32) use one factor
+    float sc;
+    row_scale(m, sc, row_un_out);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = acc[t][8 * c + e];
+            split8(x, sc, B[2 * t + c][0], B[2 * t + c][1]);
+        }
+}
+
+template <int KIND, bool COHERENT>
+__device__ inline void policy_tile1(const TileIO& io, int lane)
+{
+    static_assert(KIND == RL_D3QN || KIND == RL_PERD3QN, "one-wave tile: dueling kinds");
+    const int h = lane >> 5;
+    const Layout L = layout_of(KIND);
+    gfloat* __restrict__ packed = io.packed;
+    WRing<4, 4, 1, 2> w;
+    w.start(packed + L.l1, lane, 0);
+    // ---- the lane's half of its observation row, chunk by chunk: x[row][16c + 8h + 0..7]
+    f32x4 B1[kInChunks][kPlanes];
+    {
+        // chunk 9 of the upper half (k = 152 .. 159) holds one real input: it reads k = 149 .. 152 instead and keeps the last
+        // element, so that no load leaves the row
+        const int64_t rbase = io.row * RL_OBS_DIM;
+#pragma unroll
+        for (int c = 0; c < kInChunks; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k0 = (c == kInChunks - 1 && h == 1) ? 149 : 16 * c + 8 * h + 4 * q;
+                if (COHERENT) {
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)io.obs, 0, 0x7fffffff, 0x00027000);
+                    B1[c][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((rbase + k0) * 4), 0, 16 /* sc1 */));
+                } else
+                    B1[c][q] = *(const f32x4u*)(io.obs + rbase + k0);
+            }
+    }
+    rl_u4 draw = {0u, 0u, 0u, 0u};
+    if (io.actions) draw = rl_philox4x32(io.seed, io.key_epoch, io.key_world, io.key_tick, RL_SITE_ACT, io.key_index);  // while the rows are in flight
+    if (h == 1) { B1[kInChunks - 1][0] = f32x4{B1[kInChunks - 1][0].w, 0.0f, 0.0f, 0.0f}; B1[kInChunks - 1][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    float m = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kInChunks; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(B1[c][q].x), fabsf(B1[c][q].y)), fmaxf(fabsf(B1[c][q].z), fabsf(B1[c][q].w))));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sc0, un0;
+    row_scale(m, sc0, un0);
+#pragma unroll
+    for (int c = 0; c < kInChunks; ++c) {
+        const float x[8] = {B1[c][0].x, B1[c][0].y, B1[c][0].z, B1[c][0].w, B1[c][1].x, B1[c][1].y, B1[c][1].z, B1[c][1].w};
+        split8(x, sc0, B1[c][0], B1[c][1]);
+    }
+    // ---- input layer
+    f32x16 acc[4];
+    k_loop_reg4<kInChunks>(w, B1, acc);
+    w.start(packed + L.l2a, lane, 0);
+    f32x4 B2[8][kPlanes], B3[8][kPlanes];
+    float un1, un2;
+    layer_out_to_B(acc, packed + L.l1 + frag_floats(kInChunks, 4), h, un0, B2, un1);   // relu(feature) feeds both branches (PERD3QN.py:200-201)
+    // ---- advantage branch
+    k_loop_reg4<8>(w, B2, acc);
+    layer_out_to_B(acc, packed + L.l2a + frag_floats(8, 4), h, un1, B3, un2);
+    float adv[4], val[4];
+    head_reg<4>(packed + L.ha, B3, un2, lane, adv);
+    // ---- value branch
+    w.start(packed + L.l2b, lane, 0);
+    k_loop_reg4<8>(w, B2, acc);
+    layer_out_to_B(acc, packed + L.l2b + frag_floats(8, 4), h, un1, B3, un2);
+    head_reg<4>(packed + L.hb, B3, un2, lane, val);
+    // ---- dueling combine (per-row mean: PERD3QN.py:202 at batch 1), outputs, action
+    const f32x4 ba = ((gf32x4*)(packed + L.ha + head_consts_off(4) + 8))[h];
+    const float bv = packed[L.hb + head_consts_off(4) + 8];
+    float a4[4] = {adv[0] + ba.x, adv[1] + ba.y, adv[2] + ba.z, adv[3] + ba.w};
+    float o4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o4[r] = __shfl_xor(a4[r], 32);   // the other half's four advantages
+    if (h == 0) {
+        const float advs[8] = {a4[0], a4[1], a4[2], a4[3], o4[0], o4[1], o4[2], o4[3]};
+        float mean = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mean += advs[i];
+        mean *= 0.125f;
+        const float v = val[0] + bv;
+        float q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = advs[i] + v - mean;
+        if (io.valid) {
+            if (io.out) {
+                f32x4* o = (f32x4*)(io.out + io.row * 8);
+                o[0] = f32x4{q[0], q[1], q[2], q[3]};
+                o[1] = f32x4{q[4], q[5], q[6], q[7]};
+            }
+            if (io.actions) {
+                const float u = (float)rl_u24(draw.x);
+                int a = 0;
+                if (u < io.eps) a = (int)(draw.y >> 29);
+                else {
+                    float best = q[0];
+#pragma unroll
+                    for (int i = 1; i < 8; ++i) { const bool gt = q[i] > best; a = gt ? i : a; best = gt ? q[i] : best; }  // first maximum
+                }
+                io.actions[io.row] = (int8_t)a;
+                if (io.lds_actions_off >= 0) {
+                    extern __shared__ __attribute__((aligned(16))) char rl_dyn_lds[];
+                    ((signed char*)rl_dyn_lds)[io.lds_actions_off + io.lds_slot] = (signed char)a;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 64 rows per workgroup (the dueling kinds): two 32-row tiles share every weight fragment.
+//
+// What bounds the policy launches is not MFMA issue nor instruction issue but the WEIGHT BYTES that reach the CUs: a 32-row
+// tile pulls the brain's whole packed network (263 KB incl. epilogue constants) through its CU's vector L1, and the launches
+// sit at ~14 TB/s of L2 -> L1 traffic whatever the tile code looks like (179 MB / 12.7 us at 256 worlds, 2.87 GB / 200 us at
+// 4096; the 4-wave tile, the one-wave tile and a variant with 15 % fewer instructions all take the same time; re-reading one
+// L1-resident chunk instead of streaming changes nothing either: the return path into the registers is the limit).  So the
+// lever is rows per weight fetch: here every A fragment a wave loads feeds TWO B tiles (rows 0-31 and 32-63 of the workgroup),
+// which halves the bytes per row.  Per row the arithmetic, and therefore every result, is exactly that of policy_tile.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kRT = 2;
+__host__ __device__ constexpr int policy2_lds_units(int kind) { return kRT * policy_lds_units(kind); }
+
+template <int NS, int D>
+__device__ inline void k_loop2(WRing<4, 1, 1, D>& w, const f32x4* __restrict__ bsrc, int rt_units, int bplane, int bstep, f32x16 (&acc)[kRT],
+                               EpiConsts* epi = nullptr, gfloat* __restrict__ epi_consts = nullptr, int epi_t2 = 0, int epi_half = 0)
+{
+    f32x16 cross[kRT];
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[rt][r] = 0.0f; cross[rt][r] = 0.0f; }
+    f32x4 b[2][kRT][kPlanes];
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt)
+#pragma unroll
+        for (int pl = 0; pl < kPlanes; ++pl) b[0][rt][pl] = bsrc[rt * rt_units + pl * bplane];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        f32x4 ac[1][kPlanes];
+        w.template next<NS>(s, ac);
+        if (s + 1 < NS) {
+#pragma unroll
+            for (int rt = 0; rt < kRT; ++rt)
+#pragma unroll
+                for (int pl = 0; pl < kPlanes; ++pl) b[(s + 1) & 1][rt][pl] = bsrc[rt * rt_units + pl * bplane + (s + 1) * bstep];
+        }
+        // four accumulator chains (main / cross of the two row tiles): the same three products per row as policy_tile
+#pragma unroll
+        for (int rt = 0; rt < kRT; ++rt) cross[rt] = mfma16(ac[0][0], b[s & 1][rt][1], cross[rt]);
+#pragma unroll
+        for (int rt = 0; rt < kRT; ++rt) acc[rt] = mfma16(ac[0][0], b[s & 1][rt][0], acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < kRT; ++rt) cross[rt] = mfma16(ac[0][1], b[s & 1][rt][0], cross[rt]);
+        if (epi && s == (NS > 4 ? NS - 4 : 0)) epi->start(epi_consts, epi_t2, epi_half);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][r] += cross[rt][r];
+}
+
+// head of one row tile from the wave's registers, weights already in `w` (HeadW of policy_tile)
+__device__ inline void head_mfma1(const HeadW<1, 1>& w, const f32x16& hin, float (&out)[4])
+{
+    const f32x16 (&arr)[1] = reinterpret_cast<const f32x16 (&)[1]>(hin);
+    head_mfma(w, arr, out);
+}
+
+// io[rt]: rows / validity / keys of row tile rt (packed, obs, eps, out, actions, seed taken from io[0]).
+// LDS: lds_h = kRT x policy_lds_units(KIND) units, lds_aux = kRT x kAuxFloats, lds_part = kRT x [4][32][9].
+template <int KIND, bool COHERENT>
+__device__ inline void policy_tile2(const TileIO (&io)[kRT], f32x4* __restrict__ lds_h, float* __restrict__ lds_aux,
+                                    float (*__restrict__ lds_part)[32][9], int lane, int v)
+{
+    static_assert(KIND == RL_D3QN || KIND == RL_PERD3QN, "64-row tile: dueling kinds");
+    constexpr int PS = 4 * 2 * 64;                         // units per plane of the published activations
+    constexpr int RTU = policy_lds_units(KIND);            // units per row tile
+    const int h = lane >> 5, j = lane & 31;
+    const Layout L = layout_of(KIND);
+    gfloat* __restrict__ packed = io[0].packed;
+    const int xb = h * kXGroup + j;
+    f32x16 h1[kRT], h2[kRT];
+    float adv[kRT][4], val[kRT][4];
+    WRing<4, 1, 1, 3> w1, w2;
+    HeadW<1, 1> wh;
+    EpiConsts e1;
+    // wave v finishes row tile v (v < 2): its action draw and the head biases are fetched while the rows are in flight
+    rl_u4 draw = {0u, 0u, 0u, 0u};
+    f32x4 duel_ba0 = {0.0f, 0.0f, 0.0f, 0.0f}, duel_ba1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    float duel_bv = 0.0f;
+    const TileIO& mine = io[v < kRT ? v : 0];
+    auto early = [&]() {
+        if (v < kRT && mine.actions) draw = rl_philox4x32(mine.seed, mine.key_epoch, mine.key_world, mine.key_tick, RL_SITE_ACT, mine.key_index);
+    };
+    auto nothing = [&]() {};
+    w1.start(packed + L.l1, lane, v);
+    if (v < kRT) {
+        const gf32x4* ba = (const gf32x4*)(packed + L.ha + head_consts_off(4) + 8);
+        duel_ba0 = ba[0]; duel_ba1 = ba[1];
+        duel_bv = packed[L.hb + head_consts_off(4) + 8];
+    }
+    stage_x<COHERENT>(lds_h, lds_aux, io[0].obs, io[0].row, lane, v, early);
+    stage_x<COHERENT>(lds_h + RTU, lds_aux + kAuxFloats, io[0].obs, io[1].row, lane, v, nothing);
+    lds_barrier();
+    k_loop2<kInChunks>(w1, lds_h + xb, RTU, kXPlane, 2 * kXGroup, h1);
+    w2.start(packed + L.l2a, lane, v);
+    wh.start(packed + L.ha, 4, lane, v);
+    e1.start(packed + L.l1 + frag_floats(kInChunks, 4), v, h);
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt) {
+        epilogue_tile<true>(h1[rt], e1, lds_aux[rt * kAuxFloats + j]);   // relu(feature) feeds both branches (PERD3QN.py:200-201)
+        row_max_put(lds_aux + rt * kAuxFloats, j, v * 2 + h, reg_max(h1[rt]));
+    }
+    lds_barrier();   // every wave is done with the observation tiles: their LDS becomes the activation exchange
+    float un1[kRT];
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt) {
+        float sc1;
+        row_scale(row_max_get(lds_aux + rt * kAuxFloats, j), sc1, un1[rt]);
+        publish_tile(lds_h + rt * RTU, PS, v, lane, h1[rt], sc1);
+    }
+    lds_barrier();
+    k_loop2<8>(w2, lds_h + lane, RTU, PS, 64, h2);
+    w1.start(packed + L.l2b, lane, v);   // the value branch's first chunks arrive while the advantage head runs
+    e1.start(packed + L.l2a + frag_floats(8, 4), v, h);
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt) {
+        epilogue_tile<true>(h2[rt], e1, un1[rt]);
+        head_mfma1(wh, h2[rt], adv[rt]);
+    }
+    wh.start(packed + L.hb, 4, lane, v);
+    k_loop2<8>(w1, lds_h + lane, RTU, PS, 64, h2);
+    e1.start(packed + L.l2b + frag_floats(8, 4), v, h);
+#pragma unroll
+    for (int rt = 0; rt < kRT; ++rt) {
+        epilogue_tile<true>(h2[rt], e1, un1[rt]);
+        head_mfma1(wh, h2[rt], val[rt]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds_part[rt * 4 + v][j][4 * h + r] = adv[rt][r];
+        if (h == 0) lds_part[rt * 4 + v][j][8] = val[rt][0];
+    }
+    lds_barrier();
+    if (v < kRT && h == 0) {
+        float (*part)[32][9] = lds_part + v * 4;
+        float sum9[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sum9[i] = ((part[0][j][i] + part[1][j][i]) + part[2][j][i]) + part[3][j][i];
+        const float ba[8] = {duel_ba0.x, duel_ba0.y, duel_ba0.z, duel_ba0.w, duel_ba1.x, duel_ba1.y, duel_ba1.z, duel_ba1.w};
+        float a8[8], mean = 0.0f;  // advantage.mean() of the [1,8] tensor == per-row mean when batched
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a8[i] = sum9[i] + ba[i]; mean += a8[i]; }
+        mean *= 0.125f;
+        const float value = sum9[8] + duel_bv;
+        float q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = a8[i] + value - mean;
+        if (mine.valid) {
+            if (mine.out) {
+                f32x4* o = (f32x4*)(mine.out + mine.row * 8);
+                o[0] = f32x4{q[0], q[1], q[2], q[3]};
+                o[1] = f32x4{q[4], q[5], q[6], q[7]};
+            }
+            if (mine.actions) {
+                const float u = (float)rl_u24(draw.x);
+                int a = 0;
+                if (u < mine.eps) a = (int)(draw.y >> 29);
+                else {
+                    float best = q[0];
+#pragma unroll
+                    for (int i = 1; i < 8; ++i) { const bool gt = q[i] > best; a = gt ? i : a; best = gt ? q[i] : best; }  // first maximum
+                }
+                mine.actions[mine.row] = (int8_t)a;
+                if (mine.lds_actions_off >= 0) {
+                    extern __shared__ __attribute__((aligned(16))) char rl_dyn_lds[];
+                    ((signed char*)rl_dyn_lds)[mine.lds_actions_off + mine.lds_slot] = (signed char)a;
+                }
+            }
+        }
+    }
     lds_barrier();  // lds_h / lds_part are reused by the next tile
 }
 

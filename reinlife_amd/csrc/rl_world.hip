@@ -2022,7 +2022,12 @@ __device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& p
         }
     }
     lds_barrier();
-    const int ntiles = __builtin_amdgcn_readfirstlane(ps.meta[0]);
+    int ntiles = __builtin_amdgcn_readfirstlane(ps.meta[0]);
+    {   // tuning only (RL_RUN_DEBUG & 4 / & 8): run at most 2 / 1 tiles (results WRONG)
+        const int dbg = *(const int __attribute__((address_space(4)))*)&ka->ra.debug;
+        if (dbg & 4) ntiles = min(ntiles, 2);
+        if (dbg & 8) ntiles = min(ntiles, 1);
+    }
     for (int t0 = 0; t0 < ntiles; t0 += GROUPS) {   // uniform trip count: every group runs the same barriers
         const int ti = t0 + grp;
         const bool have = ti < ntiles;
@@ -2053,6 +2058,66 @@ __device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& p
     }
 }
 
+// The same with ONE wave per tile (policy_tile1: no LDS, no barrier inside a tile): wave i takes tiles i, i + T / 64, ...
+// Needs the 256-VGPR budget of a workgroup of at most 512 threads.
+template <int T, int KIND>
+__device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base)
+{
+    const int tid = rl_tidx(), lane = tid & 63, wave = tid >> 6, j = lane & 31;
+    if (wave == 0) {
+        int cnt = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int k = base + lane;
+            const int b = k < n ? s.brain[k] : -1;
+            for (int bb = 0; bb < p.n_brains; ++bb) { const int c = __popcll(__ballot(b == bb)); if (lane == bb) cnt += c; }
+        }
+        const int mine = lane < p.n_brains ? cnt : 0;
+        const int incl = wave_incl_scan(mine);
+        const int tiles = (mine + 31) >> 5;
+        const int tincl = wave_incl_scan(tiles);
+        if (lane < p.n_brains) { ps.bstart[lane] = incl - mine; ps.bcnt[lane] = mine; ps.tstart[lane] = tincl - tiles; }
+        if (lane == 63) ps.meta[0] = tincl;
+        int pos = incl - mine;
+        for (int base = 0; base < n; base += 64) {
+            const int k = base + lane;
+            const int b = k < n ? s.brain[k] : -1;
+            for (int bb = 0; bb < p.n_brains; ++bb) {
+                const unsigned long long m = __ballot(b == bb);
+                const int start = read_lane(pos, bb);
+                if (b == bb) ps.prow[start + __popcll(m & lowmask(lane))] = (short)k;
+                if (lane == bb) pos += __popcll(m);
+            }
+        }
+    }
+    lds_barrier();
+    const int ntiles = __builtin_amdgcn_readfirstlane(ps.meta[0]);
+    for (int ti = wave; ti < ntiles; ti += T / 64) {
+        int b = 0;
+        for (int bb = 1; bb < p.n_brains; ++bb) if (ps.tstart[bb] <= ti && ps.bcnt[bb] > 0) b = bb;
+        b = __builtin_amdgcn_readfirstlane(b);
+        const int cntb = ps.bcnt[b];
+        const int li = (ti - ps.tstart[b]) * 32 + j;
+        const int k = ps.prow[ps.bstart[b] + min(li, cntb - 1)];
+        TileIO io;
+        io.packed = (gfloat*)((const float* const __attribute__((address_space(4)))*)ka->ra.packed)[b];
+        io.obs = obs_rows;
+        io.row = (int64_t)w * p.cap + k;
+        io.valid = li < cntb;
+        io.eps = ((const float __attribute__((address_space(4)))*)ka->ra.eps)[b];
+        io.out = nullptr;
+        io.actions = *(int8_t* const __attribute__((address_space(4)))*)&ka->ra.actions;
+        io.seed = p.seed;
+        io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
+        io.key_index = (uint32_t)k;
+        io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
+#ifdef RL_PHASE_PROFILE
+        io.prof = nullptr;
+#endif
+        policy_tile1<KIND, RL_RUN_COHERENT>(io, lane);
+    }
+    lds_barrier();
+}
+
 // First half of a tick: the policy.  Reads the list length and the Agent.state parity from LDS.
 template <int T, bool FIXED, int KIND>
 __device__ __forceinline__ void run_policy_half(RunParamsC* ka)
@@ -2065,7 +2130,8 @@ __device__ __forceinline__ void run_policy_half(RunParamsC* ka)
     const int w = blockIdx.x;
     const int n = __builtin_amdgcn_readfirstlane(ps.meta[1]), cur = __builtin_amdgcn_readfirstlane(ps.meta[2]);
     const float* obs_in = ((float* const __attribute__((address_space(4)))*)ka->ra.obs)[cur];
-    run_policy<T, KIND>(p, s, ps, ka, w, n, obs_in, smem_raw);
+    if (T <= 512) run_policy1<T, KIND>(p, s, ps, ka, w, n, obs_in, smem_raw);
+    else run_policy<T, KIND>(p, s, ps, ka, w, n, obs_in, smem_raw);
 }
 
 // Second half: Environment.step + update_env (+ re-generation) out of LDS, then recycle_world.  Same sequence as
@@ -2467,10 +2533,20 @@ static size_t run_smem_bytes(const rl_world* h, int T)
     PolSmem ps;
     return carve_policy<KIND>(ps, nullptr, h->smem_bytes, h->cfg.slot_cap, T / 256);
 }
+// Workgroup size of the multi-tick kernel: 512 threads for few worlds (the one-wave policy tile needs the 256-VGPR budget; the
+// tick half alone would prefer 1024: 10.6 vs 13.1 us at 256 worlds), 256 when there are many worlds (several per CU).
+// RL_WORLD_BLOCK overrides it like for the other world kernels.
+static int run_block(const rl_world* h)
+{
+    const char* env = getenv("RL_WORLD_BLOCK");
+    const int forced = env ? atoi(env) : 0;
+    if (forced == 256 || forced == 512 || forced == 1024) return forced;
+    return h->cfg.n_worlds <= 768 ? 512 : 256;
+}
 int rl_world_run_supported(const rl_world* h, const rl_brain* brains, int n_brains)
 {
     if (run_kind_of(brains, n_brains) < 0) return 0;
-    const int T = pick_block(h);
+    const int T = run_block(h);
     if (h->cfg.slot_cap > T) return 0;
     return run_smem_bytes<RL_PERD3QN>(h, T) <= 160 * 1024;
 }
@@ -2491,7 +2567,7 @@ int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n
     for (int b = 0; b < n_brains; ++b) { ra.packed[b] = brains[b].packed; ra.eps[b] = brains[b].epsilon; }
     ra.obs[0] = obs[0]; ra.obs[1] = obs[1]; ra.first = first; ra.n_ticks = n_ticks; ra.actions = actions;
     ra.debug = getenv("RL_RUN_DEBUG") ? atoi(getenv("RL_RUN_DEBUG")) : 0;
-    const int T = pick_block(h);
+    const int T = run_block(h);
     const size_t bytes = run_smem_bytes<RL_PERD3QN>(h, T);
     const bool fixed = p.W == kFixW && p.H == kFixH && p.cap == kFixCap && p.hash_size == kFixHash && !getenv("RL_WORLD_GENERIC");
     const void* fn = T == 1024 ? (fixed ? (const void*)k_run<1024, true, RL_PERD3QN> : (const void*)k_run<1024, false, RL_PERD3QN>)

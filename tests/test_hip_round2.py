@@ -395,12 +395,16 @@ def _same_device_state(a, b, tag):
 
 
 @pytest.mark.parametrize("static", [True, False], ids=["static", "nonstatic"])
-@pytest.mark.parametrize("block", [None, 256], ids=["T1024", "T256"])
+@pytest.mark.parametrize("block", [None, 256, 1024], ids=["T512", "T256", "T1024"])
 def test_multi_tick_launch_equals_the_two_launch_loop(static, block, monkeypatch):
     """rl_run(n) == n x (rl_policy_act + rl_tick_refill): world state, both observation buffers, the last tick's outputs and
     actions, the counters -- for chunks of 1, 2, 7 and 30 ticks (odd and even: the Agent.state ping-pong), with refills."""
     if block:
         monkeypatch.setenv("RL_WORLD_BLOCK", str(block))
+    # rl_run's workgroups run the one-wave policy tile (policy_tile1); the stand-alone launch uses it too when asked to, and
+    # then the two paths must agree bit for bit (with its default 4-wave tile they agree to ~1e-7 in Q, like any two float32
+    # summation orders)
+    monkeypatch.setenv("RL_POLICY_VARIANT", "wave" if block != 1024 else "nsplit")
     (fused, loop), *_ = _run_pair(20, static, 555)
     assert fused.run_supported()
     done = 0
