@@ -285,6 +285,7 @@ struct EpiConsts {
     }
 };
 
+
 // K loop of one layer: B fragments from LDS planes `bsrc` (unit stride `bstep` per chunk, plane stride `bplane`), A
 // fragments from the ring.  Leaves acc[t] = sum hi.hi + hi.lo + lo.hi, still in the scaled domain.
 template <int NS, int TOUT, int NT, int TSTRIDE, int D>
@@ -432,6 +433,7 @@ struct TileIO {
     uint32_t key_world, key_tick, key_epoch, key_index;
     int lds_actions_off;   // optional (multi-tick kernel): byte offset of the world's action array in the DYNAMIC LDS region
     int lds_slot;          // (-1 = none), and the slot of tile row (lane & 31) in it
+    int x_lds_off;         // one-wave tile in the multi-tick kernel: byte offset of this lane's row in the LDS mirror, or -1 (read obs)
 #ifdef RL_PHASE_PROFILE
     long long* prof;       // tuning build: shader-clock stamps (slots 48..), non-null in the profiled workgroup only
 #endif
@@ -741,7 +743,7 @@ __device__ inline void layer_out_to_B(f32x16 (&acc)[4], gfloat* __restrict__ con
         }
 }
 
-template <int KIND, bool COHERENT>
+template <int KIND, bool COHERENT, bool XLDS = false>
 __device__ inline void policy_tile1(const TileIO& io, int lane)
 {
     static_assert(KIND == RL_D3QN || KIND == RL_PERD3QN, "one-wave tile: dueling kinds");
@@ -756,6 +758,17 @@ __device__ inline void policy_tile1(const TileIO& io, int lane)
         // chunk 9 of the upper half (k = 152 .. 159) holds one real input: it reads k = 149 .. 152 instead and keeps the last
         // element, so that no load leaves the row
         const int64_t rbase = io.row * RL_OBS_DIM;
+        if (XLDS && io.x_lds_off >= 0) {   // the row is mirrored in LDS (same float32 values): 20 x ds_read_b128, no trip through L2
+            extern __shared__ __attribute__((aligned(16))) char rl_dyn_lds[];
+            const float* xr = (const float*)(rl_dyn_lds + io.x_lds_off);
+#pragma unroll
+            for (int c = 0; c < kInChunks; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (c == kInChunks - 1 && h == 1) B1[c][q] = f32x4{xr[149], xr[150], xr[151], xr[152]};   // (not 16-byte aligned)
+                    else B1[c][q] = *(const f32x4*)(xr + 16 * c + 8 * h + 4 * q);
+                }
+        } else
 #pragma unroll
         for (int c = 0; c < kInChunks; ++c)
 #pragma unroll

@@ -636,8 +636,11 @@ __device__ __forceinline__ void build_planes(const KParams& p, Smem& s, int t0 =
 
 // _get_observations (environment.py:349-375): n agents in order[] -> obs rows (coalesced 49-float runs).  Executed by NT
 // threads, `t` = this thread's index among them (the fused tick lets wave 0 run _reproduce meanwhile).
+// `mirror` (optional, LDS): the same rows as float32 [xrows][kXStride] for the in-workgroup policy of k_run (rows >= xrows only
+// go to HBM).
+constexpr int kXStride = 164;   // floats per mirrored row (656 B: 16-byte aligned rows, spread over the banks)
 template <int NT>
-__device__ __forceinline__ void write_observations(const KParams& p, Smem& s, int w, int n, float* obs, int t)
+__device__ __forceinline__ void write_observations(const KParams& p, Smem& s, int w, int n, float* obs, int t, float* mirror = nullptr, int xrows = 0)
 {
     if (!obs || RL_ABL(1)) return;
     float* base = obs + (size_t)w * p.cap * RL_OBS_DIM;
@@ -661,9 +664,11 @@ __device__ __forceinline__ void write_observations(const KParams& p, Smem& s, in
                 cj += cj < 0 ? p.W : 0; cj -= cj >= p.W ? p.W : 0;
                 const int c = ci * p.W + cj;
                 const int g = s.genev[c];
-                o[0] = s.foodv[c];
-                o[49] = s.healthv[c];
-                o[98] = g == -2 ? 0.f : (g == s.gene[a] ? 1.f : -1.f);  // _extract_gene_observation, environment.py:424-428
+                const float vf = s.foodv[c], vh = s.healthv[c], vg = g == -2 ? 0.f : (g == s.gene[a] ? 1.f : -1.f);  // _extract_gene_observation, environment.py:424-428
+                o[0] = vf;
+                o[49] = vh;
+                o[98] = vg;
+                if (mirror && k < xrows) { float* m = mirror + k * kXStride + idx; m[0] = vf; m[49] = vh; m[98] = vg; }
             }
         } else
         for (int k = g0; k < n; k += U * G, o += (size_t)(U * G) * RL_OBS_DIM) {
@@ -687,9 +692,11 @@ __device__ __forceinline__ void write_observations(const KParams& p, Smem& s, in
             for (int u = 0; u < U; ++u)
                 if (ok[u]) {
                     float* ou = o + (size_t)(u * G) * RL_OBS_DIM;
+                    const float vg = g[u] == -2 ? 0.f : (g[u] == ga[u] ? 1.f : -1.f);  // _extract_gene_observation, environment.py:424-428
                     ou[0] = f[u];
                     ou[49] = h[u];
-                    ou[98] = g[u] == -2 ? 0.f : (g[u] == ga[u] ? 1.f : -1.f);  // _extract_gene_observation, environment.py:424-428
+                    ou[98] = vg;
+                    if (mirror && k + u * G < xrows) { float* m = mirror + (k + u * G) * kXStride + idx; m[0] = f[u]; m[49] = h[u]; m[98] = vg; }
                 }
         }
     }
@@ -697,18 +704,20 @@ __device__ __forceinline__ void write_observations(const KParams& p, Smem& s, in
         const int a = s.order[k];
         const int same = (int)(s.hcnt[s.hslot[a]] >> 16);
         float* o = base + (size_t)k * RL_OBS_DIM + 147;
-        o[0] = (float)((double)s.health[a] * 0.005);  // == (float)(health / 200.0), see build_planes
-        o[1] = (s.flags[a] & RL_F_REPRODUCED) ? 1.f : 0.f;
-        o[2] = (float)((double)same / (double)n);
-        o[3] = (float)((double)n / (double)p.max_agents);
-        o[4] = (s.flags[a] & RL_F_KILLED) ? 1.f : 0.f;
-        o[5] = (s.flags[a] & RL_F_ATE_SUPER) ? 1.f : -1.f;
+        const float v0 = (float)((double)s.health[a] * 0.005);  // == (float)(health / 200.0), see build_planes
+        const float v1 = (s.flags[a] & RL_F_REPRODUCED) ? 1.f : 0.f;
+        const float v2 = (float)((double)same / (double)n);
+        const float v3 = (float)((double)n / (double)p.max_agents);
+        const float v4 = (s.flags[a] & RL_F_KILLED) ? 1.f : 0.f;
+        const float v5 = (s.flags[a] & RL_F_ATE_SUPER) ? 1.f : -1.f;
+        o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4; o[5] = v5;
+        if (mirror && k < xrows) { float* m = mirror + k * kXStride + 147; m[0] = v0; m[1] = v1; m[2] = v2; m[3] = v3; m[4] = v4; m[5] = v5; }
     }
 }
 template <int T>
-__device__ inline void write_observations(const KParams& p, Smem& s, int w, int n, float* obs)
+__device__ inline void write_observations(const KParams& p, Smem& s, int w, int n, float* obs, float* mirror = nullptr, int xrows = 0)
 {
-    write_observations<T>(p, s, w, n, obs, rl_tidx());
+    write_observations<T>(p, s, w, n, obs, rl_tidx(), mirror, xrows);
 }
 
 // Lean tick: every Philox draw of the tick depends only on (seed, epoch, world, tick, site, index), so the idle upper half of
@@ -1864,10 +1873,11 @@ __global__ __launch_bounds__(T) void k_reset(const KParams p)
 // ---------------------------------------------------------------------------------------------------------------
 #include "rl_policy_dev.h"
 
+constexpr int kRunMaxBrains = 8;
+
 #ifndef RL_RUN_COHERENT
 #define RL_RUN_COHERENT true
 #endif
-constexpr int kRunMaxBrains = 8;
 struct RunArgs {
     const float* packed[kRunMaxBrains];   // device: packed weights per brains-list entry
     float eps[kRunMaxBrains];
@@ -1885,19 +1895,31 @@ struct PolSmem {
     int* bstart;        // [64] first entry of brain b in prow
     int* bcnt;          // [64]
     int* tstart;        // [64] first tile of brain b
-    int* meta;          // [8]  [0] number of tiles; loop state of k_run: [1] list length, [2] Agent.state parity, [3] ticks done
+    int* meta;          // [8]  [0] number of tiles; loop state of k_run: [1] list length, [2] Agent.state parity, [3] ticks done,
+                        //      [4] the LDS mirror holds the current Agent.state rows
+    float* xmirror;     // [xrows][kXStride] Agent.state rows of this world for the one-wave policy tile (T <= 512), or null
+    int xrows;
 };
 template <int KIND>
 __host__ __device__ constexpr int policy_group_bytes()
 {
     return (int)(align16(sizeof(f32x4) * (size_t)policy_lds_units(KIND)) + align16(sizeof(float) * kAuxFloats) + align16(sizeof(float) * 4 * 32 * 9));
 }
+// groups > 0: `groups` blocks for the 4-wave tile (T = 1024).  groups == 0: the one-wave tile needs no LDS of its own; with
+// mirror_budget > 0 the Agent.state rows are mirrored in LDS instead (as many rows as fit below the budget, at most cap).
 template <int KIND>
-__host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o, int cap, int groups)
+__host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o, int cap, int groups, size_t mirror_budget = 0)
 {
     o = align16(o);
     ps.group0 = base + o; ps.group_bytes = policy_group_bytes<KIND>();
     o += (size_t)groups * policy_group_bytes<KIND>();
+    ps.xmirror = nullptr; ps.xrows = 0;
+    if (groups == 0 && mirror_budget > o + 4096) {
+        const size_t rows = (mirror_budget - o - 4096) / (sizeof(float) * kXStride);
+        ps.xrows = (int)(rows < (size_t)cap ? rows : (size_t)cap);
+        if (ps.xrows >= 32) { ps.xmirror = (float*)(base + o); o = align16(o + sizeof(float) * kXStride * (size_t)ps.xrows); }
+        else ps.xrows = 0;
+    }
     ps.prow = (short*)(base + o); o = align16(o + sizeof(short) * (size_t)cap);
     ps.bstart = (int*)(base + o); o = align16(o + sizeof(int) * 64);
     ps.bcnt = (int*)(base + o); o = align16(o + sizeof(int) * 64);
@@ -1928,7 +1950,7 @@ __device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& p
 // Between two ticks of k_run: the post-update list becomes slots 0..n-1 (slot == list index, what load_world establishes),
 // and every per-tick scratch is reset to what load_world leaves behind.  slot_cap <= T: one agent per thread.
 template <int T, bool SPEC>
-__device__ __forceinline__ void recycle_world(const KParams& p, Smem& s, int n, int tick, int epoch, int next_uid, int max_gene)
+__device__ __forceinline__ void recycle_world(const KParams& p, Smem& s, int n, int tick, int epoch, int next_uid, int max_gene, bool drain_stores)
 {
     const int tid = rl_tidx();
     const bool mine = tid < n;
@@ -1952,7 +1974,7 @@ __device__ __forceinline__ void recycle_world(const KParams& p, Smem& s, int n, 
         s.scal[tid] = tid == S_NSLOTS ? n : tid == S_TICK ? tick : tid == S_EPOCH ? epoch : tid == S_NEXT_UID ? next_uid : tid == S_MAX_GENE ? max_gene : 0;
     lds_barrier();
     if (mine) s.occ[(r_pos & 255) * p.W + (r_pos >> 8)] = (short)tid;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tick's observation rows are in L2 before any wave reads them back
+    if (drain_stores) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tick's observation rows are in L2 before any wave reads them back
     lds_barrier();
 }
 
@@ -1981,11 +2003,17 @@ __device__ inline KParams run_params(RunParamsC* ka)
     }
     return p;
 }
+// LDS of the multi-tick kernel per workgroup size: T = 1024 runs the 4-wave policy tile (four tile blocks); T = 512 the one-wave
+// tile with the Agent.state rows mirrored in what is left of the CU's 160 KB; T = 256 (several worlds per CU) the one-wave tile
+// reading its rows back from L2.
+constexpr size_t kRunLdsBudget = 160 * 1024;
+__host__ __device__ constexpr int run_groups(int T) { return T == 1024 ? 4 : 0; }
+__host__ __device__ constexpr size_t run_mirror_budget(int T) { return T == 512 ? kRunLdsBudget : 0; }
 template <bool FIXED, int KIND>
-__device__ inline void run_carve(const KParams& p, Smem& s, PolSmem& ps, char* smem_raw, int groups)
+__device__ inline void run_carve(const KParams& p, Smem& s, PolSmem& ps, char* smem_raw, int T)
 {
     const size_t o0 = FIXED ? carve(s, smem_raw, kFixCp, kFixCap, kFixHash) : carve(s, smem_raw, p.Cp, p.cap, p.hash_size);
-    carve_policy<KIND>(ps, smem_raw, o0, p.cap, groups);
+    carve_policy<KIND>(ps, smem_raw, o0, p.cap, run_groups(T), run_mirror_budget(T));
 }
 
 template <int T, int KIND>
@@ -2050,6 +2078,7 @@ __device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& p
         io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
         io.key_index = (uint32_t)k;
         io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
+        io.x_lds_off = -1;
 #ifdef RL_PHASE_PROFILE
         io.prof = (p.prof && (int)blockIdx.x == p.prof_world) ? p.prof : nullptr;
         if (io.prof && rl_tidx() == 0) io.prof[101] = (long long)clock64();
@@ -2091,6 +2120,7 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
     }
     lds_barrier();
     const int ntiles = __builtin_amdgcn_readfirstlane(ps.meta[0]);
+    const bool mirrored = ps.xmirror != nullptr && __builtin_amdgcn_readfirstlane(ps.meta[4]) != 0;
     for (int ti = wave; ti < ntiles; ti += T / 64) {
         int b = 0;
         for (int bb = 1; bb < p.n_brains; ++bb) if (ps.tstart[bb] <= ti && ps.bcnt[bb] > 0) b = bb;
@@ -2110,10 +2140,12 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
         io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
         io.key_index = (uint32_t)k;
         io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
+        io.x_lds_off = (mirrored && k < ps.xrows) ? (int)((char*)(ps.xmirror + k * kXStride) - smem_base) : -1;
+          // (the epilogue constants from an LDS copy instead of L2: measured, no gain -- 31.0 vs 30.1 us per tick)
 #ifdef RL_PHASE_PROFILE
         io.prof = nullptr;
 #endif
-        policy_tile1<KIND, RL_RUN_COHERENT>(io, lane);
+        policy_tile1<KIND, RL_RUN_COHERENT, true>(io, lane);
     }
     lds_barrier();
 }
@@ -2126,7 +2158,7 @@ __device__ __forceinline__ void run_policy_half(RunParamsC* ka)
     const KParams p = run_params<FIXED>(ka);
     Smem s;
     PolSmem ps;
-    run_carve<FIXED, KIND>(p, s, ps, smem_raw, T / 256);
+    run_carve<FIXED, KIND>(p, s, ps, smem_raw, T);
     const int w = blockIdx.x;
     const int n = __builtin_amdgcn_readfirstlane(ps.meta[1]), cur = __builtin_amdgcn_readfirstlane(ps.meta[2]);
     const float* obs_in = ((float* const __attribute__((address_space(4)))*)ka->ra.obs)[cur];
@@ -2143,7 +2175,7 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     const KParams p = run_params<FIXED>(ka);
     Smem s;
     PolSmem ps;
-    run_carve<FIXED, KIND>(p, s, ps, smem_raw, T / 256);
+    run_carve<FIXED, KIND>(p, s, ps, smem_raw, T);
     const int w = blockIdx.x;
     const int n0 = __builtin_amdgcn_readfirstlane(ps.meta[1]), cur = __builtin_amdgcn_readfirstlane(ps.meta[2]);
     const int ticks_done = __builtin_amdgcn_readfirstlane(ps.meta[3]);
@@ -2224,9 +2256,10 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     lds_barrier();
     if (p.uo.src)
         for (int k = tid; k < n2; k += T) p.uo.src[b + k] = refill ? (short)-1 : s.src[s.order[k]];
-    write_observations<T>(p, s, w, n2, obs_out);
-    if (tid == 0) { ps.meta[1] = n2; ps.meta[2] = cur ^ 1; ps.meta[3] = ticks_done + 1; }
-    recycle_world<T, kSpec>(p, s, n2, tick_next, epoch_next, next_uid, max_gene);
+    write_observations<T>(p, s, w, n2, obs_out, ps.xmirror, ps.xrows);
+    if (tid == 0) { ps.meta[1] = n2; ps.meta[2] = cur ^ 1; ps.meta[3] = ticks_done + 1; ps.meta[4] = ps.xmirror != nullptr; }
+    // (rows the policy will read back from memory must have reached L2 first; with every row mirrored in LDS the stores just drain)
+    recycle_world<T, kSpec>(p, s, n2, tick_next, epoch_next, next_uid, max_gene, ps.xmirror == nullptr || n2 > ps.xrows);
 }
 
 template <int T, int KIND>
@@ -2242,10 +2275,10 @@ __device__ __forceinline__ void run_load_call(RunParamsC* ka)   // (inlined: loa
     const KParams p = run_params<FIXED>(ka);
     Smem s;
     PolSmem ps;
-    run_carve<FIXED, KIND>(p, s, ps, smem_raw, T / 256);
+    run_carve<FIXED, KIND>(p, s, ps, smem_raw, T);
     int n0;
     load_world<T, (T == 1024)>(p, s, (int)blockIdx.x, n0);
-    if (rl_tidx() == 0) { ps.meta[1] = n0; ps.meta[2] = *(cint*)&ka->ra.first; ps.meta[3] = 0; }
+    if (rl_tidx() == 0) { ps.meta[1] = n0; ps.meta[2] = *(cint*)&ka->ra.first; ps.meta[3] = 0; ps.meta[4] = 0; }
     lds_barrier();
 }
 template <int T, bool FIXED, int KIND>
@@ -2255,7 +2288,7 @@ __device__ __forceinline__ void run_store_call(RunParamsC* ka)
     const KParams p = run_params<FIXED>(ka);
     Smem s;
     PolSmem ps;
-    run_carve<FIXED, KIND>(p, s, ps, smem_raw, T / 256);
+    run_carve<FIXED, KIND>(p, s, ps, smem_raw, T);
     store_world<T>(p, s, (int)blockIdx.x, ps.meta[1]);
     if (rl_tidx() == 0) { p.st.tick[blockIdx.x] = s.scal[S_TICK]; p.st.epoch[blockIdx.x] = s.scal[S_EPOCH]; p.st.next_uid[blockIdx.x] = s.scal[S_NEXT_UID]; p.st.max_gene[blockIdx.x] = s.scal[S_MAX_GENE]; }
 }
@@ -2531,7 +2564,7 @@ template <int KIND>
 static size_t run_smem_bytes(const rl_world* h, int T)
 {
     PolSmem ps;
-    return carve_policy<KIND>(ps, nullptr, h->smem_bytes, h->cfg.slot_cap, T / 256);
+    return carve_policy<KIND>(ps, nullptr, h->smem_bytes, h->cfg.slot_cap, run_groups(T), run_mirror_budget(T));
 }
 // Workgroup size of the multi-tick kernel: 512 threads for few worlds (the one-wave policy tile needs the 256-VGPR budget; the
 // tick half alone would prefer 1024: 10.6 vs 13.1 us at 256 worlds), 256 when there are many worlds (several per CU).

@@ -15,7 +15,15 @@ for _ in range(3):
     y.copy_(x)            # known traffic: 512 MiB read + 512 MiB written per call
 torch.cuda.synchronize()
 dw = bench.make_worlds(args, 0, "cuda:0")
-for _ in range(40):
-    bench.one_step(dw)
+fused = os.environ.get("RL_PMC_PATH", "fused") == "fused" and dw.run_supported() and args.worlds <= 768
+TICKS, LAUNCHES = 40, 5
+if fused:   # the multi-tick launch: LAUNCHES dispatches of TICKS ticks each
+    for _ in range(LAUNCHES):
+        dw.run(TICKS, 70, 100)
+    print("ticks_per_launch", TICKS)
+else:
+    for _ in range(TICKS * LAUNCHES):
+        bench.one_step(dw)
+    print("ticks_per_launch", 1)
 torch.cuda.synchronize()
-print("agent_steps_per_tick", float(dw.acted_total.item()) / 40)
+print("agent_steps_per_tick", float(dw.acted_total.item()) / (TICKS * LAUNCHES))

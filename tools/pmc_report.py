@@ -52,11 +52,27 @@ for name, d in res.items():
         ff = summary.get("calibration", {}).get("fetch_factor", 2.0)
         summary["policy_kernel"] = name
         summary["policy_hbm_bytes_per_launch"] = d.get("FETCH_SIZE", (0, 0))[0] * 1024 * ff + d.get("WRITE_SIZE", (0, 0))[0] * 1024
+ticks_per_launch = 1
 for log in ("FETCH_SIZE.log", "WRITE_SIZE.log"):
     try:
         for line in open(os.path.join(out, log)):
             if line.startswith("agent_steps_per_tick"):
                 summary["agent_steps_per_launch"] = float(line.split()[1])
+                summary["agent_steps_per_tick"] = float(line.split()[1])
+            if line.startswith("ticks_per_launch"):
+                ticks_per_launch = int(line.split()[1])
     except OSError:
         pass
+for name, d in res.items():
+    if "k_run" in name:   # the multi-tick launch: bytes per TICK
+        ff = summary.get("calibration", {}).get("fetch_factor", 2.0)
+        wf = summary.get("calibration", {}).get("write_factor", 1.0)
+        rd = d.get("FETCH_SIZE", (0, 0))[0] * 1024 * ff / ticks_per_launch
+        wr = d.get("WRITE_SIZE", (0, 0))[0] * 1024 * wf / ticks_per_launch
+        summary["run_kernel"] = name
+        summary["ticks_per_launch"] = ticks_per_launch
+        summary["hbm_read_bytes_per_tick"] = rd
+        summary["hbm_write_bytes_per_tick"] = wr
+        summary["hbm_bytes_per_tick"] = rd + wr
+        print("multi-tick launch: read %.2f MB + write %.2f MB = %.2f MB per tick (calibrated, %d ticks per launch)" % (rd / 1e6, wr / 1e6, (rd + wr) / 1e6, ticks_per_launch))
 json.dump(summary, open(os.path.join(out, "tick_traffic.json"), "w"), indent=1)

@@ -30,7 +30,7 @@ def short(n):
 
 
 for name in sorted(per):
-    if not ("k_policy" in name or "k_world" in name or "k_bucket" in name):
+    if not ("k_policy" in name or "k_world" in name or "k_bucket" in name or "k_run" in name):
         continue
     c = {k: v[0] for k, v in per[name].items()}
     print("== %s   (dispatches per pass: %d)" % (short(name), max(v[1] for v in per[name].values())))
