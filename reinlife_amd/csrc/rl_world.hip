@@ -2119,7 +2119,13 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
         }
     }
     lds_barrier();
-    const int ntiles = __builtin_amdgcn_readfirstlane(ps.meta[0]);
+    int ntiles = __builtin_amdgcn_readfirstlane(ps.meta[0]);
+    {   // tuning only (RL_RUN_DEBUG & 4 / & 8): run at most 2 / 1 tiles (results WRONG)
+        const int dbg = *(const int __attribute__((address_space(4)))*)&ka->ra.debug;
+        if (dbg & 4) ntiles = min(ntiles, 2);
+        if (dbg & 8) ntiles = min(ntiles, 1);
+        if (dbg & 16) ntiles = min(ntiles, 3);
+    }
     const bool mirrored = ps.xmirror != nullptr && __builtin_amdgcn_readfirstlane(ps.meta[4]) != 0;
     for (int ti = wave; ti < ntiles; ti += T / 64) {
         int b = 0;
