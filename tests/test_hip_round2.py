@@ -471,3 +471,45 @@ def test_multi_tick_launch_falls_back_when_unsupported():
     for _ in range(9):
         pair[1].act(); pair[1].tick_refill(70, 100)
     _same_device_state(pair[0], pair[1], "fallback")
+
+
+@pytest.mark.parametrize("width,height,max_agents,n_new,thr,limit", [(20, 15, 60, 50, 40, False), (30, 30, 100, 100, 70, True), (12, 9, 20, 18, 12, False)],
+                         ids=["20x15", "30x30-limit_reproduction", "12x9"])
+@pytest.mark.parametrize("block", [None, 256, 1024], ids=["T512", "T256", "T1024"])
+def test_multi_tick_launch_other_shapes_and_the_sequential_update(width, height, max_agents, n_new, thr, limit, block, monkeypatch):
+    """k_run's generic (not shape-specialised) instantiations and the limit_reproduction path (update_env not overlapped with the
+    observation pass), at every workgroup size, against the two-launch loop AND the oracle."""
+    from oracle import oracle as orc
+    from reinlife_amd import _lib
+    from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights
+    if block:
+        monkeypatch.setenv("RL_WORLD_BLOCK", str(block))
+    monkeypatch.setenv("RL_POLICY_VARIANT", "wave" if block != 1024 else "nsplit")
+    R = 10
+    cfg = dict(width=width, height=height, max_agents=max_agents, n_brains=2, static_families=True, limit_reproduction=limit, incentivize_killing=True)
+    wts = [_weights("PERD3QN", 7), _weights("D3QN", 8)]
+    pair = []
+    for _ in range(2):
+        dw = DeviceWorlds(n_worlds=R, seed=99, **cfg)
+        dw.set_brains([(_lib.PERD3QN, 0.0, pack_brain_weights(_lib.PERD3QN, wts[0])), (_lib.D3QN, 0.2, pack_brain_weights(_lib.D3QN, wts[1]))])
+        dw.reset_synthetic(n_new)
+        pair.append(dw)
+    fused, loop = pair
+    if not fused.run_supported():
+        pytest.skip("slot_cap above this workgroup size")
+    ow = orc.OracleWorlds(n_worlds=R, seed=99, **cfg)
+    ow.reset_synthetic(n_new)
+    for t in range(45):
+        fused.run(1, thr, n_new)
+        loop.act(); loop.tick_refill(thr, n_new)
+        acts = fused.actions.cpu().numpy().copy()
+        ow.step(acts); ow.update(); ow.refill(thr, n_new)
+        fused.check_error_flag()
+        _same_device_state(fused, loop, "tick %d" % t)
+        _cmp_state(fused, ow, "tick %d vs oracle" % t)
+        _cmp_rows(fused.obs_state().cpu().numpy(), ow.obs2, ow.s["n_agents"], "tick %d obs2 vs oracle" % t)
+    fused.run(20, thr, n_new)
+    for _ in range(20):
+        loop.act(); loop.tick_refill(thr, n_new)
+    _same_device_state(fused, loop, "after the 20-tick launch")
+    assert int(fused.refill_count.item()) == int(loop.refill_count.item())
