@@ -286,6 +286,7 @@ struct EpiConsts {
 };
 
 
+
 // K loop of one layer: B fragments from LDS planes `bsrc` (unit stride `bstep` per chunk, plane stride `bplane`), A
 // fragments from the ring.  Leaves acc[t] = sum hi.hi + hi.lo + lo.hi, still in the scaled domain.
 template <int NS, int TOUT, int NT, int TSTRIDE, int D>
@@ -743,6 +744,11 @@ __device__ inline void layer_out_to_B(f32x16 (&acc)[4], gfloat* __restrict__ con
         }
 }
 
+#ifdef RL_PHASE_PROFILE
+#define RL_PMARK1(i) do { if (io.prof && lane == 0) io.prof[100 + (i)] = (long long)clock64(); } while (0)
+#else
+#define RL_PMARK1(i) do { } while (0)
+#endif
 template <int KIND, bool COHERENT, bool XLDS = false>
 __device__ inline void policy_tile1(const TileIO& io, int lane)
 {
@@ -751,6 +757,7 @@ __device__ inline void policy_tile1(const TileIO& io, int lane)
     const Layout L = layout_of(KIND);
     gfloat* __restrict__ packed = io.packed;
     WRing<4, 4, 1, 2> w;
+    RL_PMARK1(1);
     w.start(packed + L.l1, lane, 0);
     // ---- the lane's half of its observation row, chunk by chunk: x[row][16c + 8h + 0..7]
     f32x4 B1[kInChunks][kPlanes];
@@ -783,7 +790,9 @@ __device__ inline void policy_tile1(const TileIO& io, int lane)
             }
     }
     rl_u4 draw = {0u, 0u, 0u, 0u};
-    if (io.actions) draw = rl_philox4x32(io.seed, io.key_epoch, io.key_world, io.key_tick, RL_SITE_ACT, io.key_index);  // while the rows are in flight
+    // (a greedy brain never looks at its draw: u < 0 is false whatever u is -- and in this one-wave tile the ~100 instructions of the
+    // Philox block sit on the tile's only dependency chain)
+    if (io.actions && io.eps > 0.0f) draw = rl_philox4x32(io.seed, io.key_epoch, io.key_world, io.key_tick, RL_SITE_ACT, io.key_index);
     if (h == 1) { B1[kInChunks - 1][0] = f32x4{B1[kInChunks - 1][0].w, 0.0f, 0.0f, 0.0f}; B1[kInChunks - 1][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
     float m = 0.0f;
 #pragma unroll
@@ -801,21 +810,29 @@ __device__ inline void policy_tile1(const TileIO& io, int lane)
     }
     // ---- input layer
     f32x16 acc[4];
+    RL_PMARK1(2);
     k_loop_reg4<kInChunks>(w, B1, acc);
+    RL_PMARK1(3);
     w.start(packed + L.l2a, lane, 0);
     f32x4 B2[8][kPlanes], B3[8][kPlanes];
     float un1, un2;
     layer_out_to_B(acc, packed + L.l1 + frag_floats(kInChunks, 4), h, un0, B2, un1);   // relu(feature) feeds both branches (PERD3QN.py:200-201)
     // ---- advantage branch
+    RL_PMARK1(4);
     k_loop_reg4<8>(w, B2, acc);
+    RL_PMARK1(5);
     layer_out_to_B(acc, packed + L.l2a + frag_floats(8, 4), h, un1, B3, un2);
     float adv[4], val[4];
+    RL_PMARK1(6);
     head_reg<4>(packed + L.ha, B3, un2, lane, adv);
+    RL_PMARK1(7);
     // ---- value branch
     w.start(packed + L.l2b, lane, 0);
     k_loop_reg4<8>(w, B2, acc);
+    RL_PMARK1(8);
     layer_out_to_B(acc, packed + L.l2b + frag_floats(8, 4), h, un1, B3, un2);
     head_reg<4>(packed + L.hb, B3, un2, lane, val);
+    RL_PMARK1(9);
     // ---- dueling combine (per-row mean: PERD3QN.py:202 at batch 1), outputs, action
     const f32x4 ba = ((gf32x4*)(packed + L.ha + head_consts_off(4) + 8))[h];
     const float bv = packed[L.hb + head_consts_off(4) + 8];

@@ -2087,38 +2087,46 @@ __device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& p
     }
 }
 
+// Rows of a world grouped by brain, 32-row tiles per brain, by ONE wave (ballots; lane b keeps brain b's count): prow / bstart / bcnt /
+// tstart / meta[0].  `brain_of(k)`: brains-list index of list entry k.
+template <typename F>
+__device__ inline void policy_lists_wave0(const KParams& p, PolSmem& ps, int n, int lane, F brain_of)
+{
+    int cnt = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int k = base + lane;
+        const int b = k < n ? brain_of(k) : -1;
+        for (int bb = 0; bb < p.n_brains; ++bb) { const int c = __popcll(__ballot(b == bb)); if (lane == bb) cnt += c; }
+    }
+    const int mine = lane < p.n_brains ? cnt : 0;
+    const int incl = wave_incl_scan(mine);
+    const int tiles = (mine + 31) >> 5;
+    const int tincl = wave_incl_scan(tiles);
+    if (lane < p.n_brains) { ps.bstart[lane] = incl - mine; ps.bcnt[lane] = mine; ps.tstart[lane] = tincl - tiles; }
+    if (lane == 63) ps.meta[0] = tincl;
+    int pos = incl - mine;
+    for (int base = 0; base < n; base += 64) {
+        const int k = base + lane;
+        const int b = k < n ? brain_of(k) : -1;
+        for (int bb = 0; bb < p.n_brains; ++bb) {
+            const unsigned long long m = __ballot(b == bb);
+            const int start = read_lane(pos, bb);
+            if (b == bb) ps.prow[start + __popcll(m & lowmask(lane))] = (short)k;
+            if (lane == bb) pos += __popcll(m);
+        }
+    }
+}
+
 // The same with ONE wave per tile (policy_tile1: no LDS, no barrier inside a tile): wave i takes tiles i, i + T / 64, ...
 // Needs the 256-VGPR budget of a workgroup of at most 512 threads.
 template <int T, int KIND>
 __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base)
 {
     const int tid = rl_tidx(), lane = tid & 63, wave = tid >> 6, j = lane & 31;
-    if (wave == 0) {
-        int cnt = 0;
-        for (int base = 0; base < n; base += 64) {
-            const int k = base + lane;
-            const int b = k < n ? s.brain[k] : -1;
-            for (int bb = 0; bb < p.n_brains; ++bb) { const int c = __popcll(__ballot(b == bb)); if (lane == bb) cnt += c; }
-        }
-        const int mine = lane < p.n_brains ? cnt : 0;
-        const int incl = wave_incl_scan(mine);
-        const int tiles = (mine + 31) >> 5;
-        const int tincl = wave_incl_scan(tiles);
-        if (lane < p.n_brains) { ps.bstart[lane] = incl - mine; ps.bcnt[lane] = mine; ps.tstart[lane] = tincl - tiles; }
-        if (lane == 63) ps.meta[0] = tincl;
-        int pos = incl - mine;
-        for (int base = 0; base < n; base += 64) {
-            const int k = base + lane;
-            const int b = k < n ? s.brain[k] : -1;
-            for (int bb = 0; bb < p.n_brains; ++bb) {
-                const unsigned long long m = __ballot(b == bb);
-                const int start = read_lane(pos, bb);
-                if (b == bb) ps.prow[start + __popcll(m & lowmask(lane))] = (short)k;
-                if (lane == bb) pos += __popcll(m);
-            }
-        }
-    }
-    lds_barrier();
+#ifdef RL_PHASE_PROFILE
+    const long long t_entry = (long long)clock64();
+#endif
+    // (the per-brain row lists were built by wave 0 while the other waves wrote the previous tick's Agent.state rows: policy_lists_wave0)
     int ntiles = __builtin_amdgcn_readfirstlane(ps.meta[0]);
     {   // tuning only (RL_RUN_DEBUG & 4 / & 8): run at most 2 / 1 tiles (results WRONG)
         const int dbg = *(const int __attribute__((address_space(4)))*)&ka->ra.debug;
@@ -2147,13 +2155,20 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
         io.key_index = (uint32_t)k;
         io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
         io.x_lds_off = (mirrored && k < ps.xrows) ? (int)((char*)(ps.xmirror + k * kXStride) - smem_base) : -1;
-          // (the epilogue constants from an LDS copy instead of L2: measured, no gain -- 31.0 vs 30.1 us per tick)
+        // (the brains' epilogue constants from a copy in LDS instead of L2: measured twice, within noise -- ~300 cycles per layer boundary)
 #ifdef RL_PHASE_PROFILE
-        io.prof = nullptr;
+        io.prof = (p.prof && (int)blockIdx.x == p.prof_world && wave == 0) ? p.prof : nullptr;
+        if (io.prof && lane == 0) { io.prof[100] = t_entry; io.prof[110] = (long long)clock64(); }
 #endif
         policy_tile1<KIND, RL_RUN_COHERENT, true>(io, lane);
     }
+#ifdef RL_PHASE_PROFILE
+    if (p.prof && (int)blockIdx.x == p.prof_world && tid == 0) p.prof[111] = (long long)clock64();
+#endif
     lds_barrier();
+#ifdef RL_PHASE_PROFILE
+    if (p.prof && (int)blockIdx.x == p.prof_world && tid == 0) p.prof[112] = (long long)clock64();
+#endif
 }
 
 // First half of a tick: the policy.  Reads the list length and the Agent.state parity from LDS.
@@ -2262,7 +2277,11 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     lds_barrier();
     if (p.uo.src)
         for (int k = tid; k < n2; k += T) p.uo.src[b + k] = refill ? (short)-1 : s.src[s.order[k]];
-    write_observations<T>(p, s, w, n2, obs_out, ps.xmirror, ps.xrows);
+    if (T <= 512) {   // wave 0 prepares the next tick's policy (rows grouped by brain) while the others write the Agent.state rows
+        if (tid < 64) policy_lists_wave0(p, ps, n2, tid, [&](int k) { return s.brain[s.order[k]]; });
+        else write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n2, obs_out, tid - 64, ps.xmirror, ps.xrows);
+    } else
+        write_observations<T>(p, s, w, n2, obs_out, ps.xmirror, ps.xrows);
     if (tid == 0) { ps.meta[1] = n2; ps.meta[2] = cur ^ 1; ps.meta[3] = ticks_done + 1; ps.meta[4] = ps.xmirror != nullptr; }
     // (rows the policy will read back from memory must have reached L2 first; with every row mirrored in LDS the stores just drain)
     recycle_world<T, kSpec>(p, s, n2, tick_next, epoch_next, next_uid, max_gene, ps.xmirror == nullptr || n2 > ps.xrows);
@@ -2285,6 +2304,7 @@ __device__ __forceinline__ void run_load_call(RunParamsC* ka)   // (inlined: loa
     int n0;
     load_world<T, (T == 1024)>(p, s, (int)blockIdx.x, n0);
     if (rl_tidx() == 0) { ps.meta[1] = n0; ps.meta[2] = *(cint*)&ka->ra.first; ps.meta[3] = 0; ps.meta[4] = 0; }
+    if (T <= 512 && rl_tidx() < 64) policy_lists_wave0(p, ps, n0, rl_tidx(), [&](int k) { return s.brain[k]; });   // (slot == list index after load_world)
     lds_barrier();
 }
 template <int T, bool FIXED, int KIND>
