@@ -435,6 +435,8 @@ struct TileIO {
     int lds_actions_off;   // optional (multi-tick kernel): byte offset of the world's action array in the DYNAMIC LDS region
     int lds_slot;          // (-1 = none), and the slot of tile row (lane & 31) in it
     int x_lds_off;         // one-wave tile in the multi-tick kernel: byte offset of this lane's row in the LDS mirror, or -1 (read obs)
+    int dbg;               // tuning only (RL_RUN_DEBUG bits 32 / 64 / 128): leave policy_tile1s after the row / input layer / hidden layer
+    int c_lds_off;         // policy_tile1s: byte offset of the brain's epilogue constants in LDS ([l1 | l2a | l2b][256] floats)
 #ifdef RL_PHASE_PROFILE
     long long* prof;       // tuning build: shader-clock stamps (slots 48..), non-null in the profiled workgroup only
 #endif
@@ -749,6 +751,51 @@ __device__ inline void layer_out_to_B(f32x16 (&acc)[4], gfloat* __restrict__ con
 #else
 #define RL_PMARK1(i) do { } while (0)
 #endif
+// dueling combine (per-row mean: PERD3QN.py:202 at batch 1), outputs, action.  adv: the lane's four advantages (outputs 4h .. 4h+3
+// of row j, bias not added); val_plus_bias: the row's value (used by the lanes of half 0).
+template <int KIND>
+__device__ inline void tile1_finish(const TileIO& io, int lane, const float (&adv)[4], float val_plus_bias, const rl_u4& draw, const f32x4& ba)
+{
+    const int h = lane >> 5;
+    float a4[4] = {adv[0] + ba.x, adv[1] + ba.y, adv[2] + ba.z, adv[3] + ba.w};
+    float o4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o4[r] = __shfl_xor(a4[r], 32);   // the other half's four advantages
+    if (h == 0) {
+        const float advs[8] = {a4[0], a4[1], a4[2], a4[3], o4[0], o4[1], o4[2], o4[3]};
+        float mean = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mean += advs[i];
+        mean *= 0.125f;
+        const float v = val_plus_bias;
+        float q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = advs[i] + v - mean;
+        if (io.valid) {
+            if (io.out) {
+                f32x4* o = (f32x4*)(io.out + io.row * 8);
+                o[0] = f32x4{q[0], q[1], q[2], q[3]};
+                o[1] = f32x4{q[4], q[5], q[6], q[7]};
+            }
+            if (io.actions) {
+                const float u = (float)rl_u24(draw.x);
+                int a = 0;
+                if (u < io.eps) a = (int)(draw.y >> 29);
+                else {
+                    float best = q[0];
+#pragma unroll
+                    for (int i = 1; i < 8; ++i) { const bool gt = q[i] > best; a = gt ? i : a; best = gt ? q[i] : best; }  // first maximum
+                }
+                io.actions[io.row] = (int8_t)a;
+                if (io.lds_actions_off >= 0) {
+                    extern __shared__ __attribute__((aligned(16))) char rl_dyn_lds[];
+                    ((signed char*)rl_dyn_lds)[io.lds_actions_off + io.lds_slot] = (signed char)a;
+                }
+            }
+        }
+    }
+}
+
 template <int KIND, bool COHERENT, bool XLDS = false>
 __device__ inline void policy_tile1(const TileIO& io, int lane)
 {
@@ -833,46 +880,327 @@ __device__ inline void policy_tile1(const TileIO& io, int lane)
     layer_out_to_B(acc, packed + L.l2b + frag_floats(8, 4), h, un1, B3, un2);
     head_reg<4>(packed + L.hb, B3, un2, lane, val);
     RL_PMARK1(9);
-    // ---- dueling combine (per-row mean: PERD3QN.py:202 at batch 1), outputs, action
     const f32x4 ba = ((gf32x4*)(packed + L.ha + head_consts_off(4) + 8))[h];
-    const float bv = packed[L.hb + head_consts_off(4) + 8];
-    float a4[4] = {adv[0] + ba.x, adv[1] + ba.y, adv[2] + ba.z, adv[3] + ba.w};
-    float o4[4];
+    tile1_finish<KIND>(io, lane, adv, val[0] + packed[L.hb + head_consts_off(4) + 8], draw, ba);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The one-wave tile, SCHEDULED BY HAND (the multi-tick kernel's policy half is ONE tile's dependency chain).
+//
+// Measured on gfx950 (tools/ubench/valu_rate.hip, mfma_valu_overlap.hip): a wave that is alone on its SIMD issues one VALU
+// instruction per ~8 cycles (11.5 for v_fma_mix*), but up to four of them ride for free in the 34-cycle shadow of each of its
+// OWN v_mfma_f32_32x32x16_f16.  policy_tile1 runs its 360 MFMAs and its ~2,100 VALU instructions (epilogues, row maxima, f16
+// splits) in separate phases, so it pays their SUM (~12k + ~17k cycles).  Here every layer is taken as TWO passes over K (output
+// tiles 0,1 then 2,3: two accumulators per pass, an accumulator is reused every other MFMA), and each MFMA is followed by a
+// fixed slice of independent VALU work (a "slot"; a sched_barrier after every slot pins the order):
+//     input layer, pass 1   the f16 split of the NEXT K-chunk of the observation row
+//     pass 2 of any layer   the epilogue (unscale, bias, ReLU, row maximum) of pass 1's two tiles
+//     hidden layer, pass 1  the split of the previous layer's activations, chunk by chunk, just ahead of their use
+//     heads                 likewise the split of their input
+// What stays exposed per layer is the epilogue of tiles 2,3, the row maximum / scale, and the first chunk's split.
+// The arithmetic per accumulator (order of the partial products and chunks, epilogue, split) is that of policy_tile1, so the
+// results are identical bit for bit.  The epilogue constants come from a copy in LDS (`c_lds_off`: [3 layers][256] floats of
+// the brain, filled once per launch): their loads sit two slots ahead of their use, which an L2 round trip does not allow.
+// ---------------------------------------------------------------------------------------------------------------
+// LDS block of one brain for policy_tile1s: [l1 | l2a | l2b][256] epilogue constants, then the heads' [unscale 8 | bias 8] (advantage, value)
+constexpr int kTileConstFloats = 3 * 256 + 2 * 16;
+
+// Weight ring over the 2 * NS steps of a layer taken as two passes: step i = K-chunk i % NS of output tiles 2 * (i / NS), +1.
+template <int NS, int D>
+struct WRingH {
+    f32x4 a[D][2][kPlanes];
+    gf32x4* p;   // tile-pair fragment block of the step the next refill asks for
+#ifdef RL_ABL_WH
+    static __host__ __device__ constexpr int off(int i) { return 0; }
+#else
+    static __host__ __device__ constexpr int off(int i) { return ((i % NS) * 4 + 2 * (i / NS)) * kPlanes * 64; }   // in 16-byte units
+#endif
+    __device__ inline void start(gfloat* __restrict__ pw, int lane)
+    {
+        static_assert(D < NS, "ring deeper than a pass");
+        p = (gf32x4*)pw + lane;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o4[r] = __shfl_xor(a4[r], 32);   // the other half's four advantages
-    if (h == 0) {
-        const float advs[8] = {a4[0], a4[1], a4[2], a4[3], o4[0], o4[1], o4[2], o4[3]};
-        float mean = 0.0f;
+        for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) mean += advs[i];
-        mean *= 0.125f;
-        const float v = val[0] + bv;
-        float q[8];
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) q[i] = advs[i] + v - mean;
-        if (io.valid) {
-            if (io.out) {
-                f32x4* o = (f32x4*)(io.out + io.row * 8);
-                o[0] = f32x4{q[0], q[1], q[2], q[3]};
-                o[1] = f32x4{q[4], q[5], q[6], q[7]};
-            }
-            if (io.actions) {
-                const float u = (float)rl_u24(draw.x);
-                int a = 0;
-                if (u < io.eps) a = (int)(draw.y >> 29);
-                else {
-                    float best = q[0];
+                for (int pl = 0; pl < kPlanes; ++pl) a[d][t][pl] = p[off(d) + (t * kPlanes + pl) * 64];
+        p += off(D);
+        asm volatile("" : "+v"(p));
+    }
+    __device__ inline void take(int i, f32x4 (&ac)[2][kPlanes])
+    {
+        const int cur = i % D;
 #pragma unroll
-                    for (int i = 1; i < 8; ++i) { const bool gt = q[i] > best; a = gt ? i : a; best = gt ? q[i] : best; }  // first maximum
-                }
-                io.actions[io.row] = (int8_t)a;
-                if (io.lds_actions_off >= 0) {
-                    extern __shared__ __attribute__((aligned(16))) char rl_dyn_lds[];
-                    ((signed char*)rl_dyn_lds)[io.lds_actions_off + io.lds_slot] = (signed char)a;
-                }
-            }
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pl = 0; pl < kPlanes; ++pl) ac[t][pl] = a[cur][t][pl];
+        if (i + D < 2 * NS) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pl = 0; pl < kPlanes; ++pl) a[cur][t][pl] = p[(t * kPlanes + pl) * 64];
+            if (i + D + 1 < 2 * NS) { p += off(i + D + 1) - off(i + D); asm volatile("" : "+v"(p)); }
         }
     }
+};
+
+__device__ inline void split_hi(float x0, float x1, float sc, float& hi)
+{
+    unsigned h = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(sc));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(sc));
+#endif
+    hi = __builtin_bit_cast(float, h);
+}
+__device__ inline void split_lo(float x0, float x1, float sc, float hi, float& lo)
+{
+    unsigned l = 0;
+    const unsigned h = __builtin_bit_cast(unsigned, hi);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(sc), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(sc), "v"(h));
+#endif
+    lo = __builtin_bit_cast(float, l);
+}
+// Slice k of NSLOT of the split of one 8-element B chunk (the same instructions as split8, in the same order): the eight
+// half-pairs hi0 lo0 hi1 lo1 hi2 lo2 hi3 lo3 are dealt to the slots in order.  raw(e) = element e of the chunk.
+template <int NSLOT, typename Raw>
+__device__ inline void split_slice(int k, Raw&& raw, float sc, f32x4& hi, f32x4& lo)
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < (k * 8) / NSLOT || j >= ((k + 1) * 8) / NSLOT) continue;
+        const int q = j >> 1;
+        if ((j & 1) == 0) { float v; split_hi(raw(2 * q), raw(2 * q + 1), sc, v); hi[q] = v; }
+        else { float v; split_lo(raw(2 * q), raw(2 * q + 1), sc, hi[q], v); lo[q] = v; }
+    }
+}
+
+// One pass of a layer: K loop over NS chunks for output tiles 2 * HALF, +1.  shadow(slot), slot = 0 .. 6 * NS - 1, follows MFMA `slot`.
+template <int NS, int D, int HALF, typename Shadow>
+__device__ inline void k_pass(WRingH<NS, D>& w, const f32x4 (&B)[NS][kPlanes], f32x16& a0, f32x16& a1, Shadow&& shadow)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        f32x4 ac[2][kPlanes];
+        w.take(HALF * NS + s, ac);
+        a0 = mfma16(ac[0][0], B[s][1], a0); shadow(6 * s + 0); __builtin_amdgcn_sched_barrier(0);   // hi.lo
+        a1 = mfma16(ac[1][0], B[s][1], a1); shadow(6 * s + 1); __builtin_amdgcn_sched_barrier(0);
+        a0 = mfma16(ac[0][0], B[s][0], a0); shadow(6 * s + 2); __builtin_amdgcn_sched_barrier(0);   // hi.hi
+        a1 = mfma16(ac[1][0], B[s][0], a1); shadow(6 * s + 3); __builtin_amdgcn_sched_barrier(0);
+        a0 = mfma16(ac[0][1], B[s][0], a0); shadow(6 * s + 4); __builtin_amdgcn_sched_barrier(0);   // lo.hi
+        a1 = mfma16(ac[1][1], B[s][0], a1); shadow(6 * s + 5); __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Epilogue of two finished output tiles, one accumulator register per step (32 steps): y = relu(acc * (unscale * row_un) + bias),
+// m = max(m, y).  The constants of quarter Q (4 registers) are read from LDS while quarter Q - 1 is worked on.
+struct EpiStream {
+    const float* c;   // LDS: the layer's 256 constants + 32 * half  ([tile][half][unscale 16 | bias 16])
+    f32x4 un[2], bi[2];
+    __device__ inline void fetch(int t, int Q)   // quarter Q = 0 .. 7 of the tile pair (t = first tile of the pair)
+    {
+        const float* q = c + (t + (Q >> 2)) * 64 + 4 * (Q & 3);
+        un[Q & 1] = *(const f32x4*)q;
+        bi[Q & 1] = *(const f32x4*)(q + 16);
+    }
+    __device__ inline void step(int t, int e, f32x16& a0, f32x16& a1, float row_un, float& m)   // e = 0 .. 31
+    {
+        const int Q = e >> 2, r = e & 15, ee = e & 3;
+        if (ee == 0 && Q + 1 < 8) fetch(t, Q + 1);
+        f32x16& a = e < 16 ? a0 : a1;
+        const float y = fmaxf(__builtin_fmaf(a[r], un[Q & 1][ee] * row_un, bi[Q & 1][ee]), 0.0f);
+        a[r] = y;
+        m = fmaxf(m, y);
+    }
+};
+
+// head (8 / 1 outputs padded to one A tile) over K = 128, its input split chunk by chunk ahead of the MFMAs that use it.
+// raw(c, e): element e of B chunk c (= register 8 * (c & 1) + e of activation tile c >> 1).
+template <int D, typename Raw>
+__device__ inline void head_stream(WRing<1, 1, 1, D>& w, const f32x4& un4, Raw&& raw, float sc, float row_un, float (&out)[4])
+{
+    f32x16 a0, a1, a2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; a2[r] = 0.0f; }
+    f32x4 B[8][kPlanes];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) split_slice<3>(k, [&](int e) { return raw(0, e); }, sc, B[0][0], B[0][1]);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        f32x4 ac[1][kPlanes];
+        w.template next<8>(s, ac);
+        a0 = mfma16(ac[0][0], B[s][1], a0);
+        if (s + 1 < 8) split_slice<3>(0, [&](int e) { return raw(s + 1, e); }, sc, B[(s + 1) & 7][0], B[(s + 1) & 7][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        a1 = mfma16(ac[0][0], B[s][0], a1);
+        if (s + 1 < 8) split_slice<3>(1, [&](int e) { return raw(s + 1, e); }, sc, B[(s + 1) & 7][0], B[(s + 1) & 7][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        a2 = mfma16(ac[0][1], B[s][0], a2);
+        if (s + 1 < 8) split_slice<3>(2, [&](int e) { return raw(s + 1, e); }, sc, B[(s + 1) & 7][0], B[(s + 1) & 7][1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = ((a0[r] + a1[r]) + a2[r]) * (un4[r] * row_un);
+}
+
+// PAIR: two waves per tile on ONE SIMD (waves i and i + 4 of a workgroup share one: tools/ubench/simd_map.hip), role 0 = input layer +
+// advantage branch (+ the finish, after the caller's barrier), role 1 = input layer + value branch: each wave streams 2/3 of the
+// weights, and the two hide each other's waits.  The value reaches role 0 through `pair_lds` (32 floats per tile).
+struct Tile1Part {
+    float head[4];
+    rl_u4 draw;
+};
+template <int KIND, bool COHERENT, bool PAIR = false>
+__device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, float* pair_lds = nullptr, Tile1Part* part = nullptr)
+{
+    static_assert(KIND == RL_D3QN || KIND == RL_PERD3QN, "one-wave tile: dueling kinds");
+    extern __shared__ __attribute__((aligned(16))) char rl_dyn_lds[];
+    constexpr int D = 3;
+    const int h = lane >> 5;
+    const Layout L = layout_of(KIND);
+    gfloat* __restrict__ packed = io.packed;
+    const float* const consts = (const float*)(rl_dyn_lds + io.c_lds_off) + 32 * h;   // + 256 per layer: l1, l2a, l2b
+    const float* const hconsts = (const float*)(rl_dyn_lds + io.c_lds_off) + 768;     // heads: [un 8 | bias 8] advantage, value
+    RL_PMARK1(1);
+    WRingH<kInChunks, D> w1;
+    w1.start(packed + L.l1, lane);
+    // ---- the lane's half of its observation row, chunk by chunk: x[row][16c + 8h + 0..7] (see policy_tile1)
+    f32x4 X[kInChunks][2];
+    {
+        const int64_t rbase = io.row * RL_OBS_DIM;
+        if (io.x_lds_off >= 0) {
+            const float* xr = (const float*)(rl_dyn_lds + io.x_lds_off);
+#pragma unroll
+            for (int c = 0; c < kInChunks; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (c == kInChunks - 1 && h == 1) X[c][q] = f32x4{xr[149], xr[150], xr[151], xr[152]};
+                    else X[c][q] = *(const f32x4*)(xr + 16 * c + 8 * h + 4 * q);
+                }
+        } else
+#pragma unroll
+        for (int c = 0; c < kInChunks; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k0 = (c == kInChunks - 1 && h == 1) ? 149 : 16 * c + 8 * h + 4 * q;
+                if (COHERENT) {
+                    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)io.obs, 0, 0x7fffffff, 0x00027000);
+                    X[c][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((rbase + k0) * 4), 0, 16 /* sc1 */));
+                } else
+                    X[c][q] = *(const f32x4u*)(io.obs + rbase + k0);
+            }
+    }
+    rl_u4 draw = {0u, 0u, 0u, 0u};
+    if ((!PAIR || role == 0) && io.actions && io.eps > 0.0f) draw = rl_philox4x32(io.seed, io.key_epoch, io.key_world, io.key_tick, RL_SITE_ACT, io.key_index);
+    if (h == 1) { X[kInChunks - 1][0] = f32x4{X[kInChunks - 1][0].w, 0.0f, 0.0f, 0.0f}; X[kInChunks - 1][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    float m = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kInChunks; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(X[c][q].x), fabsf(X[c][q].y)), fmaxf(fabsf(X[c][q].z), fabsf(X[c][q].w))));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sc0, un0;
+    row_scale(m, sc0, un0);
+    f32x4 B1[kInChunks][kPlanes];
+    auto xraw = [&](int c, int e) { return X[c][e >> 2][e & 3]; };
+#pragma unroll
+    for (int k = 0; k < 6; ++k) split_slice<6>(k, [&](int e) { return xraw(0, e); }, sc0, B1[0][0], B1[0][1]);
+    RL_PMARK1(2);
+    if (io.dbg & 32) return;
+    // ---- input layer
+    f32x16 F[4];
+    EpiStream ep;
+    k_pass<kInChunks, D, 0>(w1, B1, F[0], F[1], [&](int slot) {
+        const int c = slot / 6 + 1;
+        if (c < kInChunks) split_slice<6>(slot % 6, [&](int e) { return xraw(c, e); }, sc0, B1[c][0], B1[c][1]);
+    });
+    float mrow = 0.0f;
+    ep.c = consts;
+    k_pass<kInChunks, D, 1>(w1, B1, F[2], F[3], [&](int slot) {
+        if (slot == 0) ep.fetch(0, 0);
+        if (slot >= 2 && slot < 34) ep.step(0, slot - 2, F[0], F[1], un0, mrow);
+    });
+    RL_PMARK1(3);
+    const int64_t l2 = (PAIR && role) ? L.l2b : L.l2a, hd = (PAIR && role) ? L.hb : L.ha;
+    WRingH<8, D> w2;
+    w2.start(packed + l2, lane);
+    ep.fetch(2, 0);
+#pragma unroll
+    for (int e = 0; e < 32; ++e) ep.step(2, e, F[2], F[3], un0, mrow);
+    mrow = fmaxf(mrow, __shfl_xor(mrow, 32));
+    float sc1, un1;
+    row_scale(mrow, sc1, un1);
+    // relu(feature) feeds both branches (PERD3QN.py:200-201): B2 chunk 2t + c = registers 8c .. 8c+7 of tile t
+    f32x4 B2[8][kPlanes];
+    auto fraw = [&](int c, int e) { return F[c >> 1][8 * (c & 1) + e]; };
+#pragma unroll
+    for (int k = 0; k < 6; ++k) split_slice<6>(k, [&](int e) { return fraw(0, e); }, sc1, B2[0][0], B2[0][1]);
+    RL_PMARK1(4);
+    if (io.dbg & 64) return;
+    // ---- advantage branch
+    f32x16 A[4];
+    k_pass<8, D, 0>(w2, B2, A[0], A[1], [&](int slot) {
+        const int c = slot / 6 + 1;
+        if (c < 8) split_slice<6>(slot % 6, [&](int e) { return fraw(c, e); }, sc1, B2[c][0], B2[c][1]);
+    });
+    mrow = 0.0f;
+    ep.c = consts + ((PAIR && role) ? 512 : 256);
+    k_pass<8, D, 1>(w2, B2, A[2], A[3], [&](int slot) {
+        if (slot == 0) ep.fetch(0, 0);
+        if (slot >= 2 && slot < 34) ep.step(0, slot - 2, A[0], A[1], un1, mrow);
+    });
+    RL_PMARK1(5);
+    WRing<1, 1, 1, D> wh;
+    wh.start(packed + hd, lane, 0);
+    ep.fetch(2, 0);
+#pragma unroll
+    for (int e = 0; e < 32; ++e) ep.step(2, e, A[2], A[3], un1, mrow);
+    mrow = fmaxf(mrow, __shfl_xor(mrow, 32));
+    float sc2, un2;
+    row_scale(mrow, sc2, un2);
+    auto araw = [&](int c, int e) { return A[c >> 1][8 * (c & 1) + e]; };
+    float adv[4], val[4];
+    RL_PMARK1(6);
+    if (io.dbg & 128) return;
+    if (PAIR) {
+        head_stream<D>(wh, *(const f32x4*)(hconsts + ((PAIR && role) ? 16 : 0) + 4 * h), araw, sc2, un2, adv);
+        if (role) { if (h == 0) pair_lds[lane] = adv[0] + hconsts[16 + 8]; }
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part->head[r] = adv[r];
+            part->draw = draw;
+        }
+        RL_PMARK1(9);
+        return;
+    }
+    WRingH<8, D> w3;
+    w3.start(packed + L.l2b, lane);
+    head_stream<D>(wh, *(const f32x4*)(hconsts + 4 * h), araw, sc2, un2, adv);
+    RL_PMARK1(7);
+    // ---- value branch
+    k_pass<8, D, 0>(w3, B2, A[0], A[1], [&](int) {});
+    mrow = 0.0f;
+    ep.c = consts + 512;
+    k_pass<8, D, 1>(w3, B2, A[2], A[3], [&](int slot) {
+        if (slot == 0) ep.fetch(0, 0);
+        if (slot >= 2 && slot < 34) ep.step(0, slot - 2, A[0], A[1], un1, mrow);
+    });
+    RL_PMARK1(8);
+    wh.start(packed + L.hb, lane, 0);
+    ep.fetch(2, 0);
+#pragma unroll
+    for (int e = 0; e < 32; ++e) ep.step(2, e, A[2], A[3], un1, mrow);
+    mrow = fmaxf(mrow, __shfl_xor(mrow, 32));
+    row_scale(mrow, sc2, un2);
+    head_stream<D>(wh, *(const f32x4*)(hconsts + 16 + 4 * h), araw, sc2, un2, val);
+    RL_PMARK1(9);
+    tile1_finish<KIND>(io, lane, adv, val[0] + hconsts[16 + 8], draw, *(const f32x4*)(hconsts + 8 + 4 * h));
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -1897,6 +1897,8 @@ struct PolSmem {
     int* tstart;        // [64] first tile of brain b
     int* meta;          // [8]  [0] number of tiles; loop state of k_run: [1] list length, [2] Agent.state parity, [3] ticks done,
                         //      [4] the LDS mirror holds the current Agent.state rows
+    float* pairv;       // [4][32] row values from the value-branch wave of a tile pair to its partner (T = 512), or null
+    float* cconst;      // [n_brains][3][256] epilogue constants of the brains' three 128-wide layers for policy_tile1s (T = 512), or null
     float* xmirror;     // [xrows][kXStride] Agent.state rows of this world for the one-wave policy tile (T <= 512), or null
     int xrows;
 };
@@ -1908,14 +1910,15 @@ __host__ __device__ constexpr int policy_group_bytes()
 // groups > 0: `groups` blocks for the 4-wave tile (T = 1024).  groups == 0: the one-wave tile needs no LDS of its own; with
 // mirror_budget > 0 the Agent.state rows are mirrored in LDS instead (as many rows as fit below the budget, at most cap).
 template <int KIND>
-__host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o, int cap, int groups, size_t mirror_budget = 0)
+__host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o, int cap, int groups, size_t mirror_budget = 0, int n_cbrains = 0)
 {
     o = align16(o);
     ps.group0 = base + o; ps.group_bytes = policy_group_bytes<KIND>();
     o += (size_t)groups * policy_group_bytes<KIND>();
     ps.xmirror = nullptr; ps.xrows = 0;
-    if (groups == 0 && mirror_budget > o + 4096) {
-        const size_t rows = (mirror_budget - o - 4096) / (sizeof(float) * kXStride);
+    const size_t tail = 4096 + 512 + sizeof(float) * kTileConstFloats * (size_t)n_cbrains;   // what follows the mirror
+    if (groups == 0 && mirror_budget > o + tail) {
+        const size_t rows = (mirror_budget - o - tail) / (sizeof(float) * kXStride);
         ps.xrows = (int)(rows < (size_t)cap ? rows : (size_t)cap);
         if (ps.xrows >= 32) { ps.xmirror = (float*)(base + o); o = align16(o + sizeof(float) * kXStride * (size_t)ps.xrows); }
         else ps.xrows = 0;
@@ -1925,6 +1928,10 @@ __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o
     ps.bcnt = (int*)(base + o); o = align16(o + sizeof(int) * 64);
     ps.tstart = (int*)(base + o); o = align16(o + sizeof(int) * 64);
     ps.meta = (int*)(base + o); o = align16(o + sizeof(int) * 8);
+    ps.cconst = nullptr;
+    if (n_cbrains > 0) { ps.cconst = (float*)(base + o); o = align16(o + sizeof(float) * kTileConstFloats * (size_t)n_cbrains); }
+    ps.pairv = nullptr;
+    if (n_cbrains > 0) { ps.pairv = (float*)(base + o); o = align16(o + sizeof(float) * 4 * 32); }
     return o;
 }
 template <int KIND> __device__ inline f32x4* pol_h(const PolSmem& ps, int g) { return (f32x4*)(ps.group0 + g * ps.group_bytes); }
@@ -2009,11 +2016,12 @@ __device__ inline KParams run_params(RunParamsC* ka)
 constexpr size_t kRunLdsBudget = 160 * 1024;
 __host__ __device__ constexpr int run_groups(int T) { return T == 1024 ? 4 : 0; }
 __host__ __device__ constexpr size_t run_mirror_budget(int T) { return T == 512 ? kRunLdsBudget : 0; }
+__host__ __device__ constexpr int run_cbrains(int T, int n_brains) { return T == 512 ? n_brains : 0; }   // the hand-scheduled tile keeps its epilogue constants in LDS
 template <bool FIXED, int KIND>
 __device__ inline void run_carve(const KParams& p, Smem& s, PolSmem& ps, char* smem_raw, int T)
 {
     const size_t o0 = FIXED ? carve(s, smem_raw, kFixCp, kFixCap, kFixHash) : carve(s, smem_raw, p.Cp, p.cap, p.hash_size);
-    carve_policy<KIND>(ps, smem_raw, o0, p.cap, run_groups(T), run_mirror_budget(T));
+    carve_policy<KIND>(ps, smem_raw, o0, p.cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, p.n_brains));
 }
 
 template <int T, int KIND>
@@ -2078,7 +2086,7 @@ __device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& p
         io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
         io.key_index = (uint32_t)k;
         io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
-        io.x_lds_off = -1;
+        io.x_lds_off = -1; io.c_lds_off = -1; io.dbg = 0;
 #ifdef RL_PHASE_PROFILE
         io.prof = (p.prof && (int)blockIdx.x == p.prof_world) ? p.prof : nullptr;
         if (io.prof && rl_tidx() == 0) io.prof[101] = (long long)clock64();
@@ -2135,14 +2143,13 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
         if (dbg & 16) ntiles = min(ntiles, 3);
     }
     const bool mirrored = ps.xmirror != nullptr && __builtin_amdgcn_readfirstlane(ps.meta[4]) != 0;
-    for (int ti = wave; ti < ntiles; ti += T / 64) {
+    auto tile_io = [&](int ti, TileIO& io) {
         int b = 0;
         for (int bb = 1; bb < p.n_brains; ++bb) if (ps.tstart[bb] <= ti && ps.bcnt[bb] > 0) b = bb;
         b = __builtin_amdgcn_readfirstlane(b);
         const int cntb = ps.bcnt[b];
         const int li = (ti - ps.tstart[b]) * 32 + j;
         const int k = ps.prow[ps.bstart[b] + min(li, cntb - 1)];
-        TileIO io;
         io.packed = (gfloat*)((const float* const __attribute__((address_space(4)))*)ka->ra.packed)[b];
         io.obs = obs_rows;
         io.row = (int64_t)w * p.cap + k;
@@ -2155,12 +2162,32 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
         io.key_index = (uint32_t)k;
         io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
         io.x_lds_off = (mirrored && k < ps.xrows) ? (int)((char*)(ps.xmirror + k * kXStride) - smem_base) : -1;
+        io.c_lds_off = ps.cconst ? (int)((char*)(ps.cconst + kTileConstFloats * b) - smem_base) : -1;
+        io.dbg = *(const int __attribute__((address_space(4)))*)&ka->ra.debug;
         // (the brains' epilogue constants from a copy in LDS instead of L2: measured twice, within noise -- ~300 cycles per layer boundary)
 #ifdef RL_PHASE_PROFILE
         io.prof = (p.prof && (int)blockIdx.x == p.prof_world && wave == 0) ? p.prof : nullptr;
         if (io.prof && lane == 0) { io.prof[100] = t_entry; io.prof[110] = (long long)clock64(); }
 #endif
-        policy_tile1<KIND, RL_RUN_COHERENT, true>(io, lane);
+    };
+    if (T == 512 && ps.pairv != nullptr && ntiles <= 4) {
+        // TWO waves per tile, on the same SIMD (waves i and i + 4): advantage branch / value branch (policy_tile1s<PAIR>)
+        const int role = __builtin_amdgcn_readfirstlane(wave >> 2), slot = wave & 3;
+        const bool have = slot < ntiles;
+        TileIO io;
+        Tile1Part part;
+        if (have) {
+            tile_io(slot, io);
+            policy_tile1s<KIND, RL_RUN_COHERENT, true>(io, lane, role, ps.pairv + 32 * slot, &part);
+        }
+        lds_barrier();
+        if (have && role == 0) tile1_finish<KIND>(io, lane, part.head, ps.pairv[32 * slot + j], part.draw, *(const f32x4*)((const float*)(smem_base + io.c_lds_off) + 768 + 8 + 4 * (lane >> 5)));
+    } else
+    for (int ti = wave; ti < ntiles; ti += T / 64) {
+        TileIO io;
+        tile_io(ti, io);
+        if (T == 512) policy_tile1s<KIND, RL_RUN_COHERENT>(io, lane);
+        else policy_tile1<KIND, RL_RUN_COHERENT, true>(io, lane);
     }
 #ifdef RL_PHASE_PROFILE
     if (p.prof && (int)blockIdx.x == p.prof_world && tid == 0) p.prof[111] = (long long)clock64();
@@ -2305,6 +2332,16 @@ __device__ __forceinline__ void run_load_call(RunParamsC* ka)   // (inlined: loa
     load_world<T, (T == 1024)>(p, s, (int)blockIdx.x, n0);
     if (rl_tidx() == 0) { ps.meta[1] = n0; ps.meta[2] = *(cint*)&ka->ra.first; ps.meta[3] = 0; ps.meta[4] = 0; }
     if (T <= 512 && rl_tidx() < 64) policy_lists_wave0(p, ps, n0, rl_tidx(), [&](int k) { return s.brain[k]; });   // (slot == list index after load_world)
+    if (ps.cconst) {   // the brains' epilogue constants (three 128-wide layers x 256 floats) for policy_tile1s
+        const Layout L = layout_of(KIND);
+        for (int i = rl_tidx(); i < kTileConstFloats * p.n_brains; i += T) {
+            const int b = i / kTileConstFloats, j = i - kTileConstFloats * b, layer = j >> 8;
+            gfloat* pk = (gfloat*)((const float* const __attribute__((address_space(4)))*)ka->ra.packed)[b];
+            const int64_t off = layer == 0 ? L.l1 + frag_floats(kInChunks, 4) : layer == 1 ? L.l2a + frag_floats(8, 4) : layer == 2 ? L.l2b + frag_floats(8, 4)
+                              : (j < 768 + 16 ? L.ha : L.hb) + head_consts_off(4) - (j < 768 + 16 ? 768 : 768 + 16);
+            ps.cconst[i] = pk[off + (layer < 3 ? (j & 255) : j)];
+        }
+    }
     lds_barrier();
 }
 template <int T, bool FIXED, int KIND>
@@ -2590,7 +2627,7 @@ template <int KIND>
 static size_t run_smem_bytes(const rl_world* h, int T)
 {
     PolSmem ps;
-    return carve_policy<KIND>(ps, nullptr, h->smem_bytes, h->cfg.slot_cap, run_groups(T), run_mirror_budget(T));
+    return carve_policy<KIND>(ps, nullptr, h->smem_bytes, h->cfg.slot_cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, h->cfg.n_brains));
 }
 // Workgroup size of the multi-tick kernel: 512 threads for few worlds (the one-wave policy tile needs the 256-VGPR budget; the
 // tick half alone would prefer 1024: 10.6 vs 13.1 us at 256 worlds), 256 when there are many worlds (several per CU).

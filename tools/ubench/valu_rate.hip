@@ -1,10 +1,10 @@
-// VALU issue cost of the instructions the f16 split is made of (gfx950), one wave per SIMD, independent chains.
+// VALU issue cost of the instructions the f16 split is made of (gfx950) with 1, 2 and 4 waves per SIMD, independent chains.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_rate tools/ubench/valu_rate.hip && /tmp/valu_rate
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #define REP8(X) X X X X X X X X
 template <int OP>
-__global__ __launch_bounds__(256) void k(float* out, long long* clk, int iters)
+__global__ __launch_bounds__(1024) void k(float* out, long long* clk, int iters)
 {
     float a0 = threadIdx.x * 0.001f, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
     const float sc = 1.0009765625f;
@@ -22,15 +22,20 @@ __global__ __launch_bounds__(256) void k(float* out, long long* clk, int iters)
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(u0 + u1 + u2 + u3 + u4 + u5 + u6 + u7);
     if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
 }
+// waves per SIMD = threads / 256 (one workgroup per CU: 100 KB of LDS each; waves i, i + 4, ... share a SIMD: simd_map.hip)
 template <int OP>
 void run(const char* tag)
 {
     float* out; long long* clk; const int iters = 20000;
-    (void)hipMalloc(&out, sizeof(float) * 256 * 256); (void)hipMalloc(&clk, 8);
-    k<OP><<<256, 256>>>(out, clk, iters); (void)hipDeviceSynchronize();
-    k<OP><<<256, 256>>>(out, clk, iters); (void)hipDeviceSynchronize();
-    long long c; (void)hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
-    printf("%-22s %.2f cycles per instruction and wave (1 wave per SIMD)\n", tag, (double)c / (iters * 8.0));
+    (void)hipMalloc(&out, sizeof(float) * 256 * 1024); (void)hipMalloc(&clk, 8);
+    printf("%-22s", tag);
+    for (int threads = 256; threads <= 1024; threads *= 2) {
+        k<OP><<<256, threads, 100 * 1024>>>(out, clk, iters); (void)hipDeviceSynchronize();
+        k<OP><<<256, threads, 100 * 1024>>>(out, clk, iters); (void)hipDeviceSynchronize();
+        long long c; (void)hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
+        printf("  %d wave%s/SIMD: %.2f cycles per instruction of a wave, %.2f per SIMD", threads / 256, threads > 256 ? "s" : "", (double)c / (iters * 8.0), (double)c / (iters * 8.0) / (threads / 256));
+    }
+    printf("\n");
     (void)hipFree(out); (void)hipFree(clk);
 }
 int main()
