@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : (DEEP ? 3 : 4))) void k_
         io.row = (io.valid || B.rowlist) ? listed : (int64_t)tile * 32;  // dense mode: rows past the end do not exist
         io.eps = B.eps; io.out = A.out; io.actions = A.actions; io.seed = A.seed;
         io.key_world = io.key_tick = io.key_epoch = io.key_index = 0;
-        io.lds_actions_off = -1; io.lds_slot = 0; io.x_lds_off = -1; io.c_lds_off = -1; io.dbg = 0;
+        io.lds_actions_off = -1; io.lds_slot = 0; io.x_lds_off = -1; io.c_lds_off = -1;
         // the draw's Philox key needs the world's tick / epoch: fetch them now, not in the epilogue's dependent chain
         if (A.actions && v == 0 && lane < 32) {  // rl_policy_act always passes row lists
             io.key_world = (uint32_t)(A.world_base + e_w); io.key_index = (uint32_t)e_k;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64, 2) void k_policy1(const PolicyArgs A)
     io.row = (io.valid || B.rowlist) ? listed : (int64_t)tile * 32;
     io.eps = B.eps; io.out = A.out; io.actions = A.actions; io.seed = A.seed;
     io.key_world = io.key_tick = io.key_epoch = io.key_index = 0;
-    io.lds_actions_off = -1; io.lds_slot = 0; io.x_lds_off = -1; io.c_lds_off = -1; io.dbg = 0;
+    io.lds_actions_off = -1; io.lds_slot = 0; io.x_lds_off = -1; io.c_lds_off = -1;
     if (A.actions && lane < 32) {
         io.key_world = (uint32_t)(A.world_base + e_w); io.key_index = (uint32_t)e_k;
         io.key_tick = (uint32_t)A.tick[e_w]; io.key_epoch = (uint32_t)A.epoch[e_w];
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void k_policy_mixed(const PolicyArgs A)
         io.row = (io.valid || B.rowlist) ? listed : (int64_t)tile * 32;  // dense mode: rows past the end do not exist
         io.eps = B.eps; io.out = A.out; io.actions = A.actions; io.seed = A.seed;
         io.key_world = io.key_tick = io.key_epoch = io.key_index = 0;
-        io.lds_actions_off = -1; io.lds_slot = 0; io.x_lds_off = -1; io.c_lds_off = -1; io.dbg = 0;
+        io.lds_actions_off = -1; io.lds_slot = 0; io.x_lds_off = -1; io.c_lds_off = -1;
         // the draw's Philox key needs the world's tick / epoch: fetch them now, not in the epilogue's dependent chain
         if (A.actions && v == 0 && lane < 32) {  // rl_policy_act always passes row lists
             io.key_world = (uint32_t)(A.world_base + e_w); io.key_index = (uint32_t)e_k;

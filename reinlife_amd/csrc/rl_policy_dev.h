@@ -435,7 +435,6 @@ struct TileIO {
     int lds_actions_off;   // optional (multi-tick kernel): byte offset of the world's action array in the DYNAMIC LDS region
     int lds_slot;          // (-1 = none), and the slot of tile row (lane & 31) in it
     int x_lds_off;         // one-wave tile in the multi-tick kernel: byte offset of this lane's row in the LDS mirror, or -1 (read obs)
-    int dbg;               // tuning only (RL_RUN_DEBUG bits 32 / 64 / 128): leave policy_tile1s after the row / input layer / hidden layer
     int c_lds_off;         // policy_tile1s: byte offset of the brain's epilogue constants in LDS ([l1 | l2a | l2b][256] floats)
 #ifdef RL_PHASE_PROFILE
     long long* prof;       // tuning build: shader-clock stamps (slots 48..), non-null in the profiled workgroup only
@@ -906,7 +905,7 @@ __device__ inline void policy_tile1(const TileIO& io, int lane)
 constexpr int kTileConstFloats = 3 * 256 + 2 * 16;
 
 // Weight ring over the 2 * NS steps of a layer taken as two passes: step i = K-chunk i % NS of output tiles 2 * (i / NS), +1.
-template <int NS, int D>
+template <int NS, int D, int STEPS = 2 * NS>   // STEPS = NS: one pass only (the caller offsets the base by its tile pair)
 struct WRingH {
     f32x4 a[D][2][kPlanes];
     gf32x4* p;   // tile-pair fragment block of the step the next refill asks for
@@ -935,12 +934,12 @@ struct WRingH {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int pl = 0; pl < kPlanes; ++pl) ac[t][pl] = a[cur][t][pl];
-        if (i + D < 2 * NS) {
+        if (i + D < STEPS) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int pl = 0; pl < kPlanes; ++pl) a[cur][t][pl] = p[(t * kPlanes + pl) * 64];
-            if (i + D + 1 < 2 * NS) { p += off(i + D + 1) - off(i + D); asm volatile("" : "+v"(p)); }
+            if (i + D + 1 < STEPS) { p += off(i + D + 1) - off(i + D); asm volatile("" : "+v"(p)); }
         }
     }
 };
@@ -979,8 +978,8 @@ __device__ inline void split_slice(int k, Raw&& raw, float sc, f32x4& hi, f32x4&
 }
 
 // One pass of a layer: K loop over NS chunks for output tiles 2 * HALF, +1.  shadow(slot), slot = 0 .. 6 * NS - 1, follows MFMA `slot`.
-template <int NS, int D, int HALF, typename Shadow>
-__device__ inline void k_pass(WRingH<NS, D>& w, const f32x4 (&B)[NS][kPlanes], f32x16& a0, f32x16& a1, Shadow&& shadow)
+template <int NS, int D, int HALF, int STEPS, typename Shadow>
+__device__ inline void k_pass(WRingH<NS, D, STEPS>& w, const f32x4 (&B)[NS][kPlanes], f32x16& a0, f32x16& a1, Shadow&& shadow)
 {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; }
@@ -1048,15 +1047,23 @@ __device__ inline void head_stream(WRing<1, 1, 1, D>& w, const f32x4& un4, Raw&&
     for (int r = 0; r < 4; ++r) out[r] = ((a0[r] + a1[r]) + a2[r]) * (un4[r] * row_un);
 }
 
-// PAIR: two waves per tile on ONE SIMD (waves i and i + 4 of a workgroup share one: tools/ubench/simd_map.hip), role 0 = input layer +
-// advantage branch (+ the finish, after the caller's barrier), role 1 = input layer + value branch: each wave streams 2/3 of the
-// weights, and the two hide each other's waits.  The value reaches role 0 through `pair_lds` (32 floats per tile).
+// PAIR: two waves per tile on ONE SIMD (waves i and i + 4 of a workgroup share one: tools/ubench/simd_map.hip), which hide each
+// other's waits.  Input layer: role r computes output tiles 2r, 2r+1 (its half of the 128 features); the two exchange their
+// partial row maxima (pair_lds->pmax) and then their halves of the split activations (pair_lds->ex, which may alias the LDS
+// mirror of the Agent.state rows: every tile wave has read its row before the first of the two workgroup barriers in here).
+// Then role 0 = advantage branch (+ the finish, after the caller's barrier), role 1 = value branch, whose result reaches role 0
+// through pair_lds->val.  Waves without a tile must meet the same two barriers.
+struct PairLds {
+    float* pmax;   // [2 roles][64]
+    f32x4* ex;     // [8 chunks][2 planes][64]
+    float* val;    // [32]
+};
 struct Tile1Part {
     float head[4];
     rl_u4 draw;
 };
 template <int KIND, bool COHERENT, bool PAIR = false>
-__device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, float* pair_lds = nullptr, Tile1Part* part = nullptr)
+__device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, const PairLds* pair_lds = nullptr, Tile1Part* part = nullptr)
 {
     static_assert(KIND == RL_D3QN || KIND == RL_PERD3QN, "one-wave tile: dueling kinds");
     extern __shared__ __attribute__((aligned(16))) char rl_dyn_lds[];
@@ -1067,8 +1074,8 @@ __device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, f
     const float* const consts = (const float*)(rl_dyn_lds + io.c_lds_off) + 32 * h;   // + 256 per layer: l1, l2a, l2b
     const float* const hconsts = (const float*)(rl_dyn_lds + io.c_lds_off) + 768;     // heads: [un 8 | bias 8] advantage, value
     RL_PMARK1(1);
-    WRingH<kInChunks, D> w1;
-    w1.start(packed + L.l1, lane);
+    WRingH<kInChunks, D, PAIR ? kInChunks : 2 * kInChunks> w1;
+    w1.start(packed + L.l1 + (PAIR ? role * (2 * kPlanes * 64 * 4) : 0), lane);
     // ---- the lane's half of its observation row, chunk by chunk: x[row][16c + 8h + 0..7] (see policy_tile1)
     f32x4 X[kInChunks][2];
     {
@@ -1112,7 +1119,6 @@ __device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, f
 #pragma unroll
     for (int k = 0; k < 6; ++k) split_slice<6>(k, [&](int e) { return xraw(0, e); }, sc0, B1[0][0], B1[0][1]);
     RL_PMARK1(2);
-    if (io.dbg & 32) return;
     // ---- input layer
     f32x16 F[4];
     EpiStream ep;
@@ -1121,33 +1127,58 @@ __device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, f
         if (c < kInChunks) split_slice<6>(slot % 6, [&](int e) { return xraw(c, e); }, sc0, B1[c][0], B1[c][1]);
     });
     float mrow = 0.0f;
-    ep.c = consts;
-    k_pass<kInChunks, D, 1>(w1, B1, F[2], F[3], [&](int slot) {
-        if (slot == 0) ep.fetch(0, 0);
-        if (slot >= 2 && slot < 34) ep.step(0, slot - 2, F[0], F[1], un0, mrow);
-    });
-    RL_PMARK1(3);
     const int64_t l2 = (PAIR && role) ? L.l2b : L.l2a, hd = (PAIR && role) ? L.hb : L.ha;
     WRingH<8, D> w2;
-    w2.start(packed + l2, lane);
-    ep.fetch(2, 0);
-#pragma unroll
-    for (int e = 0; e < 32; ++e) ep.step(2, e, F[2], F[3], un0, mrow);
-    mrow = fmaxf(mrow, __shfl_xor(mrow, 32));
-    float sc1, un1;
-    row_scale(mrow, sc1, un1);
-    // relu(feature) feeds both branches (PERD3QN.py:200-201): B2 chunk 2t + c = registers 8c .. 8c+7 of tile t
     f32x4 B2[8][kPlanes];
+    float sc1, un1;
     auto fraw = [&](int c, int e) { return F[c >> 1][8 * (c & 1) + e]; };
+    if (PAIR) {
+        w2.start(packed + l2, lane);
+        ep.c = consts + role * 128;   // tiles 2 * role, + 1
+        ep.fetch(0, 0);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) split_slice<6>(k, [&](int e) { return fraw(0, e); }, sc1, B2[0][0], B2[0][1]);
+        for (int e = 0; e < 32; ++e) ep.step(0, e, F[0], F[1], un0, mrow);
+        mrow = fmaxf(mrow, __shfl_xor(mrow, 32));
+        pair_lds->pmax[role * 64 + lane] = mrow;
+        lds_barrier();
+        mrow = fmaxf(mrow, pair_lds->pmax[(role ^ 1) * 64 + lane]);
+        row_scale(mrow, sc1, un1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {   // own chunks: registers 8 (c & 1) .. of own tile c >> 1 = chunk 4 * role + c of the layer
+            f32x4 hi, lo;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) split_slice<6>(k, [&](int e) { return fraw(c, e); }, sc1, hi, lo);
+            pair_lds->ex[((4 * role + c) * kPlanes + 0) * 64 + lane] = hi;
+            pair_lds->ex[((4 * role + c) * kPlanes + 1) * 64 + lane] = lo;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int pl = 0; pl < kPlanes; ++pl) B2[c][pl] = pair_lds->ex[(c * kPlanes + pl) * 64 + lane];
+    } else {
+        ep.c = consts;
+        k_pass<kInChunks, D, 1>(w1, B1, F[2], F[3], [&](int slot) {
+            if (slot == 0) ep.fetch(0, 0);
+            if (slot >= 2 && slot < 34) ep.step(0, slot - 2, F[0], F[1], un0, mrow);
+        });
+        RL_PMARK1(3);
+        w2.start(packed + l2, lane);
+        ep.fetch(2, 0);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) ep.step(2, e, F[2], F[3], un0, mrow);
+        mrow = fmaxf(mrow, __shfl_xor(mrow, 32));
+        row_scale(mrow, sc1, un1);
+        // relu(feature) feeds both branches (PERD3QN.py:200-201): B2 chunk 2t + c = registers 8c .. 8c+7 of tile t
+#pragma unroll
+        for (int k = 0; k < 6; ++k) split_slice<6>(k, [&](int e) { return fraw(0, e); }, sc1, B2[0][0], B2[0][1]);
+    }
     RL_PMARK1(4);
-    if (io.dbg & 64) return;
     // ---- advantage branch
     f32x16 A[4];
     k_pass<8, D, 0>(w2, B2, A[0], A[1], [&](int slot) {
         const int c = slot / 6 + 1;
-        if (c < 8) split_slice<6>(slot % 6, [&](int e) { return fraw(c, e); }, sc1, B2[c][0], B2[c][1]);
+        if (!PAIR && c < 8) split_slice<6>(slot % 6, [&](int e) { return fraw(c, e); }, sc1, B2[c][0], B2[c][1]);
     });
     mrow = 0.0f;
     ep.c = consts + ((PAIR && role) ? 512 : 256);
@@ -1167,10 +1198,9 @@ __device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, f
     auto araw = [&](int c, int e) { return A[c >> 1][8 * (c & 1) + e]; };
     float adv[4], val[4];
     RL_PMARK1(6);
-    if (io.dbg & 128) return;
     if (PAIR) {
         head_stream<D>(wh, *(const f32x4*)(hconsts + ((PAIR && role) ? 16 : 0) + 4 * h), araw, sc2, un2, adv);
-        if (role) { if (h == 0) pair_lds[lane] = adv[0] + hconsts[16 + 8]; }
+        if (role) { if (h == 0) pair_lds->val[lane] = adv[0] + hconsts[16 + 8]; }
         else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) part->head[r] = adv[r];

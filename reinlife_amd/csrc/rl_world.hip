@@ -1897,7 +1897,7 @@ struct PolSmem {
     int* tstart;        // [64] first tile of brain b
     int* meta;          // [8]  [0] number of tiles; loop state of k_run: [1] list length, [2] Agent.state parity, [3] ticks done,
                         //      [4] the LDS mirror holds the current Agent.state rows
-    float* pairv;       // [4][32] row values from the value-branch wave of a tile pair to its partner (T = 512), or null
+    float* pairv;       // [4 tiles][32 row values | 2 x 64 partial row maxima] of the two-waves-per-tile policy (T = 512), or null
     float* cconst;      // [n_brains][3][256] epilogue constants of the brains' three 128-wide layers for policy_tile1s (T = 512), or null
     float* xmirror;     // [xrows][kXStride] Agent.state rows of this world for the one-wave policy tile (T <= 512), or null
     int xrows;
@@ -1909,6 +1909,8 @@ __host__ __device__ constexpr int policy_group_bytes()
 }
 // groups > 0: `groups` blocks for the 4-wave tile (T = 1024).  groups == 0: the one-wave tile needs no LDS of its own; with
 // mirror_budget > 0 the Agent.state rows are mirrored in LDS instead (as many rows as fit below the budget, at most cap).
+constexpr int kPairFloats = 32 + 2 * 64;     // per tile pair: row values, partial row maxima of the two roles
+constexpr int kPairExBytes = 8 * kPlanes * 64 * 16;   // per tile pair: the split activations of the input layer (aliases the Agent.state mirror)
 template <int KIND>
 __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o, int cap, int groups, size_t mirror_budget = 0, int n_cbrains = 0)
 {
@@ -1916,7 +1918,7 @@ __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o
     ps.group0 = base + o; ps.group_bytes = policy_group_bytes<KIND>();
     o += (size_t)groups * policy_group_bytes<KIND>();
     ps.xmirror = nullptr; ps.xrows = 0;
-    const size_t tail = 4096 + 512 + sizeof(float) * kTileConstFloats * (size_t)n_cbrains;   // what follows the mirror
+    const size_t tail = 4096 + sizeof(float) * 4 * kPairFloats + sizeof(float) * kTileConstFloats * (size_t)n_cbrains;   // what follows the mirror
     if (groups == 0 && mirror_budget > o + tail) {
         const size_t rows = (mirror_budget - o - tail) / (sizeof(float) * kXStride);
         ps.xrows = (int)(rows < (size_t)cap ? rows : (size_t)cap);
@@ -1931,7 +1933,7 @@ __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o
     ps.cconst = nullptr;
     if (n_cbrains > 0) { ps.cconst = (float*)(base + o); o = align16(o + sizeof(float) * kTileConstFloats * (size_t)n_cbrains); }
     ps.pairv = nullptr;
-    if (n_cbrains > 0) { ps.pairv = (float*)(base + o); o = align16(o + sizeof(float) * 4 * 32); }
+    if (n_cbrains > 0) { ps.pairv = (float*)(base + o); o = align16(o + sizeof(float) * 4 * kPairFloats); }
     return o;
 }
 template <int KIND> __device__ inline f32x4* pol_h(const PolSmem& ps, int g) { return (f32x4*)(ps.group0 + g * ps.group_bytes); }
@@ -2086,7 +2088,7 @@ __device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& p
         io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
         io.key_index = (uint32_t)k;
         io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
-        io.x_lds_off = -1; io.c_lds_off = -1; io.dbg = 0;
+        io.x_lds_off = -1; io.c_lds_off = -1;
 #ifdef RL_PHASE_PROFILE
         io.prof = (p.prof && (int)blockIdx.x == p.prof_world) ? p.prof : nullptr;
         if (io.prof && rl_tidx() == 0) io.prof[101] = (long long)clock64();
@@ -2163,25 +2165,27 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
         io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
         io.x_lds_off = (mirrored && k < ps.xrows) ? (int)((char*)(ps.xmirror + k * kXStride) - smem_base) : -1;
         io.c_lds_off = ps.cconst ? (int)((char*)(ps.cconst + kTileConstFloats * b) - smem_base) : -1;
-        io.dbg = *(const int __attribute__((address_space(4)))*)&ka->ra.debug;
         // (the brains' epilogue constants from a copy in LDS instead of L2: measured twice, within noise -- ~300 cycles per layer boundary)
 #ifdef RL_PHASE_PROFILE
         io.prof = (p.prof && (int)blockIdx.x == p.prof_world && wave == 0) ? p.prof : nullptr;
         if (io.prof && lane == 0) { io.prof[100] = t_entry; io.prof[110] = (long long)clock64(); }
 #endif
     };
-    if (T == 512 && ps.pairv != nullptr && ntiles <= 4) {
-        // TWO waves per tile, on the same SIMD (waves i and i + 4): advantage branch / value branch (policy_tile1s<PAIR>)
+    if (T == 512 && ps.pairv != nullptr && ntiles <= 4 && (size_t)ps.xrows * kXStride * sizeof(float) >= 4 * (size_t)kPairExBytes) {
+        // TWO waves per tile, on the same SIMD (waves i and i + 4): policy_tile1s<PAIR>
         const int role = __builtin_amdgcn_readfirstlane(wave >> 2), slot = wave & 3;
         const bool have = slot < ntiles;
         TileIO io;
         Tile1Part part;
+        PairLds pl;
+        pl.val = ps.pairv + kPairFloats * slot; pl.pmax = pl.val + 32;
+        pl.ex = (f32x4*)((char*)ps.xmirror + (size_t)kPairExBytes * slot);
         if (have) {
             tile_io(slot, io);
-            policy_tile1s<KIND, RL_RUN_COHERENT, true>(io, lane, role, ps.pairv + 32 * slot, &part);
-        }
+            policy_tile1s<KIND, RL_RUN_COHERENT, true>(io, lane, role, &pl, &part);
+        } else { lds_barrier(); lds_barrier(); }   // (the two exchanges inside the tile)
         lds_barrier();
-        if (have && role == 0) tile1_finish<KIND>(io, lane, part.head, ps.pairv[32 * slot + j], part.draw, *(const f32x4*)((const float*)(smem_base + io.c_lds_off) + 768 + 8 + 4 * (lane >> 5)));
+        if (have && role == 0) tile1_finish<KIND>(io, lane, part.head, pl.val[j], part.draw, *(const f32x4*)((const float*)(smem_base + io.c_lds_off) + 768 + 8 + 4 * (lane >> 5)));
     } else
     for (int ti = wave; ti < ntiles; ti += T / 64) {
         TileIO io;
@@ -2232,11 +2236,14 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     constexpr bool kSpec = T == 1024;
     int nslots = n0;
     constexpr bool kPlanesEarly = T >= 256;
+    RL_MARK(60);
     phase_step<T, true, kPlanesEarly, kSpec>(p, s, w, n0);
+    RL_MARK(61);
     assign_order<T>(p, s, nslots);
     if (kPlanesEarly) patch_placed_planes(s);
     const int n1 = s.scal[S_N1];
     lds_barrier();
+    RL_MARK(62);
     const bool overlapped = !p.limit_reproduction;
     const size_t b = (size_t)w * p.cap;
     auto step_outputs = [&](int t, int nt) {
@@ -2262,6 +2269,7 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
         step_outputs(tid, T);
     }
     lds_barrier();
+    RL_MARK(63);
     for (int a = tid; a < nslots; a += T) s.src[a] = s.newidx[a];
     if (!overlapped) lds_barrier();
     else nslots = s.scal[S_NSLOTS];
@@ -2272,8 +2280,10 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     }
     for (int i = tid; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
     lds_barrier();
+    RL_MARK(64);
     if (tid < 64) scan_order_wave(p, s, tid, S_N2);
     lds_barrier();
+    RL_MARK(65);
     int n2 = s.scal[S_N2];
     int tick_next = s.scal[S_TICK] + 1, epoch_next = s.scal[S_EPOCH];
     int next_uid = s.scal[S_NEXT_UID], max_gene = s.scal[S_MAX_GENE];
@@ -2300,8 +2310,10 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
             hash_insert_wave(s, p.hash_mask, on, a, on ? ge : 0, 1u << 16);
         }
     }
+    RL_MARK(66);
     build_planes<T>(p, s);
     lds_barrier();
+    RL_MARK(67);
     if (p.uo.src)
         for (int k = tid; k < n2; k += T) p.uo.src[b + k] = refill ? (short)-1 : s.src[s.order[k]];
     if (T <= 512) {   // wave 0 prepares the next tick's policy (rows grouped by brain) while the others write the Agent.state rows
@@ -2309,9 +2321,11 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
         else write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n2, obs_out, tid - 64, ps.xmirror, ps.xrows);
     } else
         write_observations<T>(p, s, w, n2, obs_out, ps.xmirror, ps.xrows);
+    RL_MARK(68);
     if (tid == 0) { ps.meta[1] = n2; ps.meta[2] = cur ^ 1; ps.meta[3] = ticks_done + 1; ps.meta[4] = ps.xmirror != nullptr; }
     // (rows the policy will read back from memory must have reached L2 first; with every row mirrored in LDS the stores just drain)
     recycle_world<T, kSpec>(p, s, n2, tick_next, epoch_next, next_uid, max_gene, ps.xmirror == nullptr || n2 > ps.xrows);
+    RL_MARK(69);
 }
 
 template <int T, int KIND>

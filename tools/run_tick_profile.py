@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""Shader-clock stamps of the TICK half of the multi-tick launch (rl_run), workgroup `world`, thread 0, last tick of a launch (tuning; GPU; prof build)."""
+import ctypes as C, os, sys
+os.environ["RL_PHASE_PROFILE"] = "1"
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from reinlife_amd import _lib
+NAMES = ["policy half end -> tick entry (params, carve)", "Environment.step: act, attack, conflicts, eat/move/death, rewards, food", "order 1 + planes 1 (+ barrier)",
+         "reproduce (wave 0) || obs1 rows + step outputs (others)", "src, agent bitmap, hash clear (+ barrier)", "scan order 2", "refill or order 2 + gene hash", "planes 2 (+ barrier)",
+         "policy lists (wave 0) || obs2 rows -> memory + LDS mirror", "recycle world (compaction, clears, 3 barriers)"]
+IDX = [112, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69]
+SUB = [60, 2, 3, 35, 36, 37, 4, 5, 6, 61]   # inside Environment.step
+SUBN = ["act + attack + prep", "conflict loop", "eat + vanish flags (+bar)", "clear old cells (+bar)", "place + death + hash", "(mark 4)", "rewards", "food count + bitmap", "food placement .. end"]
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+args = __import__("argparse").Namespace(worlds=R, workload="c4", seed=1)
+dw = bench.make_worlds(args, 0, "cuda:0")
+stamps = torch.zeros(128, dtype=torch.int64, device="cuda:0")
+lib = _lib.lib()
+dw.run(50, 70, 100)
+acc = []
+sub = []
+for t in range(40):
+    _lib.check(lib.rl_bind_phase_profile(dw.handle, C.c_void_p(stamps.data_ptr()), (7 * t) % R), "bind")
+    stamps.zero_()
+    dw.run(20 + t % 5, 70, 100)   # the stamps of the LAST tick remain
+    torch.cuda.synchronize()
+    st = stamps.cpu().numpy()[IDX]
+    if st.all() and (np.diff(st) > 0).all():
+        acc.append(np.diff(st))
+        sub.append(np.diff(stamps.cpu().numpy()[SUB]))
+m = np.mean(acc, axis=0)
+print("rl_run tick half, thread 0 of the sampled world, mean of %d launches, total %.0f cycles" % (len(acc), m.sum()))
+for n, v in zip(NAMES, m):
+    print("   %-70s %8.0f  %5.1f%%" % (n, v, 100 * v / m.sum()))
+ms = np.mean(sub, axis=0)
+print("inside Environment.step:")
+for n, v in zip(SUBN, ms):
+    print("      %-60s %8.0f" % (n, v))
