@@ -317,9 +317,13 @@ def main():
         fused_roof["tick_half"] = {"us_per_tick": round(t_tick_half * 1e6, 2), "hbm_GBs": round(n_tick_half * TICK_BYTES_PER_AGENT_STEP / t_tick_half / 1e9, 1),
                                    "hbm_frac": round(n_tick_half * TICK_BYTES_PER_AGENT_STEP / t_tick_half / 1e9 / HBM_PEAK_GBS, 4),
                                    "how": "launches with the policy half skipped (RL_RUN_DEBUG=1)"}
-        fused_roof["policy_half"] = {"us_per_tick": round(t_pol_half * 1e6, 2), "mfma_tflops": round(per_tick * flop / t_pol_half / 1e12, 1),
-                                     "mfma_frac": round(per_tick * flop / t_pol_half / 1e12 / MFMA_F32_EQUIV_PEAK_TFLOPS, 4),
-                                     "how": "launches with the tick half skipped (RL_RUN_DEBUG=2)"}
+        # the policy half inside a full tick = the tick minus the tick half alone (the policy alone, with the tick half skipped, reads its
+        # rows from memory instead of the LDS mirror the tick half fills, and is slower than in place)
+        t_pol_in = max(t_all - t_tick_half, 1e-9)
+        fused_roof["policy_half"] = {"us_per_tick": round(t_pol_in * 1e6, 2), "mfma_tflops": round(per_tick * flop / t_pol_in / 1e12, 1),
+                                     "mfma_frac": round(per_tick * flop / t_pol_in / 1e12 / MFMA_F32_EQUIV_PEAK_TFLOPS, 4),
+                                     "alone_us_per_tick": round(t_pol_half * 1e6, 2),
+                                     "how": "avg_tick_us - tick_half.us_per_tick; alone_us_per_tick = launches with the tick half skipped (RL_RUN_DEBUG=2: rows from memory, not from the LDS mirror)"}
     if rank == 0 and not args.no_kernel_timing:
         # (with --groups G the probe runs group 0 alone: its launches cover worlds/G worlds each)
         # back-to-back launches, no host sync inside the probe (a launch from an idle stream costs ~8 us extra): the event

@@ -2184,6 +2184,9 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
             tile_io(slot, io);
             policy_tile1s<KIND, RL_RUN_COHERENT, true>(io, lane, role, &pl, &part);
         } else { lds_barrier(); lds_barrier(); }   // (the two exchanges inside the tile)
+#ifdef RL_PHASE_PROFILE
+        if (p.prof && (int)blockIdx.x == p.prof_world && lane == 0) p.prof[116 + wave] = (long long)clock64();   // (128 slots)
+#endif
         lds_barrier();
         if (have && role == 0) tile1_finish<KIND>(io, lane, part.head, pl.val[j], part.draw, *(const f32x4*)((const float*)(smem_base + io.c_lds_off) + 768 + 8 + 4 * (lane >> 5)));
     } else
