@@ -1209,9 +1209,9 @@ __device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, c
         RL_PMARK1(9);
         return;
     }
-    WRingH<8, D> w3;
-    w3.start(packed + L.l2b, lane);
     head_stream<D>(wh, *(const f32x4*)(hconsts + 4 * h), araw, sc2, un2, adv);
+    WRingH<8, D> w3;   // (started before the head its twelve fragments are spilled and reloaded inside the value branch's MFMA stream)
+    w3.start(packed + L.l2b, lane);
     RL_PMARK1(7);
     // ---- value branch
     k_pass<8, D, 0>(w3, B2, A[0], A[1], [&](int) {});

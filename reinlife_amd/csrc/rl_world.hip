@@ -1895,6 +1895,8 @@ struct PolSmem {
     int* bstart;        // [64] first entry of brain b in prow
     int* bcnt;          // [64]
     int* tstart;        // [64] first tile of brain b
+    short* trow;        // [kMaxTiles][32] list index of tile row j (| 0x8000: padding, repeats the brain's last row)
+    int* tbrain;        // [kMaxTiles] brain of tile t
     int* meta;          // [8]  [0] number of tiles; loop state of k_run: [1] list length, [2] Agent.state parity, [3] ticks done,
                         //      [4] the LDS mirror holds the current Agent.state rows
     float* pairv;       // [4 tiles][32 row values | 2 x 64 partial row maxima] of the two-waves-per-tile policy (T = 512), or null
@@ -1909,6 +1911,7 @@ __host__ __device__ constexpr int policy_group_bytes()
 }
 // groups > 0: `groups` blocks for the 4-wave tile (T = 1024).  groups == 0: the one-wave tile needs no LDS of its own; with
 // mirror_budget > 0 the Agent.state rows are mirrored in LDS instead (as many rows as fit below the budget, at most cap).
+constexpr int kMaxTiles = 32;                // 32-row tiles of one brain per world: <= cap / 32 + n_brains
 constexpr int kPairFloats = 32 + 2 * 64;     // per tile pair: row values, partial row maxima of the two roles
 constexpr int kPairExBytes = 8 * kPlanes * 64 * 16;   // per tile pair: the split activations of the input layer (aliases the Agent.state mirror)
 template <int KIND>
@@ -1918,7 +1921,7 @@ __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o
     ps.group0 = base + o; ps.group_bytes = policy_group_bytes<KIND>();
     o += (size_t)groups * policy_group_bytes<KIND>();
     ps.xmirror = nullptr; ps.xrows = 0;
-    const size_t tail = 4096 + sizeof(float) * 4 * kPairFloats + sizeof(float) * kTileConstFloats * (size_t)n_cbrains;   // what follows the mirror
+    const size_t tail = 6144 + sizeof(float) * 4 * kPairFloats + sizeof(float) * kTileConstFloats * (size_t)n_cbrains;   // what follows the mirror
     if (groups == 0 && mirror_budget > o + tail) {
         const size_t rows = (mirror_budget - o - tail) / (sizeof(float) * kXStride);
         ps.xrows = (int)(rows < (size_t)cap ? rows : (size_t)cap);
@@ -1929,6 +1932,8 @@ __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o
     ps.bstart = (int*)(base + o); o = align16(o + sizeof(int) * 64);
     ps.bcnt = (int*)(base + o); o = align16(o + sizeof(int) * 64);
     ps.tstart = (int*)(base + o); o = align16(o + sizeof(int) * 64);
+    ps.trow = (short*)(base + o); o = align16(o + sizeof(short) * kMaxTiles * 32);
+    ps.tbrain = (int*)(base + o); o = align16(o + sizeof(int) * kMaxTiles);
     ps.meta = (int*)(base + o); o = align16(o + sizeof(int) * 8);
     ps.cconst = nullptr;
     if (n_cbrains > 0) { ps.cconst = (float*)(base + o); o = align16(o + sizeof(float) * kTileConstFloats * (size_t)n_cbrains); }
@@ -2125,6 +2130,18 @@ __device__ inline void policy_lists_wave0(const KParams& p, PolSmem& ps, int n, 
             if (lane == bb) pos += __popcll(m);
         }
     }
+    // tile descriptors: one LDS read per lane instead of a dependent chain of four at the start of every policy half
+    const int tt = min(read_lane(tincl, 63), kMaxTiles);
+    const int first_tile = tincl - tiles, first_row = incl - mine;
+    for (int e = lane; e < tt * 32; e += 64) {
+        const int t = e >> 5, j = e & 31;
+        int b = 0;
+        for (int bb = 1; bb < p.n_brains; ++bb) if (read_lane(first_tile, bb) <= t && read_lane(mine, bb) > 0) b = bb;
+        const int cntb = __shfl(mine, b), li = (t - __shfl(first_tile, b)) * 32 + j;
+        const int k = ps.prow[__shfl(first_row, b) + min(li, cntb - 1)];
+        ps.trow[e] = (short)(k | (li < cntb ? 0 : 0x8000));
+        if (j == 0) ps.tbrain[t] = b;
+    }
 }
 
 // The same with ONE wave per tile (policy_tile1: no LDS, no barrier inside a tile): wave i takes tiles i, i + T / 64, ...
@@ -2146,16 +2163,12 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
     }
     const bool mirrored = ps.xmirror != nullptr && __builtin_amdgcn_readfirstlane(ps.meta[4]) != 0;
     auto tile_io = [&](int ti, TileIO& io) {
-        int b = 0;
-        for (int bb = 1; bb < p.n_brains; ++bb) if (ps.tstart[bb] <= ti && ps.bcnt[bb] > 0) b = bb;
-        b = __builtin_amdgcn_readfirstlane(b);
-        const int cntb = ps.bcnt[b];
-        const int li = (ti - ps.tstart[b]) * 32 + j;
-        const int k = ps.prow[ps.bstart[b] + min(li, cntb - 1)];
+        const int b = __builtin_amdgcn_readfirstlane(ps.tbrain[ti]);
+        const int e = (unsigned short)ps.trow[ti * 32 + j], k = e & 0x7fff;
         io.packed = (gfloat*)((const float* const __attribute__((address_space(4)))*)ka->ra.packed)[b];
         io.obs = obs_rows;
         io.row = (int64_t)w * p.cap + k;
-        io.valid = li < cntb;
+        io.valid = !(e & 0x8000);
         io.eps = ((const float __attribute__((address_space(4)))*)ka->ra.eps)[b];
         io.out = nullptr;
         io.actions = *(int8_t* const __attribute__((address_space(4)))*)&ka->ra.actions;
