@@ -20,6 +20,8 @@ lib = _lib.lib()
 dw.run(50, 70, 100)
 acc = []
 sub = []
+sub2 = []
+SUB2 = [62, 14, 41, 42, 63]   # inside the reproduce interval (wave 0)
 for t in range(40):
     _lib.check(lib.rl_bind_phase_profile(dw.handle, C.c_void_p(stamps.data_ptr()), (7 * t) % R), "bind")
     stamps.zero_()
@@ -29,6 +31,8 @@ for t in range(40):
     if st.all() and (np.diff(st) > 0).all():
         acc.append(np.diff(st))
         sub.append(np.diff(stamps.cpu().numpy()[SUB]))
+        r2 = stamps.cpu().numpy()[SUB2]
+        if r2.all(): sub2.append(np.diff(r2))
 m = np.mean(acc, axis=0)
 print("rl_run tick half, thread 0 of the sampled world, mean of %d launches, total %.0f cycles" % (len(acc), m.sum()))
 for n, v in zip(NAMES, m):
@@ -37,3 +41,5 @@ ms = np.mean(sub, axis=0)
 print("inside Environment.step:")
 for n, v in zip(SUBN, ms):
     print("      %-60s %8.0f" % (n, v))
+if sub2:
+    print("inside reproduce (wave 0): gates + parents | placements | produce | newborns, dead -> food, barrier:", np.mean(sub2, axis=0).round(0))
