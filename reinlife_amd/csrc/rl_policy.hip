@@ -157,6 +157,42 @@ __global__ __launch_bounds__(64, 2) void k_policy1(const PolicyArgs A)
     policy_tile1<KIND, false>(io, lane);
 }
 
+// Eight tiles of one brain per workgroup, the weights through LDS (policy_tile1d): grid = (groups of 8 tiles a brain can have at most, brains).
+template <int KIND>
+__global__ __launch_bounds__(64 * kDenseTiles, 2) void k_policy_dense(const PolicyArgs A)
+{
+    __shared__ __attribute__((aligned(16))) f32x4 lds_w[3 * kStageUnits];
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, wave = tid >> 6;
+    typedef const int __attribute__((address_space(4))) cint;
+    const int bi = blockIdx.y;
+    const BrainSlot B = A.b[bi];
+    const int n = B.count_ptr ? ((cint*)B.count_ptr)[0] : (int)A.n_rows;
+    if ((int64_t)blockIdx.x * kDenseTiles * 32 >= n) return;   // (uniform: the whole workgroup)
+    const int tile = blockIdx.x * kDenseTiles + wave;
+    const int li = tile * 32 + j;
+    const int lic = min(li, n - 1);                  // waves / lanes past the end: the brain's last row, not stored
+    const int entry = B.rowlist ? B.rowlist[lic] : 0;
+    const int e_w = rl_list_world(entry), e_k = rl_list_slot(entry);
+    TileIO io;
+    io.packed = (gfloat*)B.packed;
+    io.obs = A.obs;
+    io.valid = li < n;
+    io.row = B.rowlist ? (int64_t)e_w * A.cap + e_k : (int64_t)lic;
+    io.eps = B.eps; io.out = A.out; io.actions = A.actions; io.seed = A.seed;
+    io.key_world = io.key_tick = io.key_epoch = io.key_index = 0;
+    io.lds_actions_off = -1; io.lds_slot = 0; io.x_lds_off = -1; io.c_lds_off = -1;
+    if (A.actions && lane < 32) {
+        io.key_world = (uint32_t)(A.world_base + e_w); io.key_index = (uint32_t)e_k;
+        io.key_tick = (uint32_t)A.tick[e_w]; io.key_epoch = (uint32_t)A.epoch[e_w];
+    }
+#ifdef RL_PHASE_PROFILE
+    io.prof = nullptr;
+#endif
+    WStage ws;
+    ws.buf = lds_w; ws.src = (gf32x4*)B.packed + tid; ws.tid = tid; ws.lane = lane;
+    policy_tile1d<KIND>(io, lane, ws);
+}
+
 // 64 rows per workgroup (policy_tile2, the dueling kinds): grid = (64-row tiles a brain can have at most, brains).
 template <int KIND>
 __global__ __launch_bounds__(256, 2) void k_policy2(const PolicyArgs A)
@@ -469,9 +505,17 @@ static int launch_policy(int kind, const PolicyArgs& a, int64_t max_rows, int64_
     // its workgroups; set it to compare rl_run with this path bit for bit), "rows64" = 64 rows per workgroup (policy_tile2).  The
     // default stays the 4-wave 32-row tile: at 256 worlds it is the fastest stand-alone launch (dense 680 tiles: 17.6 us against 17.8 /
     // 22.9; from freshly written rows 18.9 against 25.8 for the one-wave tile, whose row reads are not coalesced).
+    // "dense" = four one-wave tiles of one brain per workgroup with the weights through LDS (policy_tile1d): the default from 1,536 tiles on
+    // (dense launches of one brain, 2,048 / 4,096 / 10,880 tiles: 33.7 / 62.8 / 157 us against 38.6 / 72.7 / 188 for the 4-wave tile; below
+    // ~1,200 tiles its 30 stage barriers per tile cost more than the weight bytes it saves).  "nsplit" forces the 4-wave tile.
     const char* variant = getenv("RL_POLICY_VARIANT");
-    if ((kind == RL_D3QN || kind == RL_PERD3QN) && variant && (!strcmp(variant, "wave") || !strcmp(variant, "rows64"))) {
-        if (!strcmp(variant, "wave")) {
+    if ((kind == RL_D3QN || kind == RL_PERD3QN) && !variant && expected_rows / 32 >= 1536) variant = "dense";
+    if ((kind == RL_D3QN || kind == RL_PERD3QN) && variant && (!strcmp(variant, "wave") || !strcmp(variant, "rows64") || !strcmp(variant, "dense"))) {
+        if (!strcmp(variant, "dense")) {
+            const dim3 gridd((grid.x + kDenseTiles - 1) / kDenseTiles, a.nb);
+            if (kind == RL_D3QN) hipLaunchKernelGGL((k_policy_dense<RL_D3QN>), gridd, dim3(64 * kDenseTiles), 0, st, a);
+            else hipLaunchKernelGGL((k_policy_dense<RL_PERD3QN>), gridd, dim3(64 * kDenseTiles), 0, st, a);
+        } else if (!strcmp(variant, "wave")) {
             if (kind == RL_D3QN) hipLaunchKernelGGL((k_policy1<RL_D3QN>), grid, dim3(64), 0, st, a);
             else hipLaunchKernelGGL((k_policy1<RL_PERD3QN>), grid, dim3(64), 0, st, a);
         } else {

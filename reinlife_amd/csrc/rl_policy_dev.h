@@ -884,6 +884,170 @@ __device__ inline void policy_tile1(const TileIO& io, int lane)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Dense launches (thousands of tiles): kDenseTiles one-wave tiles of one brain per workgroup, the weights through LDS.
+//
+// What bounds the stand-alone policy launches in the throughput regime is the weight stream into the CUs: every
+// 32-row tile pulls the brain's 263 KB through its CU's vector L1.  Here a workgroup of 8 waves = 8 tiles of ONE brain fetches every
+// weight chunk ONCE (512 threads x 16 bytes = one 8 KB stage: a K-chunk of all four output tiles, or four K-chunks of a head),
+// parks it in LDS (three stage buffers, one workgroup barrier per stage) and all eight waves take their MFMA A operands from
+// there: 1/8 of the bytes per row through L2 -> L1, and the LDS reads (64 KB per stage per workgroup = 512 cycles at 128 B/clk)
+// stay below the stage's MFMA time (8 waves x 12 MFMAs on 4 SIMDs = 816 cycles).  Per tile the arithmetic is policy_tile1's,
+// operation for operation: the results are identical bit for bit (tests: RL_POLICY_VARIANT=dense against =wave).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kStageUnits = 512;     // 16-byte units per stage (8 KB)
+constexpr int kStages = 10 + 8 + 2 + 8 + 2;   // input layer, hidden advantage, head advantage, hidden value, head value
+constexpr int kDenseTiles = 4;       // tiles (waves) per workgroup: two such workgroups per CU run out of step and fill each other's VALU / MFMA phases
+constexpr int kDenseLoads = kStageUnits / (64 * kDenseTiles);   // 16-byte loads per thread and stage
+struct WStage {
+    f32x4* buf;       // LDS: 3 x kStageUnits
+    gf32x4* src;      // the brain's packed weights in 16-byte units, + thread index
+    f32x4 q[2][kDenseLoads];   // stages in flight to LDS
+    int tid, lane;
+    static __device__ inline int64_t off(const Layout& L, int I)   // 16-byte units
+    {
+        const int64_t f = I < 10 ? L.l1 + (int64_t)I * 2048 : I < 18 ? L.l2a + (int64_t)(I - 10) * 2048 : I < 20 ? L.ha + (int64_t)(I - 18) * 2048
+                        : I < 28 ? L.l2b + (int64_t)(I - 20) * 2048 : L.hb + (int64_t)(I - 28) * 2048;
+        return f / 4;
+    }
+    __device__ inline void load(const Layout& L, int I, f32x4 (&dst)[kDenseLoads])
+    {
+#pragma unroll
+        for (int u = 0; u < kDenseLoads; ++u) dst[u] = src[off(L, I) + u * 64 * kDenseTiles];
+    }
+    __device__ inline void put(int I, const f32x4 (&v)[kDenseLoads])
+    {
+#pragma unroll
+        for (int u = 0; u < kDenseLoads; ++u) buf[(I % 3) * kStageUnits + u * 64 * kDenseTiles + tid] = v[u];
+    }
+    __device__ inline void start(const Layout& L)
+    {
+        f32x4 s0[kDenseLoads], s1[kDenseLoads];
+        load(L, 0, s0);
+        load(L, 1, s1);
+        load(L, 2, q[0]);
+        load(L, 3, q[1]);
+        put(0, s0);
+        put(1, s1);
+        lds_barrier();
+    }
+    // Stage I: stage I + 2 is written to LDS from its registers (requested two stages ago), stage I + 4 is requested into the registers
+    // that just became free, and ONE barrier publishes stage I + 2 -- so that the fragments of stage I + 1 (published a stage ago) can be
+    // read while the MFMAs of stage I run.  Three buffers: stage I + 2's buffer was last read during stage I - 2, and every wave
+    // has passed stage I - 1's barrier since.
+    __device__ inline void begin(const Layout& L, int I)
+    {
+        if (I + 2 < kStages) put(I + 2, q[I & 1]);
+        if (I + 4 < kStages) load(L, I + 4, q[I & 1]);
+        lds_barrier();
+    }
+    __device__ inline f32x4 frag(int I, int unit) const { return buf[(I % 3) * kStageUnits + unit * 64 + lane]; }
+};
+
+template <int S0, int NS>
+__device__ inline void k_loop_stage(WStage& ws, const Layout& L, const f32x4 (&B)[NS][kPlanes], f32x16 (&acc)[4])
+{
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    f32x4 ac[2][4][kPlanes];   // this stage's fragments, and the next stage's on their way out of LDS
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int pl = 0; pl < kPlanes; ++pl) ac[0][t][pl] = ws.frag(S0, t * kPlanes + pl);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        ws.begin(L, S0 + s);
+        if (s + 1 < NS) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int pl = 0; pl < kPlanes; ++pl) ac[(s + 1) & 1][t][pl] = ws.frag(S0 + s + 1, t * kPlanes + pl);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(ac[s & 1][t][0], B[s][1], acc[t]);  // hi.lo
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(ac[s & 1][t][0], B[s][0], acc[t]);  // hi.hi
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(ac[s & 1][t][1], B[s][0], acc[t]);  // lo.hi
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int S0>
+__device__ inline void head_stage(WStage& ws, const Layout& L, gfloat* __restrict__ hw, const f32x4 (&B)[8][kPlanes], float row_un, int lane, float (&out)[4])
+{
+    const f32x4 un4 = ((gf32x4*)(hw + head_consts_off(4)))[lane >> 5];
+    f32x16 a0, a1, a2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; a2[r] = 0.0f; }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if ((s & 3) == 0) ws.begin(L, S0 + (s >> 2));
+        const f32x4 hi = ws.frag(S0 + (s >> 2), (s & 3) * kPlanes + 0), lo = ws.frag(S0 + (s >> 2), (s & 3) * kPlanes + 1);
+        a0 = mfma16(hi, B[s][1], a0);
+        a1 = mfma16(hi, B[s][0], a1);
+        a2 = mfma16(lo, B[s][0], a2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = ((a0[r] + a1[r]) + a2[r]) * (un4[r] * row_un);
+}
+
+// One wave's tile inside the 8-tile workgroup.  EVERY wave of the workgroup must call it (the stage barriers); a wave without rows
+// passes io.valid == false in all lanes and a readable row.
+template <int KIND>
+__device__ inline void policy_tile1d(const TileIO& io, int lane, WStage& ws)
+{
+    static_assert(KIND == RL_D3QN || KIND == RL_PERD3QN, "dense tile: dueling kinds");
+    const int h = lane >> 5;
+    const Layout L = layout_of(KIND);
+    gfloat* __restrict__ packed = io.packed;
+    ws.start(L);
+    f32x4 B1[kInChunks][kPlanes];
+    {
+        const int64_t rbase = io.row * RL_OBS_DIM;
+#pragma unroll
+        for (int c = 0; c < kInChunks; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k0 = (c == kInChunks - 1 && h == 1) ? 149 : 16 * c + 8 * h + 4 * q;   // (see policy_tile1)
+                B1[c][q] = *(const f32x4u*)(io.obs + rbase + k0);
+            }
+    }
+    rl_u4 draw = {0u, 0u, 0u, 0u};
+    if (io.actions && io.eps > 0.0f) draw = rl_philox4x32(io.seed, io.key_epoch, io.key_world, io.key_tick, RL_SITE_ACT, io.key_index);
+    if (h == 1) { B1[kInChunks - 1][0] = f32x4{B1[kInChunks - 1][0].w, 0.0f, 0.0f, 0.0f}; B1[kInChunks - 1][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    float m = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kInChunks; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(B1[c][q].x), fabsf(B1[c][q].y)), fmaxf(fabsf(B1[c][q].z), fabsf(B1[c][q].w))));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sc0, un0;
+    row_scale(m, sc0, un0);
+#pragma unroll
+    for (int c = 0; c < kInChunks; ++c) {
+        const float x[8] = {B1[c][0].x, B1[c][0].y, B1[c][0].z, B1[c][0].w, B1[c][1].x, B1[c][1].y, B1[c][1].z, B1[c][1].w};
+        split8(x, sc0, B1[c][0], B1[c][1]);
+    }
+    f32x16 acc[4];
+    k_loop_stage<0, kInChunks>(ws, L, B1, acc);
+    f32x4 B2[8][kPlanes], B3[8][kPlanes];
+    float un1, un2;
+    layer_out_to_B(acc, packed + L.l1 + frag_floats(kInChunks, 4), h, un0, B2, un1);
+    k_loop_stage<10, 8>(ws, L, B2, acc);
+    layer_out_to_B(acc, packed + L.l2a + frag_floats(8, 4), h, un1, B3, un2);
+    float adv[4], val[4];
+    head_stage<18>(ws, L, packed + L.ha, B3, un2, lane, adv);
+    k_loop_stage<20, 8>(ws, L, B2, acc);
+    layer_out_to_B(acc, packed + L.l2b + frag_floats(8, 4), h, un1, B3, un2);
+    head_stage<28>(ws, L, packed + L.hb, B3, un2, lane, val);
+    const f32x4 ba = ((gf32x4*)(packed + L.ha + head_consts_off(4) + 8))[h];
+    tile1_finish<KIND>(io, lane, adv, val[0] + packed[L.hb + head_consts_off(4) + 8], draw, ba);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // The one-wave tile, SCHEDULED BY HAND (the multi-tick kernel's policy half is ONE tile's dependency chain).
 //
 // Measured on gfx950 (tools/ubench/valu_rate.hip, mfma_valu_overlap.hip): a wave that is alone on its SIMD issues one VALU

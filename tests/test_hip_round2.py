@@ -513,3 +513,69 @@ def test_multi_tick_launch_other_shapes_and_the_sequential_update(width, height,
         loop.act(); loop.tick_refill(thr, n_new)
     _same_device_state(fused, loop, "after the 20-tick launch")
     assert int(fused.refill_count.item()) == int(loop.refill_count.item())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# dense policy launches: four one-wave tiles per workgroup, weights through LDS (k_policy_dense)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind_name", ["PERD3QN", "D3QN"])
+def test_dense_policy_kernel_is_the_one_wave_tile_bit_for_bit(kind_name, monkeypatch):
+    """RL_POLICY_VARIANT=dense against =wave (the same arithmetic per row) for ragged row counts, the automatic choice above
+    1,536 tiles, and the f32 oracle forward (1e-5) on a sample."""
+    import torch
+    from oracle import oracle as orc
+    from reinlife_amd import _lib
+    from reinlife_amd.worlds import pack_brain_weights, policy_forward
+    kind = _lib.KIND_BY_METHOD[kind_name]
+    w = _weights(kind_name, 11)
+    packed = pack_brain_weights(kind, w)
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    for n in (1, 33, 257, 4095, 8191, 60000):
+        obs = torch.randn(n + 1, 153, device="cuda:0", generator=g)[:n].contiguous()
+        outs = {}
+        for v in ("wave", "dense", None):
+            if v is None:
+                monkeypatch.delenv("RL_POLICY_VARIANT", raising=False)
+            else:
+                monkeypatch.setenv("RL_POLICY_VARIANT", v)
+            out = torch.full((n, 8), float("nan"), device="cuda:0")
+            policy_forward(kind, packed, obs, out)
+            torch.cuda.synchronize()
+            outs[v] = out.cpu().numpy()
+        assert np.array_equal(outs["wave"], outs["dense"]), n
+        if n >= 1536 * 32:
+            assert np.array_equal(outs[None], outs["dense"]), "the dense kernel is the default from 1,536 tiles on"
+        sub = slice(max(0, n - 300), n)
+        want = orc.policy_forward(orc.KIND_BY_NAME[kind_name], w, obs[sub].cpu().numpy())
+        np.testing.assert_allclose(outs["dense"][sub], want, rtol=0, atol=1e-5)
+
+
+def test_dense_policy_kernel_through_the_row_lists_with_draws(monkeypatch):
+    """rl_policy_act over 832 worlds of two PERD3QN brains (one of them epsilon-greedy: the Philox draw per row): the launch picks the
+    dense kernel by itself; actions and Q values equal the one-wave tile's."""
+    import torch
+    from reinlife_amd import _lib
+    from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights
+    cfg = dict(width=30, height=30, max_agents=100, n_brains=2, static_families=True)
+    res = {}
+    for v in ("wave", None):
+        if v is None:
+            monkeypatch.delenv("RL_POLICY_VARIANT", raising=False)
+        else:
+            monkeypatch.setenv("RL_POLICY_VARIANT", v)
+        dw = DeviceWorlds(n_worlds=832, seed=21, **cfg)
+        dw.set_brains([(_lib.PERD3QN, eps, pack_brain_weights(_lib.PERD3QN, _weights("PERD3QN", 40 + k))) for k, eps in enumerate((0.0, 0.3))])
+        dw.reset_synthetic(100)
+        seq = []
+        for t in range(3):
+            dw.act(want_q=True)
+            torch.cuda.synchronize()
+            n = dw.s["n_agents"].cpu().numpy()
+            seq.append((n.copy(), dw.actions.cpu().numpy().copy(), dw.out_q.cpu().numpy().copy()))
+            dw.tick_refill(70, 100)
+        res[v] = seq
+    for (n0, a0, q0), (n1, a1, q1) in zip(res["wave"], res[None]):
+        assert np.array_equal(n0, n1)
+        live = np.arange(a0.shape[1])[None, :] < n0[:, None]
+        assert np.array_equal(a0[live], a1[live])
+        assert np.array_equal(q0[live], q1[live])
