@@ -1073,7 +1073,7 @@ template <int NS, int D, int STEPS = 2 * NS>   // STEPS = NS: one pass only (the
 struct WRingH {
     f32x4 a[D][2][kPlanes];
     gf32x4* p;   // tile-pair fragment block of the step the next refill asks for
-#ifdef RL_ABL_WH
+#ifdef RL_ABL_WH  // tuning experiment (RL_EXTRA_HIPCC_FLAGS=-DRL_ABL_WH): every step re-reads the layer's first fragments (L1 hits; results WRONG)
     static __host__ __device__ constexpr int off(int i) { return 0; }
 #else
     static __host__ __device__ constexpr int off(int i) { return ((i % NS) * 4 + 2 * (i / NS)) * kPlanes * 64; }   // in 16-byte units

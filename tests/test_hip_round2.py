@@ -579,3 +579,38 @@ def test_dense_policy_kernel_through_the_row_lists_with_draws(monkeypatch):
         live = np.arange(a0.shape[1])[None, :] < n0[:, None]
         assert np.array_equal(a0[live], a1[live])
         assert np.array_equal(q0[live], q1[live])
+
+
+@pytest.mark.parametrize("n_brains,max_agents,n_new,thr", [(1, 100, 100, 70), (3, 100, 100, 70), (8, 100, 100, 70), (2, 200, 190, 120)],
+                         ids=["1brain", "3brains", "8brains", "crowded-200"])
+def test_multi_tick_launch_brain_counts_and_crowded_worlds(n_brains, max_agents, n_new, thr, monkeypatch):
+    """rl_run == the two-launch loop for 1 / 3 / 8 brains (1-8 tiles per world: two waves per tile up to four tiles, one wave per tile
+    above) and for worlds of up to 200+ agents (slot capacity 448, more than 128 rows per world), half of the brains epsilon-greedy."""
+    import torch
+    from reinlife_amd import _lib
+    from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights
+    monkeypatch.setenv("RL_POLICY_VARIANT", "wave")
+    cfg = dict(width=30, height=30, max_agents=max_agents, n_brains=n_brains, static_families=True, limit_reproduction=False, incentivize_killing=True)
+    names = ["PERD3QN" if b % 2 == 0 else "D3QN" for b in range(n_brains)]
+    wts = [_weights(n, 700 + k) for k, n in enumerate(names)]
+    pair = []
+    for _ in range(2):
+        dw = DeviceWorlds(n_worlds=12, seed=99, world_base=5, **cfg)
+        dw.set_brains([(_lib.KIND_BY_METHOD[n], 0.2 * (k % 2), pack_brain_weights(_lib.KIND_BY_METHOD[n], w)) for k, (n, w) in enumerate(zip(names, wts))])
+        dw.reset_synthetic(n_new)
+        pair.append(dw)
+    fused, loop = pair
+    assert fused.run_supported()
+    most = 0
+    for chunk in (1, 6, 25, 40):
+        fused.run(chunk, thr, n_new)
+        for _ in range(chunk):
+            loop.act(); loop.tick_refill(thr, n_new)
+        fused.check_error_flag(); loop.check_error_flag()
+        _same_device_state(fused, loop, "%d brains, chunk %d" % (n_brains, chunk))
+        acted = fused.n_acted.cpu().numpy()
+        most = max(most, int(acted.max()))
+        _cmp_rows(fused.actions.cpu().numpy(), loop.actions.cpu().numpy(), acted, "actions")
+        assert int(fused.acted_total.item()) == int(loop.acted_total.item())
+    if max_agents >= 200:
+        assert most > 128, "the crowded case is meant to exceed four 32-row tiles of one brain"
