@@ -45,7 +45,7 @@ constexpr uint8_t kPadCell = 0xFF;  // grid padding up to a multiple of 64 cells
 
 // scalar slots in LDS
 enum { S_ALIVE = 0, S_NFOOD, S_NPOISON, S_NSUPER, S_NSLOTS, S_N1, S_N2, S_NPARENTS, S_NELIG, S_BESTK, S_ERR, S_TICK, S_EPOCH,
-       S_NEXT_UID, S_MAX_GENE, S_ANYFLAG0, S_ANYFLAG1, S_NPLACED, S_SPEC_NF, S_SPEC_NP, S_SPEC_DONE, S_COUNT = 24 };
+       S_NEXT_UID, S_MAX_GENE, S_ANYFLAG0, S_ANYFLAG1, S_NPLACED, S_SPEC_NF, S_SPEC_NP, S_SPEC_DONE, S_PLANES_DIRTY, S_COUNT = 24 };
 
 struct KParams {
     int W, H, C, Cp, nW;
@@ -2234,6 +2234,33 @@ __device__ __forceinline__ void run_policy_half(RunParamsC* ka)
     else run_policy<T, KIND>(p, s, ps, ka, w, n, obs_in, smem_raw);
 }
 
+// The observation planes of the post-UPDATE grid are the post-step planes with two kinds of cells changed: a corpse's cell holds Food now
+// (environment.py:795-799) and a newborn's cell holds an agent of health 200 that is not dead (h = 1 in either dtype mode, f = 0, no gene
+// entry).  Patching those few cells replaces a sweep over the whole grid.  One exception: np.vectorize infers the health plane's dtype from
+// cell (0,0) (build_planes), so a birth or a death THERE changes every agent cell: the caller then rebuilds the planes (S_PLANES_DIRTY).
+// Runs after the barrier behind reproduce_wave0 (order[] still lists the post-step agents; the newborns occupy slots first_new .. end_new-1).
+template <int T>
+__device__ inline void patch_planes_after_update(const KParams& p, Smem& s, int n1, int first_new, int end_new)
+{
+    const int tid = rl_tidx();
+    bool cell0 = false;
+    for (int k = tid; k < n1; k += T) {
+        const int a = s.order[k];
+        const int fl = s.flags[a], ps = s.pos[a];  // one batch
+        if (fl & RL_F_DEAD) {
+            const int c = (ps & 255) * p.W + (ps >> 8);
+            s.foodv[c] = 0.5f; s.healthv[c] = -1.f; s.genev[c] = -2;
+            cell0 |= c == 0;
+        }
+    }
+    for (int i = first_new + tid; i < end_new; i += T) {
+        const int c = s.tgt[i];
+        s.foodv[c] = 0.f; s.healthv[c] = 1.f; s.genev[c] = -2;
+        cell0 |= c == 0;
+    }
+    if (cell0) s.scal[S_PLANES_DIRTY] = 1;
+}
+
 // Second half: Environment.step + update_env (+ re-generation) out of LDS, then recycle_world.  Same sequence as
 // k_world<T, MODE_TICK, LEAN>; writes Agent.state into ra.obs[cur ^ 1] and advances the loop state in LDS.
 template <int T, bool FIXED, int KIND>
@@ -2288,7 +2315,7 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     RL_MARK(63);
     for (int a = tid; a < nslots; a += T) s.src[a] = s.newidx[a];
     if (!overlapped) lds_barrier();
-    else nslots = s.scal[S_NSLOTS];
+    else { const int first_new = nslots; nslots = s.scal[S_NSLOTS]; patch_planes_after_update<T>(p, s, n1, first_new, nslots); }
     if (!overlapped) phase_update<T, true>(p, s, w, n1, nslots, true);
     for (int c = tid; c < p.Cp; c += T) {
         const unsigned long long m = __ballot(s.type[c] == RL_AGENT);
@@ -2327,7 +2354,7 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
         }
     }
     RL_MARK(66);
-    build_planes<T>(p, s);
+    if (refill || !overlapped || s.scal[S_PLANES_DIRTY]) build_planes<T>(p, s);   // (otherwise patched: patch_planes_after_update)
     lds_barrier();
     RL_MARK(67);
     if (p.uo.src)
