@@ -1963,17 +1963,37 @@ __device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& p
 
 // Between two ticks of k_run: the post-update list becomes slots 0..n-1 (slot == list index, what load_world establishes),
 // and every per-tick scratch is reset to what load_world leaves behind.  slot_cap <= T: one agent per thread.
+// (the reads are issued BEFORE the last observation pass, which leaves the agents alone: their dependent LDS round trips then
+// overlap that pass instead of forming an interval of their own)
+struct RecycleRegs {
+    unsigned short pos;
+    int h, age, ma, g, b, u;
+    uint8_t fl;
+    signed char act;
+    double f;
+};
+__device__ inline RecycleRegs recycle_read(Smem& s, int n)
+{
+    const int tid = rl_tidx();
+    const int a = tid < n ? s.order[tid] : 0;
+    RecycleRegs r;
+    r.pos = s.pos[a];
+    r.h = s.health[a]; r.age = s.age[a]; r.ma = s.max_age[a]; r.g = s.gene[a]; r.b = s.brain[a]; r.u = s.uid[a];
+    r.fl = s.flags[a];
+    r.act = s.action[a];
+    r.f = s.fitness[a];
+    return r;
+}
 template <int T, bool SPEC>
-__device__ __forceinline__ void recycle_world(const KParams& p, Smem& s, int n, int tick, int epoch, int next_uid, int max_gene, bool drain_stores)
+__device__ __forceinline__ void recycle_world(const KParams& p, Smem& s, int n, int tick, int epoch, int next_uid, int max_gene, bool drain_stores, const RecycleRegs& rr)
 {
     const int tid = rl_tidx();
     const bool mine = tid < n;
-    const int a = mine ? s.order[tid] : 0;
-    const unsigned short r_pos = s.pos[a];
-    const int r_h = s.health[a], r_age = s.age[a], r_ma = s.max_age[a], r_g = s.gene[a], r_b = s.brain[a], r_u = s.uid[a];
-    const uint8_t r_fl = s.flags[a];
-    const signed char r_act = s.action[a];
-    const double r_f = s.fitness[a];
+    const unsigned short r_pos = rr.pos;
+    const int r_h = rr.h, r_age = rr.age, r_ma = rr.ma, r_g = rr.g, r_b = rr.b, r_u = rr.u;
+    const uint8_t r_fl = rr.fl;
+    const signed char r_act = rr.act;
+    const double r_f = rr.f;
     lds_barrier();   // every field is in registers; the planes were last read before the barrier that precedes this call
     if (mine) {
         s.pos[tid] = r_pos; s.health[tid] = r_h; s.age[tid] = r_age; s.max_age[tid] = r_ma; s.gene[tid] = r_g; s.brain[tid] = r_b;
@@ -2359,6 +2379,7 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     RL_MARK(67);
     if (p.uo.src)
         for (int k = tid; k < n2; k += T) p.uo.src[b + k] = refill ? (short)-1 : s.src[s.order[k]];
+    const RecycleRegs rr = recycle_read(s, n2);
     if (T <= 512) {   // wave 0 prepares the next tick's policy (rows grouped by brain) while the others write the Agent.state rows
         if (tid < 64) policy_lists_wave0(p, ps, n2, tid, [&](int k) { return s.brain[s.order[k]]; });
         else write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n2, obs_out, tid - 64, ps.xmirror, ps.xrows);
@@ -2367,7 +2388,7 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     RL_MARK(68);
     if (tid == 0) { ps.meta[1] = n2; ps.meta[2] = cur ^ 1; ps.meta[3] = ticks_done + 1; ps.meta[4] = ps.xmirror != nullptr; }
     // (rows the policy will read back from memory must have reached L2 first; with every row mirrored in LDS the stores just drain)
-    recycle_world<T, kSpec>(p, s, n2, tick_next, epoch_next, next_uid, max_gene, ps.xmirror == nullptr || n2 > ps.xrows);
+    recycle_world<T, kSpec>(p, s, n2, tick_next, epoch_next, next_uid, max_gene, ps.xmirror == nullptr || n2 > ps.xrows, rr);
     RL_MARK(69);
 }
 
