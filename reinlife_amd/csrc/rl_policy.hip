@@ -193,53 +193,6 @@ __global__ __launch_bounds__(64 * kDenseTiles, 2) void k_policy_dense(const Poli
     policy_tile1d<KIND>(io, lane, ws);
 }
 
-// 64 rows per workgroup (policy_tile2, the dueling kinds): grid = (64-row tiles a brain can have at most, brains).
-template <int KIND>
-__global__ __launch_bounds__(256, 2) void k_policy2(const PolicyArgs A)
-{
-    __shared__ __attribute__((aligned(16))) f32x4 lds_h[policy2_lds_units(KIND)];
-    __shared__ __attribute__((aligned(16))) float lds_aux[kRT * kAuxFloats];
-    __shared__ float lds_part[kRT * 4][32][9];
-    const int lane = threadIdx.x & 63, j = lane & 31, v = threadIdx.x >> 6;
-    {
-        auto ka = __builtin_amdgcn_kernarg_segment_ptr();
-        int t0, t1, t2, t3, t4, t5;
-        asm volatile("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\t"
-                     "s_load_dword %3, %6, 0xc0\n\ts_load_dword %4, %6, 0x100\n\ts_load_dword %5, %6, 0x140\n\ts_waitcnt lgkmcnt(0)"
-                     : "=s"(t0), "=s"(t1), "=s"(t2), "=s"(t3), "=s"(t4), "=s"(t5) : "s"(ka) : "memory");
-    }
-    typedef const int __attribute__((address_space(4))) cint;
-    const int bi = blockIdx.y, tile = blockIdx.x;
-    const BrainSlot B = A.b[bi];
-    const int n = B.count_ptr ? ((cint*)B.count_ptr)[0] : (int)A.n_rows;
-    int entry[kRT];
-#pragma unroll
-    for (int rt = 0; rt < kRT; ++rt) entry[rt] = B.rowlist ? B.rowlist[tile * 64 + rt * 32 + j] : 0;
-    if (tile * 64 >= n) return;
-    TileIO io[kRT];
-#pragma unroll
-    for (int rt = 0; rt < kRT; ++rt) {
-        const int li = tile * 64 + rt * 32 + j;
-        const int e_w = rl_list_world(entry[rt]), e_k = rl_list_slot(entry[rt]);
-        const int64_t listed = B.rowlist ? (int64_t)e_w * A.cap + e_k : (int64_t)li;
-        io[rt].packed = (gfloat*)B.packed;
-        io[rt].obs = A.obs;
-        io[rt].valid = li < n;
-        io[rt].row = (io[rt].valid || B.rowlist) ? listed : (int64_t)tile * 64;  // dense mode: rows past the end do not exist
-        io[rt].eps = B.eps; io[rt].out = A.out; io[rt].actions = A.actions; io[rt].seed = A.seed;
-        io[rt].key_world = io[rt].key_tick = io[rt].key_epoch = io[rt].key_index = 0;
-        io[rt].lds_actions_off = -1; io[rt].lds_slot = 0; io[rt].x_lds_off = -1;
-        if (A.actions && v == rt && lane < 32) {
-            io[rt].key_world = (uint32_t)(A.world_base + e_w); io[rt].key_index = (uint32_t)e_k;
-            io[rt].key_tick = (uint32_t)A.tick[e_w]; io[rt].key_epoch = (uint32_t)A.epoch[e_w];
-        }
-#ifdef RL_PHASE_PROFILE
-        io[rt].prof = nullptr;
-#endif
-    }
-    policy_tile2<KIND, false>(io, lds_h, lds_aux, lds_part, lane, v);
-}
-
 // Brains of DIFFERENT kinds in one launch (mixed populations, BASELINE configs[4]): one launch per kind ran them back to
 // back (PPO 16 us + PERD3QN 13.5 us for the two halves of 680 tiles); here every workgroup picks its brain's tile code at run
 // time, so the kinds overlap on the chip.  Register budget and LDS are the widest kind's (PPO: 2 waves per SIMD).
@@ -501,27 +454,23 @@ static int launch_policy(int kind, const PolicyArgs& a, int64_t max_rows, int64_
     // agent), but the ~2,500 empty workgroups cost < 1 us (a dense launch of the same 680 tiles without them: 17.6 vs 18.4 us).
     // Brain-fastest order (all real tiles dispatched first) is SLOWER: 21.6 vs 18.4 us.
     const dim3 grid(policy_grid(max_rows), a.nb), block(256);
-    // Dueling kinds, A/B variants (env RL_POLICY_VARIANT): "wave" = one wave per 32-row tile (policy_tile1: what rl_run uses inside
-    // its workgroups; set it to compare rl_run with this path bit for bit), "rows64" = 64 rows per workgroup (policy_tile2).  The
-    // default stays the 4-wave 32-row tile: at 256 worlds it is the fastest stand-alone launch (dense 680 tiles: 17.6 us against 17.8 /
-    // 22.9; from freshly written rows 18.9 against 25.8 for the one-wave tile, whose row reads are not coalesced).
-    // "dense" = four one-wave tiles of one brain per workgroup with the weights through LDS (policy_tile1d): the default from 1,536 tiles on
-    // (dense launches of one brain, 2,048 / 4,096 / 10,880 tiles: 33.7 / 62.8 / 157 us against 38.6 / 72.7 / 188 for the 4-wave tile; below
-    // ~1,200 tiles its 30 stage barriers per tile cost more than the weight bytes it saves).  "nsplit" forces the 4-wave tile.
+    // Dueling kinds, variants (env RL_POLICY_VARIANT, read at every launch): "wave" = one wave per 32-row tile (policy_tile1: set it to
+    // compare rl_run, whose workgroups run that arithmetic, with this path bit for bit); "dense" = four one-wave tiles of one brain per
+    // workgroup with the weights through LDS (policy_tile1d), the default from 1,536 tiles on (dense launches of one brain, 2,048 / 4,096 /
+    // 10,880 tiles: 33.7 / 62.8 / 157 us against 38.6 / 72.7 / 188 for the 4-wave tile; below ~1,200 tiles its 30 stage barriers per tile
+    // cost more than the weight bytes it saves); "nsplit" forces the 4-wave 32-row tile, the default below that (at 256 worlds the fastest
+    // stand-alone launch: dense 680 tiles 17.6 us against 17.8; from freshly written rows 18.9 against 25.8 for the one-wave tile, whose
+    // row reads are not coalesced).
     const char* variant = getenv("RL_POLICY_VARIANT");
     if ((kind == RL_D3QN || kind == RL_PERD3QN) && !variant && expected_rows / 32 >= 1536) variant = "dense";
-    if ((kind == RL_D3QN || kind == RL_PERD3QN) && variant && (!strcmp(variant, "wave") || !strcmp(variant, "rows64") || !strcmp(variant, "dense"))) {
+    if ((kind == RL_D3QN || kind == RL_PERD3QN) && variant && (!strcmp(variant, "wave") || !strcmp(variant, "dense"))) {
         if (!strcmp(variant, "dense")) {
             const dim3 gridd((grid.x + kDenseTiles - 1) / kDenseTiles, a.nb);
             if (kind == RL_D3QN) hipLaunchKernelGGL((k_policy_dense<RL_D3QN>), gridd, dim3(64 * kDenseTiles), 0, st, a);
             else hipLaunchKernelGGL((k_policy_dense<RL_PERD3QN>), gridd, dim3(64 * kDenseTiles), 0, st, a);
-        } else if (!strcmp(variant, "wave")) {
+        } else {
             if (kind == RL_D3QN) hipLaunchKernelGGL((k_policy1<RL_D3QN>), grid, dim3(64), 0, st, a);
             else hipLaunchKernelGGL((k_policy1<RL_PERD3QN>), grid, dim3(64), 0, st, a);
-        } else {
-            const dim3 grid2((grid.x + 1) / 2, a.nb);
-            if (kind == RL_D3QN) hipLaunchKernelGGL((k_policy2<RL_D3QN>), grid2, block, 0, st, a);
-            else hipLaunchKernelGGL((k_policy2<RL_PERD3QN>), grid2, block, 0, st, a);
         }
         const hipError_t e1 = hipGetLastError();
         if (e1 != hipSuccess) { rl_set_error("policy kernel launch failed: %s", hipGetErrorString(e1)); return RL_E_LAUNCH; }

@@ -1397,179 +1397,4 @@ __device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, c
     tile1_finish<KIND>(io, lane, adv, val[0] + hconsts[16 + 8], draw, *(const f32x4*)(hconsts + 8 + 4 * h));
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// 64 rows per workgroup (the dueling kinds): two 32-row tiles share every weight fragment.
-//
-// What bounds the policy launches is not MFMA issue nor instruction issue but the WEIGHT BYTES that reach the CUs: a 32-row
-// tile pulls the brain's whole packed network (263 KB incl. epilogue constants) through its CU's vector L1, and the launches
-// sit at ~14 TB/s of L2 -> L1 traffic whatever the tile code looks like (179 MB / 12.7 us at 256 worlds, 2.87 GB / 200 us at
-// 4096; the 4-wave tile, the one-wave tile and a variant with 15 % fewer instructions all take the same time; re-reading one
-// L1-resident chunk instead of streaming changes nothing either: the return path into the registers is the limit).  So the
-// lever is rows per weight fetch: here every A fragment a wave loads feeds TWO B tiles (rows 0-31 and 32-63 of the workgroup),
-// which halves the bytes per row.  Per row the arithmetic, and therefore every result, is exactly that of policy_tile.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int kRT = 2;
-__host__ __device__ constexpr int policy2_lds_units(int kind) { return kRT * policy_lds_units(kind); }
-
-template <int NS, int D>
-__device__ inline void k_loop2(WRing<4, 1, 1, D>& w, const f32x4* __restrict__ bsrc, int rt_units, int bplane, int bstep, f32x16 (&acc)[kRT],
-                               EpiConsts* epi = nullptr, gfloat* __restrict__ epi_consts = nullptr, int epi_t2 = 0, int epi_half = 0)
-{
-    f32x16 cross[kRT];
-#pragma unroll
-    for (int rt = 0; rt < kRT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[rt][r] = 0.0f; cross[rt][r] = 0.0f; }
-    f32x4 b[2][kRT][kPlanes];
-#pragma unroll
-    for (int rt = 0; rt < kRT; ++rt)
-#pragma unroll
-        for (int pl = 0; pl < kPlanes; ++pl) b[0][rt][pl] = bsrc[rt * rt_units + pl * bplane];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        f32x4 ac[1][kPlanes];
-        w.template next<NS>(s, ac);
-        if (s + 1 < NS) {
-#pragma unroll
-            for (int rt = 0; rt < kRT; ++rt)
-#pragma unroll
-                for (int pl = 0; pl < kPlanes; ++pl) b[(s + 1) & 1][rt][pl] = bsrc[rt * rt_units + pl * bplane + (s + 1) * bstep];
-        }
-        // four accumulator chains (main / cross of the two row tiles): the same three products per row as policy_tile
-#pragma unroll
-        for (int rt = 0; rt < kRT; ++rt) cross[rt] = mfma16(ac[0][0], b[s & 1][rt][1], cross[rt]);
-#pragma unroll
-        for (int rt = 0; rt < kRT; ++rt) acc[rt] = mfma16(ac[0][0], b[s & 1][rt][0], acc[rt]);
-#pragma unroll
-        for (int rt = 0; rt < kRT; ++rt) cross[rt] = mfma16(ac[0][1], b[s & 1][rt][0], cross[rt]);
-        if (epi && s == (NS > 4 ? NS - 4 : 0)) epi->start(epi_consts, epi_t2, epi_half);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int rt = 0; rt < kRT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rt][r] += cross[rt][r];
-}
-
-// head of one row tile from the wave's registers, weights already in `w` (HeadW of policy_tile)
-__device__ inline void head_mfma1(const HeadW<1, 1>& w, const f32x16& hin, float (&out)[4])
-{
-    const f32x16 (&arr)[1] = reinterpret_cast<const f32x16 (&)[1]>(hin);
-    head_mfma(w, arr, out);
-}
-
-// io[rt]: rows / validity / keys of row tile rt (packed, obs, eps, out, actions, seed taken from io[0]).
-// LDS: lds_h = kRT x policy_lds_units(KIND) units, lds_aux = kRT x kAuxFloats, lds_part = kRT x [4][32][9].
-template <int KIND, bool COHERENT>
-__device__ inline void policy_tile2(const TileIO (&io)[kRT], f32x4* __restrict__ lds_h, float* __restrict__ lds_aux,
-                                    float (*__restrict__ lds_part)[32][9], int lane, int v)
-{
-    static_assert(KIND == RL_D3QN || KIND == RL_PERD3QN, "64-row tile: dueling kinds");
-    constexpr int PS = 4 * 2 * 64;                         // units per plane of the published activations
-    constexpr int RTU = policy_lds_units(KIND);            // units per row tile
-    const int h = lane >> 5, j = lane & 31;
-    const Layout L = layout_of(KIND);
-    gfloat* __restrict__ packed = io[0].packed;
-    const int xb = h * kXGroup + j;
-    f32x16 h1[kRT], h2[kRT];
-    float adv[kRT][4], val[kRT][4];
-    WRing<4, 1, 1, 3> w1, w2;
-    HeadW<1, 1> wh;
-    EpiConsts e1;
-    // wave v finishes row tile v (v < 2): its action draw and the head biases are fetched while the rows are in flight
-    rl_u4 draw = {0u, 0u, 0u, 0u};
-    f32x4 duel_ba0 = {0.0f, 0.0f, 0.0f, 0.0f}, duel_ba1 = {0.0f, 0.0f, 0.0f, 0.0f};
-    float duel_bv = 0.0f;
-    const TileIO& mine = io[v < kRT ? v : 0];
-    auto early = [&]() {
-        if (v < kRT && mine.actions) draw = rl_philox4x32(mine.seed, mine.key_epoch, mine.key_world, mine.key_tick, RL_SITE_ACT, mine.key_index);
-    };
-    auto nothing = [&]() {};
-    w1.start(packed + L.l1, lane, v);
-    if (v < kRT) {
-        const gf32x4* ba = (const gf32x4*)(packed + L.ha + head_consts_off(4) + 8);
-        duel_ba0 = ba[0]; duel_ba1 = ba[1];
-        duel_bv = packed[L.hb + head_consts_off(4) + 8];
-    }
-    stage_x<COHERENT>(lds_h, lds_aux, io[0].obs, io[0].row, lane, v, early);
-    stage_x<COHERENT>(lds_h + RTU, lds_aux + kAuxFloats, io[0].obs, io[1].row, lane, v, nothing);
-    lds_barrier();
-    k_loop2<kInChunks>(w1, lds_h + xb, RTU, kXPlane, 2 * kXGroup, h1);
-    w2.start(packed + L.l2a, lane, v);
-    wh.start(packed + L.ha, 4, lane, v);
-    e1.start(packed + L.l1 + frag_floats(kInChunks, 4), v, h);
-#pragma unroll
-    for (int rt = 0; rt < kRT; ++rt) {
-        epilogue_tile<true>(h1[rt], e1, lds_aux[rt * kAuxFloats + j]);   // relu(feature) feeds both branches (PERD3QN.py:200-201)
-        row_max_put(lds_aux + rt * kAuxFloats, j, v * 2 + h, reg_max(h1[rt]));
-    }
-    lds_barrier();   // every wave is done with the observation tiles: their LDS becomes the activation exchange
-    float un1[kRT];
-#pragma unroll
-    for (int rt = 0; rt < kRT; ++rt) {
-        float sc1;
-        row_scale(row_max_get(lds_aux + rt * kAuxFloats, j), sc1, un1[rt]);
-        publish_tile(lds_h + rt * RTU, PS, v, lane, h1[rt], sc1);
-    }
-    lds_barrier();
-    k_loop2<8>(w2, lds_h + lane, RTU, PS, 64, h2);
-    w1.start(packed + L.l2b, lane, v);   // the value branch's first chunks arrive while the advantage head runs
-    e1.start(packed + L.l2a + frag_floats(8, 4), v, h);
-#pragma unroll
-    for (int rt = 0; rt < kRT; ++rt) {
-        epilogue_tile<true>(h2[rt], e1, un1[rt]);
-        head_mfma1(wh, h2[rt], adv[rt]);
-    }
-    wh.start(packed + L.hb, 4, lane, v);
-    k_loop2<8>(w1, lds_h + lane, RTU, PS, 64, h2);
-    e1.start(packed + L.l2b + frag_floats(8, 4), v, h);
-#pragma unroll
-    for (int rt = 0; rt < kRT; ++rt) {
-        epilogue_tile<true>(h2[rt], e1, un1[rt]);
-        head_mfma1(wh, h2[rt], val[rt]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lds_part[rt * 4 + v][j][4 * h + r] = adv[rt][r];
-        if (h == 0) lds_part[rt * 4 + v][j][8] = val[rt][0];
-    }
-    lds_barrier();
-    if (v < kRT && h == 0) {
-        float (*part)[32][9] = lds_part + v * 4;
-        float sum9[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) sum9[i] = ((part[0][j][i] + part[1][j][i]) + part[2][j][i]) + part[3][j][i];
-        const float ba[8] = {duel_ba0.x, duel_ba0.y, duel_ba0.z, duel_ba0.w, duel_ba1.x, duel_ba1.y, duel_ba1.z, duel_ba1.w};
-        float a8[8], mean = 0.0f;  // advantage.mean() of the [1,8] tensor == per-row mean when batched
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { a8[i] = sum9[i] + ba[i]; mean += a8[i]; }
-        mean *= 0.125f;
-        const float value = sum9[8] + duel_bv;
-        float q[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) q[i] = a8[i] + value - mean;
-        if (mine.valid) {
-            if (mine.out) {
-                f32x4* o = (f32x4*)(mine.out + mine.row * 8);
-                o[0] = f32x4{q[0], q[1], q[2], q[3]};
-                o[1] = f32x4{q[4], q[5], q[6], q[7]};
-            }
-            if (mine.actions) {
-                const float u = (float)rl_u24(draw.x);
-                int a = 0;
-                if (u < mine.eps) a = (int)(draw.y >> 29);
-                else {
-                    float best = q[0];
-#pragma unroll
-                    for (int i = 1; i < 8; ++i) { const bool gt = q[i] > best; a = gt ? i : a; best = gt ? q[i] : best; }  // first maximum
-                }
-                mine.actions[mine.row] = (int8_t)a;
-                if (mine.lds_actions_off >= 0) {
-                    extern __shared__ __attribute__((aligned(16))) char rl_dyn_lds[];
-                    ((signed char*)rl_dyn_lds)[mine.lds_actions_off + mine.lds_slot] = (signed char)a;
-                }
-            }
-        }
-    }
-    lds_barrier();  // lds_h / lds_part are reused by the next tile
-}
-
 }  // namespace
