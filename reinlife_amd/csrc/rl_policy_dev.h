@@ -932,8 +932,8 @@ struct WStage {
     }
     // Stage I: stage I + 2 is written to LDS from its registers (requested two stages ago), stage I + 4 is requested into the registers
     // that just became free, and ONE barrier publishes stage I + 2 -- so that the fragments of stage I + 1 (published a stage ago) can be
-    // read while the MFMAs of stage I run.  Three buffers: stage I + 2's buffer was last read during stage I - 2, and every wave
-    // has passed stage I - 1's barrier since.
+    // read while the MFMAs of stage I run.  Three buffers, and ONE RULE for the readers: stage J is read into registers before the
+    // wave meets stage J's barrier (begin(J)); behind that barrier a faster wave's begin(J + 1) overwrites stage J's buffer.
     __device__ inline void begin(const Layout& L, int I)
     {
         if (I + 2 < kStages) put(I + 2, q[I & 1]);
@@ -981,13 +981,22 @@ __device__ inline void head_stage(WStage& ws, const Layout& L, gfloat* __restric
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; a2[r] = 0.0f; }
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        if ((s & 3) == 0) ws.begin(L, S0 + (s >> 2));
-        const f32x4 hi = ws.frag(S0 + (s >> 2), (s & 3) * kPlanes + 0), lo = ws.frag(S0 + (s >> 2), (s & 3) * kPlanes + 1);
-        a0 = mfma16(hi, B[s][1], a0);
-        a1 = mfma16(hi, B[s][0], a1);
-        a2 = mfma16(lo, B[s][0], a2);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int hs = 0; hs < 2; ++hs) {   // a head = two stages of four K-chunks
+        // A stage must be out of LDS BEFORE the wave meets that stage's barrier: behind it the faster waves refill the buffer (begin()).
+        f32x4 fr[4][kPlanes];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int pl = 0; pl < kPlanes; ++pl) fr[c][pl] = ws.frag(S0 + hs, c * kPlanes + pl);
+        ws.begin(L, S0 + hs);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int s = 4 * hs + c;
+            a0 = mfma16(fr[c][0], B[s][1], a0);
+            a1 = mfma16(fr[c][0], B[s][0], a1);
+            a2 = mfma16(fr[c][1], B[s][0], a2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[r] = ((a0[r] + a1[r]) + a2[r]) * (un4[r] * row_un);

@@ -567,7 +567,7 @@ def test_dense_policy_kernel_through_the_row_lists_with_draws(monkeypatch):
         dw.set_brains([(_lib.PERD3QN, eps, pack_brain_weights(_lib.PERD3QN, _weights("PERD3QN", 40 + k))) for k, eps in enumerate((0.0, 0.3))])
         dw.reset_synthetic(100)
         seq = []
-        for t in range(3):
+        for t in range(8):
             dw.act(want_q=True)
             torch.cuda.synchronize()
             n = dw.s["n_agents"].cpu().numpy()
