@@ -1169,6 +1169,13 @@ __device__ inline void k_pass(WRingH<NS, D, STEPS>& w, const f32x4 (&B)[NS][kPla
     }
 }
 
+__device__ inline void max3_abs(float& m, float a, float b)   // m = max(m, |a|, |b|) in one instruction
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
+#endif
+}
+
 // Epilogue of two finished output tiles, one accumulator register per step (32 steps): y = relu(acc * (unscale * row_un) + bias),
 // m = max(m, y).  The constants of quarter Q (4 registers) are read from LDS while quarter Q - 1 is worked on.
 struct EpiStream {
@@ -1278,12 +1285,17 @@ __device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, c
     rl_u4 draw = {0u, 0u, 0u, 0u};
     if ((!PAIR || role == 0) && io.actions && io.eps > 0.0f) draw = rl_philox4x32(io.seed, io.key_epoch, io.key_world, io.key_tick, RL_SITE_ACT, io.key_index);
     if (h == 1) { X[kInChunks - 1][0] = f32x4{X[kInChunks - 1][0].w, 0.0f, 0.0f, 0.0f}; X[kInChunks - 1][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-    float m = 0.0f;
+    // the row's largest magnitude: four independent chains of max3(m, |a|, |b|) -- 40 instructions (the compiler's tree over fabsf / fmaxf
+    // is 92, and ONE chain of 40 is slower than that tree: a dependent VALU instruction costs a lone wave more than its issue slot)
+    float m4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int c = 0; c < kInChunks; ++c)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-            m = fmaxf(m, fmaxf(fmaxf(fabsf(X[c][q].x), fabsf(X[c][q].y)), fmaxf(fabsf(X[c][q].z), fabsf(X[c][q].w))));
+        for (int q = 0; q < 2; ++q) {
+            max3_abs(m4[(2 * c + q) & 3], X[c][q].x, X[c][q].y);
+            max3_abs(m4[(2 * c + q + 2) & 3], X[c][q].z, X[c][q].w);
+        }
+    float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
     m = fmaxf(m, __shfl_xor(m, 32));
     float sc0, un0;
     row_scale(m, sc0, un0);
