@@ -32,6 +32,16 @@
 // policy and tick back to back inside a tick loop; with the plain builtin every per-thread constant of the tick phases (window
 // offsets, row bases, ...) was hoisted out of that loop and kept alive -- i.e. spilled -- across the 126-VGPR tile code.
 __device__ inline int rl_tidx() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+// The lane index WITHOUT the thread index: at the head of the policy half the thread index has been spilled (the tile code takes all 256
+// VGPRs), and its reload is a memory round trip that also waits for the wave's observation-row stores.  Opaque for the same reason as above.
+__device__ inline int rl_lane_fresh()
+{
+    int l = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+#endif
+    return l;
+}
 
 int rl_world_prepare_bytes(size_t bytes);
 size_t rl_world_smem_bytes(int cpad, int cap, int hash);
@@ -2167,9 +2177,10 @@ __device__ inline void policy_lists_wave0(const KParams& p, PolSmem& ps, int n, 
 // The same with ONE wave per tile (policy_tile1: no LDS, no barrier inside a tile): wave i takes tiles i, i + T / 64, ...
 // Needs the 256-VGPR budget of a workgroup of at most 512 threads.
 template <int T, int KIND>
-__device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base)
+__device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base, int wave)
 {
-    const int tid = rl_tidx(), lane = tid & 63, wave = tid >> 6, j = lane & 31;
+    // (`wave`: the wave's index in the workgroup, uniform -- computed once per launch and kept in an SGPR)
+    const int lane = rl_lane_fresh(), tid = wave * 64 + lane, j = lane & 31;
 #ifdef RL_PHASE_PROFILE
     const long long t_entry = (long long)clock64();
 #endif
@@ -2240,7 +2251,7 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
 
 // First half of a tick: the policy.  Reads the list length and the Agent.state parity from LDS.
 template <int T, bool FIXED, int KIND>
-__device__ __forceinline__ void run_policy_half(RunParamsC* ka)
+__device__ __forceinline__ void run_policy_half(RunParamsC* ka, int wave)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const KParams p = run_params<FIXED>(ka);
@@ -2250,7 +2261,7 @@ __device__ __forceinline__ void run_policy_half(RunParamsC* ka)
     const int w = blockIdx.x;
     const int n = __builtin_amdgcn_readfirstlane(ps.meta[1]), cur = __builtin_amdgcn_readfirstlane(ps.meta[2]);
     const float* obs_in = ((float* const __attribute__((address_space(4)))*)ka->ra.obs)[cur];
-    if (T <= 512) run_policy1<T, KIND>(p, s, ps, ka, w, n, obs_in, smem_raw);
+    if (T <= 512) run_policy1<T, KIND>(p, s, ps, ka, w, n, obs_in, smem_raw, wave);
     else run_policy<T, KIND>(p, s, ps, ka, w, n, obs_in, smem_raw);
 }
 
@@ -2444,8 +2455,9 @@ __global__ __launch_bounds__(T) void k_run(const RunParams rp)
     run_load_call<T, FIXED, KIND>(ka);
     const int n_ticks = *(cint*)&ka->ra.n_ticks;
     const int dbg = *(cint*)&ka->ra.debug;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     for (int it = 0; it < n_ticks; ++it) {   // (`it` and the bounds are uniform: SGPRs, which a callee preserves)
-        if (!(dbg & 1)) run_policy_half<T, FIXED, KIND>(ka);
+        if (!(dbg & 1)) run_policy_half<T, FIXED, KIND>(ka, wave);
         if (!(dbg & 2)) {
             if constexpr (FIXED) run_tick_call_fixed<T, KIND>(ka);
             else run_tick_call_generic<T, KIND>(ka);
