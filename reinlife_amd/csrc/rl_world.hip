@@ -2174,8 +2174,10 @@ __device__ inline void policy_lists_wave0(const KParams& p, PolSmem& ps, int n, 
     }
 }
 
-// The same with ONE wave per tile (policy_tile1: no LDS, no barrier inside a tile): wave i takes tiles i, i + T / 64, ...
-// Needs the 256-VGPR budget of a workgroup of at most 512 threads.
+// The policy half for workgroups of at most 512 threads (the tiles below need the 256-VGPR budget).  T = 512, up to four tiles: TWO waves per
+// tile on one SIMD (policy_tile1s<PAIR>); five to eight tiles: one hand-scheduled tile per wave (policy_tile1s); T = 256: one
+// policy_tile1 per wave (no LDS, no barrier inside a tile), wave i takes tiles i, i + 4, ...  Tile rows, validity and brain come from the
+// descriptors wave 0 wrote next to the row lists (policy_lists_wave0).
 template <int T, int KIND>
 __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base, int wave)
 {
@@ -2209,7 +2211,6 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
         io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
         io.x_lds_off = (mirrored && k < ps.xrows) ? (int)((char*)(ps.xmirror + k * kXStride) - smem_base) : -1;
         io.c_lds_off = ps.cconst ? (int)((char*)(ps.cconst + kTileConstFloats * b) - smem_base) : -1;
-        // (the brains' epilogue constants from a copy in LDS instead of L2: measured twice, within noise -- ~300 cycles per layer boundary)
 #ifdef RL_PHASE_PROFILE
         io.prof = (p.prof && (int)blockIdx.x == p.prof_world && wave == 0) ? p.prof : nullptr;
         if (io.prof && lane == 0) { io.prof[100] = t_entry; io.prof[110] = (long long)clock64(); }
