@@ -2453,9 +2453,17 @@ __global__ __launch_bounds__(T) void k_run(const RunParams rp)
 {
     RunParamsC* ka = (RunParamsC*)__builtin_amdgcn_kernarg_segment_ptr();
     typedef const int __attribute__((address_space(4))) cint;
-    run_load_call<T, FIXED, KIND>(ka);
     const int n_ticks = *(cint*)&ka->ra.n_ticks;
     const int dbg = *(cint*)&ka->ra.debug;
+    // Workgroups that start in exact lockstep stay in lockstep for tens of ticks (every world does the same work at the same moment:
+    // 256 CUs ask L2 for the same weight lines, then all write their observation rows), and such ticks are ~3 us slower than those of
+    // drifted-apart worlds: kernel time of a 20-tick launch 545 -> 518 us with the starts spread over 3.75 us (16 steps of 0.25 us; 0.5 / 1 us
+    // steps, 32 or 64 groups give the same), 100- and 500-tick launches unchanged.  RL_RUN_DEBUG & 32 switches it off (measurements).
+    if (!(dbg & 32)) {
+        const long long until = (long long)clock64() + (long long)(blockIdx.x & 15) * 500;
+        while ((long long)clock64() < until) __builtin_amdgcn_s_sleep(2);
+    }
+    run_load_call<T, FIXED, KIND>(ka);
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     for (int it = 0; it < n_ticks; ++it) {   // (`it` and the bounds are uniform: SGPRs, which a callee preserves)
         if (!(dbg & 1)) run_policy_half<T, FIXED, KIND>(ka, wave);
