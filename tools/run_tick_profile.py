@@ -25,7 +25,7 @@ SUB2 = [62, 14, 41, 42, 63]   # inside the reproduce interval (wave 0)
 for t in range(40):
     _lib.check(lib.rl_bind_phase_profile(dw.handle, C.c_void_p(stamps.data_ptr()), (7 * t) % R), "bind")
     stamps.zero_()
-    dw.run(20 + t % 5, 70, 100)   # the stamps of the LAST tick remain
+    dw.run(int(os.environ.get("RL_PROFILE_TICKS", "0")) or (20 + t % 5), 70, 100)   # the stamps of the LAST tick remain (RL_PROFILE_TICKS=1: a launch's FIRST tick)
     torch.cuda.synchronize()
     st = stamps.cpu().numpy()[IDX]
     if st.all() and (np.diff(st) > 0).all():
