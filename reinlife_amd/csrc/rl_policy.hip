@@ -157,11 +157,13 @@ __global__ __launch_bounds__(64, 2) void k_policy1(const PolicyArgs A)
     policy_tile1<KIND, false>(io, lane);
 }
 
-// Eight tiles of one brain per workgroup, the weights through LDS (policy_tile1d): grid = (groups of 8 tiles a brain can have at most, brains).
+// kDenseTiles tiles of one brain per workgroup, the weights through LDS (policy_tile1ds): grid = (groups of kDenseTiles tiles a brain can
+// have at most, brains).
 template <int KIND>
 __global__ __launch_bounds__(64 * kDenseTiles, 2) void k_policy_dense(const PolicyArgs A)
 {
     __shared__ __attribute__((aligned(16))) f32x4 lds_w[3 * kStageUnits];
+    __shared__ __attribute__((aligned(16))) float lds_c[kTileConstFloats];
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, wave = tid >> 6;
     typedef const int __attribute__((address_space(4))) cint;
     const int bi = blockIdx.y;
@@ -188,9 +190,19 @@ __global__ __launch_bounds__(64 * kDenseTiles, 2) void k_policy_dense(const Poli
 #ifdef RL_PHASE_PROFILE
     io.prof = nullptr;
 #endif
-    WStage ws;
+    {   // the brain's epilogue / head constants (published by the barrier in WStage2::start)
+        const Layout L = layout_of(KIND);
+        gfloat* pk = (gfloat*)B.packed;
+        for (int i = tid; i < kTileConstFloats; i += 64 * kDenseTiles) {
+            const int layer = i >> 8;
+            const int64_t off = layer == 0 ? L.l1 + frag_floats(kInChunks, 4) : layer == 1 ? L.l2a + frag_floats(8, 4) : layer == 2 ? L.l2b + frag_floats(8, 4)
+                              : (i < 768 + 16 ? L.ha : L.hb) + head_consts_off(4) - (i < 768 + 16 ? 768 : 768 + 16);
+            lds_c[i] = pk[off + (layer < 3 ? (i & 255) : i)];
+        }
+    }
+    WStage2 ws;
     ws.buf = lds_w; ws.src = (gf32x4*)B.packed + tid; ws.tid = tid; ws.lane = lane;
-    policy_tile1d<KIND>(io, lane, ws);
+    policy_tile1ds<KIND>(io, lane, ws, lds_c);
 }
 
 // Brains of DIFFERENT kinds in one launch (mixed populations, BASELINE configs[4]): one launch per kind ran them back to
@@ -456,8 +468,8 @@ static int launch_policy(int kind, const PolicyArgs& a, int64_t max_rows, int64_
     const dim3 grid(policy_grid(max_rows), a.nb), block(256);
     // Dueling kinds, variants (env RL_POLICY_VARIANT, read at every launch): "wave" = one wave per 32-row tile (policy_tile1: set it to
     // compare rl_run, whose workgroups run that arithmetic, with this path bit for bit); "dense" = four one-wave tiles of one brain per
-    // workgroup with the weights through LDS (policy_tile1d), the default from 1,536 tiles on (dense launches of one brain, 2,048 / 4,096 /
-    // 10,880 tiles: 33.7 / 62.8 / 157 us against 38.6 / 72.7 / 188 for the 4-wave tile; below ~1,200 tiles its 30 stage barriers per tile
+    // workgroup with the weights through LDS (policy_tile1ds), the default from 1,536 tiles on (dense launches of one brain, 2,048 / 4,096 /
+    // 10,880 tiles: 32.4 / 60.9 / 148 us against 38.6 / 72.7 / 188 for the 4-wave tile; below ~1,200 tiles its 30 stage barriers per tile
     // cost more than the weight bytes it saves); "nsplit" forces the 4-wave 32-row tile, the default below that (at 256 worlds the fastest
     // stand-alone launch: dense 680 tiles 17.6 us against 17.8; from freshly written rows 18.9 against 25.8 for the one-wave tile, whose
     // row reads are not coalesced).

@@ -887,174 +887,15 @@ __device__ inline void policy_tile1(const TileIO& io, int lane)
 // Dense launches (thousands of tiles): kDenseTiles one-wave tiles of one brain per workgroup, the weights through LDS.
 //
 // What bounds the stand-alone policy launches in the throughput regime is the weight stream into the CUs: every
-// 32-row tile pulls the brain's 263 KB through its CU's vector L1.  Here a workgroup of 8 waves = 8 tiles of ONE brain fetches every
-// weight chunk ONCE (512 threads x 16 bytes = one 8 KB stage: a K-chunk of all four output tiles, or four K-chunks of a head),
-// parks it in LDS (three stage buffers, one workgroup barrier per stage) and all eight waves take their MFMA A operands from
-// there: 1/8 of the bytes per row through L2 -> L1, and the LDS reads (64 KB per stage per workgroup = 512 cycles at 128 B/clk)
-// stay below the stage's MFMA time (8 waves x 12 MFMAs on 4 SIMDs = 816 cycles).  Per tile the arithmetic is policy_tile1's,
-// operation for operation: the results are identical bit for bit (tests: RL_POLICY_VARIANT=dense against =wave).
+// 32-row tile pulls the brain's 263 KB through its CU's vector L1.  In k_policy_dense a workgroup of 4 waves = 4 tiles of ONE brain
+// fetches every weight stage ONCE (256 threads x 2 x 16 bytes = 8 KB: two K-chunks of a tile pair, or four K-chunks of a head), parks
+// it in LDS (three stage buffers, one workgroup barrier per stage) and all four waves take their MFMA A operands from there: a
+// quarter of the bytes per row through L2 -> L1; two such workgroups per CU run out of step.  The tile itself (policy_tile1ds, at the
+// end of this file) is the hand-scheduled one-wave tile on those stages.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kStageUnits = 512;     // 16-byte units per stage (8 KB)
 constexpr int kStages = 10 + 8 + 2 + 8 + 2;   // input layer, hidden advantage, head advantage, hidden value, head value
-constexpr int kDenseTiles = 4;       // tiles (waves) per workgroup: two such workgroups per CU run out of step and fill each other's VALU / MFMA phases
-constexpr int kDenseLoads = kStageUnits / (64 * kDenseTiles);   // 16-byte loads per thread and stage
-struct WStage {
-    f32x4* buf;       // LDS: 3 x kStageUnits
-    gf32x4* src;      // the brain's packed weights in 16-byte units, + thread index
-    f32x4 q[2][kDenseLoads];   // stages in flight to LDS
-    int tid, lane;
-    static __device__ inline int64_t off(const Layout& L, int I)   // 16-byte units
-    {
-        const int64_t f = I < 10 ? L.l1 + (int64_t)I * 2048 : I < 18 ? L.l2a + (int64_t)(I - 10) * 2048 : I < 20 ? L.ha + (int64_t)(I - 18) * 2048
-                        : I < 28 ? L.l2b + (int64_t)(I - 20) * 2048 : L.hb + (int64_t)(I - 28) * 2048;
-        return f / 4;
-    }
-    __device__ inline void load(const Layout& L, int I, f32x4 (&dst)[kDenseLoads])
-    {
-#pragma unroll
-        for (int u = 0; u < kDenseLoads; ++u) dst[u] = src[off(L, I) + u * 64 * kDenseTiles];
-    }
-    __device__ inline void put(int I, const f32x4 (&v)[kDenseLoads])
-    {
-#pragma unroll
-        for (int u = 0; u < kDenseLoads; ++u) buf[(I % 3) * kStageUnits + u * 64 * kDenseTiles + tid] = v[u];
-    }
-    __device__ inline void start(const Layout& L)
-    {
-        f32x4 s0[kDenseLoads], s1[kDenseLoads];
-        load(L, 0, s0);
-        load(L, 1, s1);
-        load(L, 2, q[0]);
-        load(L, 3, q[1]);
-        put(0, s0);
-        put(1, s1);
-        lds_barrier();
-    }
-    // Stage I: stage I + 2 is written to LDS from its registers (requested two stages ago), stage I + 4 is requested into the registers
-    // that just became free, and ONE barrier publishes stage I + 2 -- so that the fragments of stage I + 1 (published a stage ago) can be
-    // read while the MFMAs of stage I run.  Three buffers, and ONE RULE for the readers: stage J is read into registers before the
-    // wave meets stage J's barrier (begin(J)); behind that barrier a faster wave's begin(J + 1) overwrites stage J's buffer.
-    __device__ inline void begin(const Layout& L, int I)
-    {
-        if (I + 2 < kStages) put(I + 2, q[I & 1]);
-        if (I + 4 < kStages) load(L, I + 4, q[I & 1]);
-        lds_barrier();
-    }
-    __device__ inline f32x4 frag(int I, int unit) const { return buf[(I % 3) * kStageUnits + unit * 64 + lane]; }
-};
-
-template <int S0, int NS>
-__device__ inline void k_loop_stage(WStage& ws, const Layout& L, const f32x4 (&B)[NS][kPlanes], f32x16 (&acc)[4])
-{
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    f32x4 ac[2][4][kPlanes];   // this stage's fragments, and the next stage's on their way out of LDS
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int pl = 0; pl < kPlanes; ++pl) ac[0][t][pl] = ws.frag(S0, t * kPlanes + pl);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        ws.begin(L, S0 + s);
-        if (s + 1 < NS) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int pl = 0; pl < kPlanes; ++pl) ac[(s + 1) & 1][t][pl] = ws.frag(S0 + s + 1, t * kPlanes + pl);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = mfma16(ac[s & 1][t][0], B[s][1], acc[t]);  // hi.lo
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = mfma16(ac[s & 1][t][0], B[s][0], acc[t]);  // hi.hi
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = mfma16(ac[s & 1][t][1], B[s][0], acc[t]);  // lo.hi
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-template <int S0>
-__device__ inline void head_stage(WStage& ws, const Layout& L, gfloat* __restrict__ hw, const f32x4 (&B)[8][kPlanes], float row_un, int lane, float (&out)[4])
-{
-    const f32x4 un4 = ((gf32x4*)(hw + head_consts_off(4)))[lane >> 5];
-    f32x16 a0, a1, a2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; a2[r] = 0.0f; }
-#pragma unroll
-    for (int hs = 0; hs < 2; ++hs) {   // a head = two stages of four K-chunks
-        // A stage must be out of LDS BEFORE the wave meets that stage's barrier: behind it the faster waves refill the buffer (begin()).
-        f32x4 fr[4][kPlanes];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int pl = 0; pl < kPlanes; ++pl) fr[c][pl] = ws.frag(S0 + hs, c * kPlanes + pl);
-        ws.begin(L, S0 + hs);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int s = 4 * hs + c;
-            a0 = mfma16(fr[c][0], B[s][1], a0);
-            a1 = mfma16(fr[c][0], B[s][0], a1);
-            a2 = mfma16(fr[c][1], B[s][0], a2);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) out[r] = ((a0[r] + a1[r]) + a2[r]) * (un4[r] * row_un);
-}
-
-// One wave's tile inside the 8-tile workgroup.  EVERY wave of the workgroup must call it (the stage barriers); a wave without rows
-// passes io.valid == false in all lanes and a readable row.
-template <int KIND>
-__device__ inline void policy_tile1d(const TileIO& io, int lane, WStage& ws)
-{
-    static_assert(KIND == RL_D3QN || KIND == RL_PERD3QN, "dense tile: dueling kinds");
-    const int h = lane >> 5;
-    const Layout L = layout_of(KIND);
-    gfloat* __restrict__ packed = io.packed;
-    ws.start(L);
-    f32x4 B1[kInChunks][kPlanes];
-    {
-        const int64_t rbase = io.row * RL_OBS_DIM;
-#pragma unroll
-        for (int c = 0; c < kInChunks; ++c)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int k0 = (c == kInChunks - 1 && h == 1) ? 149 : 16 * c + 8 * h + 4 * q;   // (see policy_tile1)
-                B1[c][q] = *(const f32x4u*)(io.obs + rbase + k0);
-            }
-    }
-    rl_u4 draw = {0u, 0u, 0u, 0u};
-    if (io.actions && io.eps > 0.0f) draw = rl_philox4x32(io.seed, io.key_epoch, io.key_world, io.key_tick, RL_SITE_ACT, io.key_index);
-    if (h == 1) { B1[kInChunks - 1][0] = f32x4{B1[kInChunks - 1][0].w, 0.0f, 0.0f, 0.0f}; B1[kInChunks - 1][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-    float m = 0.0f;
-#pragma unroll
-    for (int c = 0; c < kInChunks; ++c)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-            m = fmaxf(m, fmaxf(fmaxf(fabsf(B1[c][q].x), fabsf(B1[c][q].y)), fmaxf(fabsf(B1[c][q].z), fabsf(B1[c][q].w))));
-    m = fmaxf(m, __shfl_xor(m, 32));
-    float sc0, un0;
-    row_scale(m, sc0, un0);
-#pragma unroll
-    for (int c = 0; c < kInChunks; ++c) {
-        const float x[8] = {B1[c][0].x, B1[c][0].y, B1[c][0].z, B1[c][0].w, B1[c][1].x, B1[c][1].y, B1[c][1].z, B1[c][1].w};
-        split8(x, sc0, B1[c][0], B1[c][1]);
-    }
-    f32x16 acc[4];
-    k_loop_stage<0, kInChunks>(ws, L, B1, acc);
-    f32x4 B2[8][kPlanes], B3[8][kPlanes];
-    float un1, un2;
-    layer_out_to_B(acc, packed + L.l1 + frag_floats(kInChunks, 4), h, un0, B2, un1);
-    k_loop_stage<10, 8>(ws, L, B2, acc);
-    layer_out_to_B(acc, packed + L.l2a + frag_floats(8, 4), h, un1, B3, un2);
-    float adv[4], val[4];
-    head_stage<18>(ws, L, packed + L.ha, B3, un2, lane, adv);
-    k_loop_stage<20, 8>(ws, L, B2, acc);
-    layer_out_to_B(acc, packed + L.l2b + frag_floats(8, 4), h, un1, B3, un2);
-    head_stage<28>(ws, L, packed + L.hb, B3, un2, lane, val);
-    const f32x4 ba = ((gf32x4*)(packed + L.ha + head_consts_off(4) + 8))[h];
-    tile1_finish<KIND>(io, lane, adv, val[0] + packed[L.hb + head_consts_off(4) + 8], draw, ba);
-}
+constexpr int kDenseTiles = 4;       // tiles (waves) per workgroup
 
 // ---------------------------------------------------------------------------------------------------------------
 // The one-wave tile, SCHEDULED BY HAND (the multi-tick kernel's policy half is ONE tile's dependency chain).
@@ -1151,8 +992,8 @@ __device__ inline void split_slice(int k, Raw&& raw, float sc, f32x4& hi, f32x4&
 }
 
 // One pass of a layer: K loop over NS chunks for output tiles 2 * HALF, +1.  shadow(slot), slot = 0 .. 6 * NS - 1, follows MFMA `slot`.
-template <int NS, int D, int HALF, int STEPS, typename Shadow>
-__device__ inline void k_pass(WRingH<NS, D, STEPS>& w, const f32x4 (&B)[NS][kPlanes], f32x16& a0, f32x16& a1, Shadow&& shadow)
+template <int NS, int HALF, typename Ring, typename Shadow>   // Ring: take(step, fragments) -- WRingH (registers) or WStageH (LDS stages)
+__device__ inline void k_pass(Ring& w, const f32x4 (&B)[NS][kPlanes], f32x16& a0, f32x16& a1, Shadow&& shadow)
 {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; }
@@ -1307,7 +1148,7 @@ __device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, c
     // ---- input layer
     f32x16 F[4];
     EpiStream ep;
-    k_pass<kInChunks, D, 0>(w1, B1, F[0], F[1], [&](int slot) {
+    k_pass<kInChunks, 0>(w1, B1, F[0], F[1], [&](int slot) {
         const int c = slot / 6 + 1;
         if (c < kInChunks) split_slice<6>(slot % 6, [&](int e) { return xraw(c, e); }, sc0, B1[c][0], B1[c][1]);
     });
@@ -1343,7 +1184,7 @@ __device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, c
             for (int pl = 0; pl < kPlanes; ++pl) B2[c][pl] = pair_lds->ex[(c * kPlanes + pl) * 64 + lane];
     } else {
         ep.c = consts;
-        k_pass<kInChunks, D, 1>(w1, B1, F[2], F[3], [&](int slot) {
+        k_pass<kInChunks, 1>(w1, B1, F[2], F[3], [&](int slot) {
             if (slot == 0) ep.fetch(0, 0);
             if (slot >= 2 && slot < 34) ep.step(0, slot - 2, F[0], F[1], un0, mrow);
         });
@@ -1361,13 +1202,13 @@ __device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, c
     RL_PMARK1(4);
     // ---- advantage branch
     f32x16 A[4];
-    k_pass<8, D, 0>(w2, B2, A[0], A[1], [&](int slot) {
+    k_pass<8, 0>(w2, B2, A[0], A[1], [&](int slot) {
         const int c = slot / 6 + 1;
         if (!PAIR && c < 8) split_slice<6>(slot % 6, [&](int e) { return fraw(c, e); }, sc1, B2[c][0], B2[c][1]);
     });
     mrow = 0.0f;
     ep.c = consts + ((PAIR && role) ? 512 : 256);
-    k_pass<8, D, 1>(w2, B2, A[2], A[3], [&](int slot) {
+    k_pass<8, 1>(w2, B2, A[2], A[3], [&](int slot) {
         if (slot == 0) ep.fetch(0, 0);
         if (slot >= 2 && slot < 34) ep.step(0, slot - 2, A[0], A[1], un1, mrow);
     });
@@ -1399,10 +1240,10 @@ __device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, c
     w3.start(packed + L.l2b, lane);
     RL_PMARK1(7);
     // ---- value branch
-    k_pass<8, D, 0>(w3, B2, A[0], A[1], [&](int) {});
+    k_pass<8, 0>(w3, B2, A[0], A[1], [&](int) {});
     mrow = 0.0f;
     ep.c = consts + 512;
-    k_pass<8, D, 1>(w3, B2, A[2], A[3], [&](int slot) {
+    k_pass<8, 1>(w3, B2, A[2], A[3], [&](int slot) {
         if (slot == 0) ep.fetch(0, 0);
         if (slot >= 2 && slot < 34) ep.step(0, slot - 2, A[0], A[1], un1, mrow);
     });
@@ -1415,6 +1256,223 @@ __device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, c
     row_scale(mrow, sc2, un2);
     head_stream<D>(wh, *(const f32x4*)(hconsts + 16 + 4 * h), araw, sc2, un2, val);
     RL_PMARK1(9);
+    tile1_finish<KIND>(io, lane, adv, val[0] + hconsts[16 + 8], draw, *(const f32x4*)(hconsts + 8 + 4 * h));
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The dense tile: the weights through LDS stages AND the tile scheduled around the matrix pipe (as policy_tile1s: two passes per layer
+// over output-tile pairs, the VALU work in the MFMAs' shadows).  A first version ran policy_tile1's phases on 8 KB stages of whole
+// K-chunks (10,880 tiles: 157 us against 177-188 for the register-fed tiles); this one 148 us.  With the weight bytes out of the way the
+// launch is bound by each wave's own chain and its 30 stage barriers (a lone 4-tile workgroup: 18 us).  A stage is 8 KB = two K-chunks of
+// one tile pair (or four K-chunks of a head).  Same arithmetic per accumulator as every one-wave tile: bit-identical results.
+// ---------------------------------------------------------------------------------------------------------------
+struct WStage2 {
+    f32x4* buf;       // LDS: 3 x kStageUnits
+    gf32x4* src;      // the brain's packed weights in 16-byte units, + thread index (256 threads)
+    f32x4 q[2][2];    // two stages in flight to LDS, two 4 KB blocks each
+    int tid, lane;
+    // source of block u (0, 1) of stage I: layers -- chunks c0 + u of tile pair h (4 KB each); heads -- the stage's two halves
+    static __device__ inline int64_t off(const Layout& L, int I, int u)   // 16-byte units
+    {
+        if (I >= 18 && I < 20) return (L.ha + (int64_t)(I - 18) * 2048) / 4 + u * 256;
+        if (I >= 28) return (L.hb + (int64_t)(I - 28) * 2048) / 4 + u * 256;
+        const int64_t base = (I < 10 ? L.l1 : I < 18 ? L.l2a : L.l2b) / 4;
+        const int jl = I < 10 ? I : I < 18 ? I - 10 : I - 20, per_pass = I < 10 ? kInChunks / 2 : 4;
+        const int h = jl / per_pass, c0 = 2 * (jl % per_pass);
+        return base + (int64_t)(c0 + u) * 512 + 256 * h;
+    }
+    __device__ inline void load(const Layout& L, int I, f32x4 (&dst)[2]) { dst[0] = src[off(L, I, 0)]; dst[1] = src[off(L, I, 1)]; }
+    __device__ inline void put(int I, const f32x4 (&v)[2]) { buf[(I % 3) * kStageUnits + tid] = v[0]; buf[(I % 3) * kStageUnits + 256 + tid] = v[1]; }
+    __device__ inline void start(const Layout& L)
+    {
+        f32x4 s0[2], s1[2];
+        load(L, 0, s0); load(L, 1, s1); load(L, 2, q[0]); load(L, 3, q[1]);
+        put(0, s0); put(1, s1);
+        lds_barrier();
+    }
+    // Stage I: stage I + 2 is written to LDS from its registers (requested two stages ago), stage I + 4 is requested into the registers
+    // that just became free, and ONE barrier publishes stage I + 2 -- so that the fragments of stage I + 1 (published a stage ago) can be
+    // read while the MFMAs of stage I run.  Three buffers, and ONE RULE for the readers: stage J is read into registers before the
+    // wave meets stage J's barrier (begin(J)); behind that barrier a faster wave's begin(J + 1) overwrites stage J's buffer.
+    __device__ inline void begin(const Layout& L, int I)
+    {
+        if (I + 2 < kStages) put(I + 2, q[I & 1]);
+        if (I + 4 < kStages) load(L, I + 4, q[I & 1]);
+        lds_barrier();
+    }
+    __device__ inline f32x4 frag(int I, int unit) const { return buf[(I % 3) * kStageUnits + unit * 64 + lane]; }
+};
+// The stages of one layer seen as the weight ring of k_pass: step i (chunk i % NS of tile pair i / NS) = half (i & 1) of stage S0 + (i >> 1).
+template <int NS, int S0>
+struct WStageH {
+    WStage2& ws;
+    const Layout& L;
+    f32x4 fr[2][8];   // the current stage's fragments and the next stage's on their way out of LDS
+    __device__ inline WStageH(WStage2& w, const Layout& l) : ws(w), L(l) {}
+    __device__ inline void read(int jl, f32x4 (&dst)[8])
+    {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[k] = ws.frag(S0 + jl, k);
+    }
+    __device__ inline void take(int i, f32x4 (&ac)[2][kPlanes])
+    {
+        const int jl = i >> 1;
+        if ((i & 1) == 0) {
+            if (i == 0) read(0, fr[0]);                  // (published two stages ago)
+            ws.begin(L, S0 + jl);
+            if (jl + 1 < NS) read(jl + 1, fr[(jl + 1) & 1]);   // before the wave meets stage jl + 1's barrier
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pl = 0; pl < kPlanes; ++pl) ac[t][pl] = fr[jl & 1][(i & 1) * 4 + t * kPlanes + pl];
+    }
+};
+// head over two stages of four K-chunks, its input split chunk by chunk ahead of the MFMAs that use it (head_stream on stages)
+template <int S0, typename Raw>
+__device__ inline void head_stream_stage(WStage2& ws, const Layout& L, const f32x4& un4, Raw&& raw, float sc, float row_un, float (&out)[4])
+{
+    f32x16 a0, a1, a2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; a2[r] = 0.0f; }
+    f32x4 B[8][kPlanes];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) split_slice<3>(k, [&](int e) { return raw(0, e); }, sc, B[0][0], B[0][1]);
+#pragma unroll
+    for (int hs = 0; hs < 2; ++hs) {
+        f32x4 fr[4][kPlanes];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int pl = 0; pl < kPlanes; ++pl) fr[c][pl] = ws.frag(S0 + hs, c * kPlanes + pl);
+        ws.begin(L, S0 + hs);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int s = 4 * hs + c;
+            a0 = mfma16(fr[c][0], B[s][1], a0);
+            if (s + 1 < 8) split_slice<3>(0, [&](int e) { return raw(s + 1, e); }, sc, B[(s + 1) & 7][0], B[(s + 1) & 7][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            a1 = mfma16(fr[c][0], B[s][0], a1);
+            if (s + 1 < 8) split_slice<3>(1, [&](int e) { return raw(s + 1, e); }, sc, B[(s + 1) & 7][0], B[(s + 1) & 7][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            a2 = mfma16(fr[c][1], B[s][0], a2);
+            if (s + 1 < 8) split_slice<3>(2, [&](int e) { return raw(s + 1, e); }, sc, B[(s + 1) & 7][0], B[(s + 1) & 7][1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = ((a0[r] + a1[r]) + a2[r]) * (un4[r] * row_un);
+}
+
+// One wave's tile inside the 4-tile workgroup (every wave must call it: the stage barriers).  lds_consts: the brain's
+// kTileConstFloats epilogue / head constants (LDS, filled by the caller before ws.start()).
+template <int KIND>
+__device__ inline void policy_tile1ds(const TileIO& io, int lane, WStage2& ws, const float* lds_consts)
+{
+    static_assert(KIND == RL_D3QN || KIND == RL_PERD3QN, "dense tile: dueling kinds");
+    const int h = lane >> 5;
+    const Layout L = layout_of(KIND);
+    const float* const consts = lds_consts + 32 * h;
+    const float* const hconsts = lds_consts + 768;
+    ws.start(L);
+    f32x4 X[kInChunks][2];
+    {
+        const int64_t rbase = io.row * RL_OBS_DIM;
+#pragma unroll
+        for (int c = 0; c < kInChunks; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k0 = (c == kInChunks - 1 && h == 1) ? 149 : 16 * c + 8 * h + 4 * q;   // (see policy_tile1)
+                X[c][q] = *(const f32x4u*)(io.obs + rbase + k0);
+            }
+    }
+    rl_u4 draw = {0u, 0u, 0u, 0u};
+    if (io.actions && io.eps > 0.0f) draw = rl_philox4x32(io.seed, io.key_epoch, io.key_world, io.key_tick, RL_SITE_ACT, io.key_index);
+    if (h == 1) { X[kInChunks - 1][0] = f32x4{X[kInChunks - 1][0].w, 0.0f, 0.0f, 0.0f}; X[kInChunks - 1][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    float m4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < kInChunks; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            max3_abs(m4[(2 * c + q) & 3], X[c][q].x, X[c][q].y);
+            max3_abs(m4[(2 * c + q + 2) & 3], X[c][q].z, X[c][q].w);
+        }
+    float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sc0, un0;
+    row_scale(m, sc0, un0);
+    f32x4 B1[kInChunks][kPlanes];
+    auto xraw = [&](int c, int e) { return X[c][e >> 2][e & 3]; };
+#pragma unroll
+    for (int k = 0; k < 6; ++k) split_slice<6>(k, [&](int e) { return xraw(0, e); }, sc0, B1[0][0], B1[0][1]);
+    // ---- input layer
+    f32x16 F[4];
+    EpiStream ep;
+    float mrow = 0.0f;
+    {
+        WStageH<kInChunks, 0> w1(ws, L);
+        k_pass<kInChunks, 0>(w1, B1, F[0], F[1], [&](int slot) {
+            const int c = slot / 6 + 1;
+            if (c < kInChunks) split_slice<6>(slot % 6, [&](int e) { return xraw(c, e); }, sc0, B1[c][0], B1[c][1]);
+        });
+        ep.c = consts;
+        k_pass<kInChunks, 1>(w1, B1, F[2], F[3], [&](int slot) {
+            if (slot == 0) ep.fetch(0, 0);
+            if (slot >= 2 && slot < 34) ep.step(0, slot - 2, F[0], F[1], un0, mrow);
+        });
+    }
+    ep.fetch(2, 0);
+#pragma unroll
+    for (int e = 0; e < 32; ++e) ep.step(2, e, F[2], F[3], un0, mrow);
+    mrow = fmaxf(mrow, __shfl_xor(mrow, 32));
+    float sc1, un1;
+    row_scale(mrow, sc1, un1);
+    f32x4 B2[8][kPlanes];
+    auto fraw = [&](int c, int e) { return F[c >> 1][8 * (c & 1) + e]; };
+#pragma unroll
+    for (int k = 0; k < 6; ++k) split_slice<6>(k, [&](int e) { return fraw(0, e); }, sc1, B2[0][0], B2[0][1]);
+    // ---- advantage branch
+    f32x16 A[4];
+    {
+        WStageH<8, 10> w2(ws, L);
+        k_pass<8, 0>(w2, B2, A[0], A[1], [&](int slot) {
+            const int c = slot / 6 + 1;
+            if (c < 8) split_slice<6>(slot % 6, [&](int e) { return fraw(c, e); }, sc1, B2[c][0], B2[c][1]);
+        });
+        mrow = 0.0f;
+        ep.c = consts + 256;
+        k_pass<8, 1>(w2, B2, A[2], A[3], [&](int slot) {
+            if (slot == 0) ep.fetch(0, 0);
+            if (slot >= 2 && slot < 34) ep.step(0, slot - 2, A[0], A[1], un1, mrow);
+        });
+    }
+    ep.fetch(2, 0);
+#pragma unroll
+    for (int e = 0; e < 32; ++e) ep.step(2, e, A[2], A[3], un1, mrow);
+    mrow = fmaxf(mrow, __shfl_xor(mrow, 32));
+    float sc2, un2;
+    row_scale(mrow, sc2, un2);
+    auto araw = [&](int c, int e) { return A[c >> 1][8 * (c & 1) + e]; };
+    float adv[4], val[4];
+    head_stream_stage<18>(ws, L, *(const f32x4*)(hconsts + 4 * h), araw, sc2, un2, adv);
+    // ---- value branch
+    {
+        WStageH<8, 20> w3(ws, L);
+        k_pass<8, 0>(w3, B2, A[0], A[1], [&](int) {});
+        mrow = 0.0f;
+        ep.c = consts + 512;
+        k_pass<8, 1>(w3, B2, A[2], A[3], [&](int slot) {
+            if (slot == 0) ep.fetch(0, 0);
+            if (slot >= 2 && slot < 34) ep.step(0, slot - 2, A[0], A[1], un1, mrow);
+        });
+    }
+    ep.fetch(2, 0);
+#pragma unroll
+    for (int e = 0; e < 32; ++e) ep.step(2, e, A[2], A[3], un1, mrow);
+    mrow = fmaxf(mrow, __shfl_xor(mrow, 32));
+    row_scale(mrow, sc2, un2);
+    head_stream_stage<28>(ws, L, *(const f32x4*)(hconsts + 16 + 4 * h), araw, sc2, un2, val);
     tile1_finish<KIND>(io, lane, adv, val[0] + hconsts[16 + 8], draw, *(const f32x4*)(hconsts + 8 + 4 * h));
 }
 
