@@ -97,7 +97,7 @@ def one_step(dw):
     dw.tick_refill(70, 100)     # k_world<TICK>: step + update_env (+ re-generation of worlds below 70 agents)
 
 
-FUSED_CHUNK = 500   # ticks per rl_run launch (a launch of 500 ticks lasts ~15 ms)
+FUSED_CHUNK = 2000  # ticks per rl_run launch (a launch of 2000 ticks lasts ~50 ms; each launch costs ~40 us of start-up)
 
 
 def run_ticks(dw, n, fused):
