@@ -2420,7 +2420,19 @@ __device__ __forceinline__ void run_load_call(RunParamsC* ka)   // (inlined: loa
     run_carve<FIXED, KIND>(p, s, ps, smem_raw, T);
     int n0;
     load_world<T, (T == 1024)>(p, s, (int)blockIdx.x, n0);
-    if (rl_tidx() == 0) { ps.meta[1] = n0; ps.meta[2] = *(cint*)&ka->ra.first; ps.meta[3] = 0; ps.meta[4] = 0; }
+    // The first tick's policy input: rows written by the previous launch (or the reset / observe call).  With the mirror they are copied
+    // into LDS here, by the whole workgroup with coalesced loads, instead of being fetched row by row by the tile waves (the row phase of
+    // a launch's first tick: 12.2k cycles against 3.5k from the mirror).
+    const int first = *(cint*)&ka->ra.first;
+    const bool preload = ps.xmirror != nullptr && n0 <= ps.xrows;
+    if (preload) {
+        const float* rows = ((float* const __attribute__((address_space(4)))*)ka->ra.obs)[first] + (size_t)blockIdx.x * p.cap * RL_OBS_DIM;
+        for (int i = rl_tidx(); i < n0 * RL_OBS_DIM; i += T) {
+            const int r = i / RL_OBS_DIM;
+            ps.xmirror[r * kXStride + (i - r * RL_OBS_DIM)] = rows[i];
+        }
+    }
+    if (rl_tidx() == 0) { ps.meta[1] = n0; ps.meta[2] = first; ps.meta[3] = 0; ps.meta[4] = preload ? 1 : 0; }
     if (T <= 512 && rl_tidx() < 64) policy_lists_wave0(p, ps, n0, rl_tidx(), [&](int k) { return s.brain[k]; });   // (slot == list index after load_world)
     if (ps.cconst) {   // the brains' epilogue constants (three 128-wide layers x 256 floats) for policy_tile1s
         const Layout L = layout_of(KIND);
