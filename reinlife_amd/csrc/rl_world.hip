@@ -1056,8 +1056,15 @@ __device__ __forceinline__ void reproduce_wave0(const KParams& p, Smem& s, int w
         const int k = base + lane;
         const bool act = k < n1;
         const int a = act ? s.order[k] : 0;
-        const int fl = s.flags[a], age = s.age[a], ge = s.gene[a];  // one batch (slot 0 is always valid)
+        const int fl = s.flags[a], age = s.age[a], ge = s.gene[a], ps_ = s.pos[a];  // one batch (slot 0 is always valid)
         const bool e = act && room && !(fl & (RL_F_DEAD | RL_F_REPRODUCED)) && age > 5;  // can_reproduce, entities.py:244
+        // _remove_dead_agents (environment.py:795-799) rides in the same pass: corpses become Food.  The reference does it after the
+        // placements, which must still see the corpses' cells as occupied -- they do: the placements below work on the occupancy BITMAP
+        // taken before this pass, and nothing else in this function reads type[] / occ[] of a corpse's cell.
+        if (act && (fl & RL_F_DEAD)) {
+            const int cell = (ps_ & 255) * p.W + (ps_ >> 8);
+            s.type[cell] = RL_FOOD; s.occ[cell] = -1;
+        }
         if (act && p.static_families && ge >= 0 && ge < RL_MAX_BRAINS) s.present[ge] = 1;
         const unsigned long long em = __ballot(e);
         bool par = false;
@@ -1206,16 +1213,6 @@ __device__ __forceinline__ void reproduce_wave0(const KParams& p, Smem& s, int w
     if (tid == 0) {
         s.scal[S_NSLOTS] = slots; s.scal[S_NEXT_UID] = next_uid; s.scal[S_MAX_GENE] = max_gene;
         p.st.next_uid[w] = next_uid; p.st.max_gene[w] = max_gene;
-    }
-    // _remove_dead_agents (environment.py:795-799): corpses become Food -- after the placements, which must still
-    // see their cells as occupied; same wave, so no barrier in between
-    for (int k = lane; k < n1; k += 64) {
-        const int a = s.order[k];
-        const int fl = s.flags[a], ps = s.pos[a];  // one batch
-        if (fl & RL_F_DEAD) {
-            const int cell = (ps & 255) * p.W + (ps >> 8);
-            s.type[cell] = RL_FOOD; s.occ[cell] = -1;
-        }
     }
 }
 
