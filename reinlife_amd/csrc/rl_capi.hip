@@ -59,7 +59,7 @@ void rl_set_error(const char* fmt, ...)
 extern "C" {
 
 const char* rl_last_error(void) { return g_err; }
-const char* rl_version(void) { return "reinlife_hip 0.1 (gfx950)"; }
+const char* rl_version(void) { return "reinlife_hip 0.2 (gfx950)"; }
 
 int rl_create(const rl_config* cfg, rl_world** out)
 {
