@@ -157,6 +157,52 @@ def cpu_baseline(args):
                          cores=max(1, min(os.cpu_count() or 1, 64)))
 
 
+def api_trainer(args, device):
+    """The same loop through the reference's API surface (Helpers/trainer.py:7-107): trainer(brains, n_episodes=K, n_worlds=...,
+    save=False, print_results=False) with the reference's default training=True -- the brains' epsilon decays per episode and the
+    Tracker closes an interval every 500 episodes -- on the benchmark's synthetic worlds (100 agents per world, re-generated below
+    70: the keyword-only extras synthetic_agents / refill_below).  Wall-clocked around the loop inside trainer() (env.loop_seconds:
+    construction of the Environment and the reset launch are set-up, like the untimed set-up of the main line); agent-steps from the
+    device counter."""
+    import warnings
+    from reinlife_amd import Models
+    from reinlife_amd.Helpers.trainer import trainer
+    wl = WORKLOADS[args.workload]
+    cls = {"DQN": Models.DQN, "D3QN": Models.D3QN, "PERD3QN": Models.PERD3QN, "PPO": Models.PPO}
+
+    def brains():
+        out = []
+        for k, n in enumerate(wl["brains"]):
+            b = cls[n](max_epi=10_000) if n == "DQN" else cls[n]()
+            flat, o = torch.from_numpy(brain_weights(n, 100 + k)), 0
+            sd = b._net().state_dict()
+            for key, v in sd.items():   # the same random-init weights as the main line, through load_state_dict
+                sd[key] = flat[o:o + v.numel()].reshape(v.shape).clone(); o += v.numel()
+            b._net().load_state_dict(sd)
+            out.append(b)
+        return out
+
+    def one(k):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            env = trainer(brains(), n_episodes=k, n_worlds=args.worlds, save=False, print_results=False, static_families=wl["static_families"],
+                          device=device, seed=args.seed, synthetic_agents=100, refill_below=70)
+        steps = int(env.worlds.acted_total.item())
+        env.worlds.check_error_flag()
+        return steps, env.loop_seconds, env
+    one(20)                                    # warm-up: library, packed weights, first launches
+    k_long = max(2000, args.steps)
+    s_long, t_long, env = one(k_long)
+    s_win, t_win, _ = one(args.steps)          # the same window as the main line's --steps
+    return {"value": round(s_long / t_long, 1), "unit": "agent-steps/s", "episodes": k_long + 1, "us_per_tick": round(t_long / (k_long + 1) * 1e6, 2),
+            "launches": 1 + k_long // 500, "tracker_intervals_closed": len(env.tracker.results["Avg Number of Populations"]),
+            "final_epsilon": [round(float(getattr(b, "epsilon", 0.0)), 4) for b in env.brains],
+            "value_at_steps": round(s_win / t_win, 1), "steps_window": args.steps + 1, "window_ms": round(t_win * 1e3, 4),
+            "call": "trainer(brains, n_episodes=K, n_worlds=%d, save=False, print_results=False, synthetic_agents=100, refill_below=70) "
+                    "[training=True, update_interval=500: the reference's defaults]" % args.worlds,
+            "timed": "the loop inside trainer() (env.loop_seconds), device idle before and after; agent-steps from the device counter"}
+
+
 def respawn_under_torchrun(args):
     """`python bench.py --gpus N` with N > 1 and no torchrun environment: run N ranks of this script, one per GPU."""
     n_vis = torch.cuda.device_count()
@@ -188,6 +234,7 @@ def main():
                     help="fused = one multi-tick launch (rl_run); two-launch = rl_policy_act + rl_tick_refill per tick")
     ap.add_argument("--burnin", type=int, default=300, help="untimed set-up ticks that de-synchronise the worlds' cohorts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api-trainer", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
@@ -262,21 +309,23 @@ def main():
     elapsed = time.perf_counter() - t0
     (grp or dw).check_error_flag()
 
-    # the only collective of the job: one RCCL all-reduce of the metric counters over xGMI (reinlife_amd/distributed.py)
+    # the only collective of the job: ONE RCCL all-gather of every rank's [agent-steps, refills, elapsed] row over xGMI
+    # (reinlife_amd/distributed.py); executed whenever a process group exists, also with one rank
     counted = grp.counters() if grp else (float(dw.acted_total.item()), float(dw.refill_count.item()))
     stats = torch.tensor(counted, dtype=torch.float64, device=device)
-    stats, elapsed = reduce_counters(stats, elapsed, dist)
+    stats, elapsed, rank_table = reduce_counters(stats, elapsed, dist)
     total_agent_steps, refills = stats.tolist()
+    rank_rates = (rank_table[:, 0] / rank_table[:, 2]).tolist()   # each rank's own agent-steps/s over its own clock: stragglers show here
 
     # ---- per-kernel durations with HIP events on the launch stream (untimed extra steps) ------------------------------
     roofline, extra = None, {}
     fused_roof = None
     if rank == 0 and not args.no_kernel_timing and fused:
-        # the multi-tick launch, HIP events around launches of N ticks; then its two halves alone (RL_RUN_DEBUG: the library
+        # the multi-tick launch, HIP events around launches of N ticks; then its two halves alone (rl_debug_set_run_mask: the library
         # skips one half of every tick -- results are then wrong, the work of the remaining half is the same)
         def timed_run(n, debug=None):
             if debug:
-                os.environ["RL_RUN_DEBUG"] = debug
+                _lib.lib().rl_debug_set_run_mask(int(debug))   # explicit measurement switch of THIS process (never an environment variable)
             try:
                 dw.run(20, 70, 100)
                 before = int(dw.acted_total.item())
@@ -285,7 +334,7 @@ def main():
                 torch.cuda.synchronize()
                 return e0.elapsed_time(e1) * 1e-3 / n, (int(dw.acted_total.item()) - before) / n
             finally:
-                os.environ.pop("RL_RUN_DEBUG", None)
+                _lib.lib().rl_debug_set_run_mask(0)
         t_all, per_tick = timed_run(300)
         wl = WORKLOADS[args.workload]
         flop = float(np.mean([POLICY_FLOP_PER_AGENT[n] for n in wl["brains"]]))
@@ -296,10 +345,17 @@ def main():
                       "avg_tick_us": round(t_all * 1e6, 2), "ticks_per_launch": 300, "agent_steps_per_tick": round(per_tick, 1),
                       "bytes_per_agent_step": by,
                       "mfma_tflops": round(per_tick * flop / t_all / 1e12, 2), "mfma_frac": round(per_tick * flop / t_all / 1e12 / MFMA_F32_EQUIV_PEAK_TFLOPS, 5)}
+        # PMC bytes need rocprofv3 (tools/pmc_traffic.sh), so they come from a tracked file -- stamped with the hash of the kernel
+        # sources they were measured on: when the sources have changed since, the figure is dropped, not silently carried along
         tpath = os.path.join(ROOT, "profiles", "run_traffic.json")
         if os.path.exists(tpath) and args.worlds == 256 and args.workload == "c4":
             try:
-                fused_roof["traffic"] = json.load(open(tpath)).get("hbm_bytes_per_tick")
+                tj = json.load(open(tpath))
+                from reinlife_amd import build as _build
+                now = _build.source_hash()
+                fused_roof["traffic"] = tj.get("hbm_bytes_per_tick") if tj.get("kernel_src_sha16") == now else None
+                fused_roof["traffic_source"] = {"file": "profiles/run_traffic.json", "measured_on_kernel_src_sha16": tj.get("kernel_src_sha16"),
+                                                "current_kernel_src_sha16": now}
             except Exception:  # noqa: BLE001
                 pass
         dw_state = {k: v.clone() for k, v in dw.s.items()}   # the half-runs leave wrong worlds behind: restore afterwards
@@ -316,14 +372,14 @@ def main():
             o.copy_(keep)
         fused_roof["tick_half"] = {"us_per_tick": round(t_tick_half * 1e6, 2), "hbm_GBs": round(n_tick_half * TICK_BYTES_PER_AGENT_STEP / t_tick_half / 1e9, 1),
                                    "hbm_frac": round(n_tick_half * TICK_BYTES_PER_AGENT_STEP / t_tick_half / 1e9 / HBM_PEAK_GBS, 4),
-                                   "how": "launches with the policy half skipped (RL_RUN_DEBUG=1)"}
+                                   "how": "launches with the policy half skipped (rl_debug_set_run_mask(1))"}
         # the policy half inside a full tick = the tick minus the tick half alone (the policy alone, with the tick half skipped, reads its
         # rows from memory instead of the LDS mirror the tick half fills, and is slower than in place)
         t_pol_in = max(t_all - t_tick_half, 1e-9)
         fused_roof["policy_half"] = {"us_per_tick": round(t_pol_in * 1e6, 2), "mfma_tflops": round(per_tick * flop / t_pol_in / 1e12, 1),
                                      "mfma_frac": round(per_tick * flop / t_pol_in / 1e12 / MFMA_F32_EQUIV_PEAK_TFLOPS, 4),
                                      "alone_us_per_tick": round(t_pol_half * 1e6, 2),
-                                     "how": "avg_tick_us - tick_half.us_per_tick; alone_us_per_tick = launches with the tick half skipped (RL_RUN_DEBUG=2: rows from memory, not from the LDS mirror)"}
+                                     "how": "avg_tick_us - tick_half.us_per_tick; alone_us_per_tick = launches with the tick half skipped (rl_debug_set_run_mask(2): rows from memory, not from the LDS mirror)"}
     if rank == 0 and not args.no_kernel_timing:
         # (with --groups G the probe runs group 0 alone: its launches cover worlds/G worlds each)
         # back-to-back launches, no host sync inside the probe (a launch from an idle stream costs ~8 us extra): the event
@@ -350,7 +406,9 @@ def main():
         if os.path.exists(tpath) and args.worlds == 256 and args.workload == "c4" and args.groups == 1:
             try:
                 tj = json.load(open(tpath))
-                traffic, pol_traffic = tj.get("hbm_bytes_per_launch"), tj.get("policy_hbm_bytes_per_launch")
+                from reinlife_amd import build as _build
+                if tj.get("kernel_src_sha16") == _build.source_hash():   # (stamped like run_traffic.json)
+                    traffic, pol_traffic = tj.get("hbm_bytes_per_launch"), tj.get("policy_hbm_bytes_per_launch")
             except Exception:  # noqa: BLE001
                 traffic = pol_traffic = None
         tick_roof = {"kernel": "k_world<TICK> (rl_tick_refill)", "bound": "hbm", "achieved": round(tick_gbs, 2), "peak": HBM_PEAK_GBS,
@@ -390,6 +448,10 @@ def main():
                 "what": "rl_policy_act + rl_step (Environment.step, un-fused kernel) between HIP events; update_env + refill run untimed "
                         "between the pairs; 1 GPU (rank 0)"}
 
+    api = None
+    if rank == 0 and args.gpus == 1 and not args.no_api_trainer and args.groups == 1:
+        api = api_trainer(args, device)
+
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
@@ -402,6 +464,9 @@ def main():
             "unit": "agent-steps/s",
             "n_gpus": args.gpus,
             "rccl_ranks": rccl_ranks,
+            "rccl_collectives_executed": 1 if dist is not None else 0,
+            "per_rank": {"value_min": round(min(rank_rates), 1), "value_max": round(max(rank_rates), 1),
+                         "elapsed_ms": [round(float(x) * 1e3, 3) for x in rank_table[:, 2].tolist()]},
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
@@ -417,6 +482,7 @@ def main():
                        "world_refills": int(refills), "agent_steps": int(round(total_agent_steps)), "parallelism": "replica-sharded x%d, no data-path collective" % max(1, world_size)},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "api_trainer": api,
         }
         out.update(extra)
         sys.stdout.flush()

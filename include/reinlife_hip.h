@@ -8,6 +8,7 @@
  *   rl_tick            step() + update_env() of one trainer-loop iteration, fused (Helpers/trainer.py:92,99)
  *   rl_observe         Environment._get_observations()            World/environment.py:313-375
  *   rl_reset_synthetic Environment.reset()-style world generator  World/environment.py:133-158, 741-761
+ *   rl_reset_families  Environment.reset() itself (one agent per brain) World/environment.py:133-158
  *   rl_policy_act      Agent.get_action() over all agents         World/entities.py:215-222 ->
  *                      DQN.py:126-139, D3QN.py:161-173, PERD3QN.py:198-210, PPO.py:101-106,164-169
  *   rl_policy_forward  the bare network forward of one brain on a dense batch of observation rows
@@ -167,6 +168,10 @@ int rl_bind_error_flag(rl_world* h, int32_t* device_flag);
 int rl_bind_phase_profile(rl_world* h, long long* device_stamps, int world);
 
 int rl_reset_synthetic(rl_world* h, int n_agents, float* obs, void* stream);
+/* Environment.reset() for every world (environment.py:133-158): one agent per brain -- gene = brain = its index, each at a
+ * uniformly random cell (:147-149) -- and _init_food's Binomial food / poison counts + one super food (:741-761), from the
+ * Philox streams (epoch as found in the state); obs as in rl_reset_synthetic */
+int rl_reset_families(rl_world* h, float* obs, void* stream);
 /* worlds with n_agents < threshold are re-generated (epoch+1); refill_count: optional device int32 accumulator */
 int rl_refill(rl_world* h, int threshold, int n_agents, float* obs, int32_t* refill_count, void* stream);
 int rl_observe(rl_world* h, float* obs, void* stream);
@@ -192,19 +197,36 @@ int rl_tick_refill(rl_world* h, const int8_t* actions, const rl_step_out* sout, 
  * rl_tick_refill (same Philox streams), and every per-tick output is written every tick, so after the call the buffers hold
  * the LAST tick's values:
  *   actions     [R][cap]      the actions chosen in the last tick (its pre-step list order)
- *   sout        reward / done / src / obs (state_prime) / n_acted / acted_total as in rl_tick (tracker and capture outputs
- *               are not supported here: RL_E_UNSUPPORTED)
+ *   sout        reward / done / src / obs (state_prime) / n_acted / acted_total and the Tracker accumulators as in rl_tick (the
+ *               capture outputs n_post / age / brain are not produced here: RL_E_UNSUPPORTED)
  *   obs[2]      Agent.state ping-pong pair: tick i READS obs[(first_obs + i) & 1] (the policy's input; for i = 0 it must hold
  *               the current Agent.state rows) and WRITES the other one; after the call the current rows are in
  *               obs[(first_obs + n_ticks) & 1] and the rows the policy read for the last tick in the other buffer
  *   update_src  [R][cap] or NULL: rl_update_out.src of the last tick
  *   threshold   < 0: no re-generation; else worlds below `threshold` agents are re-generated with n_agents (rl_refill)
  * Supported (rl_run_supported() != 0): brains all of the dueling kinds (RL_D3QN / RL_PERD3QN), n_brains <= 8, slot_cap <= the
- * workgroup size (1024; 256 when n_worlds > 768).  Otherwise RL_E_UNSUPPORTED: loop over rl_policy_act + rl_tick_refill. */
+ * workgroup size (512 threads; 256 when n_worlds > 768).  Otherwise RL_E_UNSUPPORTED: loop over rl_policy_act + rl_tick_refill. */
+/* rl_run_ex: rl_run with the options a TRAINING loop needs (Helpers/trainer.py:85-99 with training=True):
+ *   eps_schedule  device [n_ticks][n_brains] or NULL: the brains' exploration rate in every tick of the launch -- the reference's brains
+ *                 change epsilon from episode to episode (D3QN.py:84-89 / PERD3QN.py:82-86: x 0.99 per new n_epi; DQN.py:67-69);
+ *                 NULL = brains[b].epsilon throughout
+ *   sout->trk_*   the Tracker accumulators of rl_step_out are maintained every tick (environment.py:206-207 -> tracker.py:107-121):
+ *                 trk_tick holds the last tick's values, trk_sum / trk_cnt / trk_pop[1..2] are read at the start of the launch and
+ *                 written back at its end (running sums over as many launches as the caller likes; it zeroes them at interval ends) */
+typedef struct {
+    int32_t threshold, n_agents;     /* refill rule as in rl_run (threshold < 0: none) */
+    int32_t* refill_count;
+    const float* eps_schedule;
+    int32_t trk_skip_ticks;          /* the first trk_skip_ticks ticks of the launch write trk_tick but stay out of the running sums:
+                                      * episode 0 of a training run never reaches an aggregate (tracker.py:279-282 keeps the last
+                                      * update_interval entries of update_interval + 1) */
+} rl_run_opts;
 int rl_run_supported(const rl_world* h, const rl_brain* brains, int n_brains);
 int rl_run(rl_world* h, const rl_brain* brains, int n_brains, int n_ticks, int8_t* actions, const rl_step_out* sout,
            float* const obs[2], int first_obs, int16_t* update_src, int threshold, int n_agents, int32_t* refill_count,
            void* stream);
+int rl_run_ex(rl_world* h, const rl_brain* brains, int n_brains, int n_ticks, int8_t* actions, const rl_step_out* sout,
+              float* const obs[2], int first_obs, int16_t* update_src, const rl_run_opts* opts, void* stream);
 
 /* trainer.py:95-96 for every world: agents of the post-step list with age > 1 append (state, action, reward,
  * state_prime, done[, prob]) to the replay ring of their brain.

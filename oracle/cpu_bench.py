@@ -3,9 +3,10 @@ reference's world tick) plus a BATCHED float32 policy forward (numpy sgemm over 
 reference's torch-CPU networks would cost if they were batched; the reference itself runs one batch-1 forward per agent,
 Helpers/trainer.py:88-89), timed on the host cores with one PROCESS per core (no GIL, BLAS pinned to one thread each).
 
-Three rates are reported, single-thread and all-core, over the same workload as the GPU line (30x30 worlds filled to 100
+Four rates are reported, single-thread and all-core, over the same workload as the GPU line (30x30 worlds filled to 100
 agents, refill below 70, greedy brains):  world_only (step + update_env + refill),  policy_only (batched forward + argmax),
-full_tick (both; the number bench.py puts in cpu_baseline.value).
+full_tick (both; the number bench.py puts in cpu_baseline.value),  policy_plus_step (variant (i) of SURVEY.md 8d: get_action +
+step, with update_env + refill running untimed in between -- the counterpart of the GPU line's variant_policy_plus_step).
 """
 import json
 import os
@@ -78,10 +79,11 @@ def _worker(idx, n_worlds, brains, static_families, seed, weights, duration, sta
         t1 = time.perf_counter()
         steps = int(n.sum())
         ow.step(acts)
+        ts = time.perf_counter()
         ow.update()
         ow.refill(70, 100)
         t2 = time.perf_counter()
-        return steps, t1 - t0, t2 - t1
+        return steps, t1 - t0, t2 - t1, ts - t1
 
     for _ in range(3):
         tick()
@@ -89,11 +91,11 @@ def _worker(idx, n_worlds, brains, static_families, seed, weights, duration, sta
         time.sleep(0.005)
     t_start = time.perf_counter()
     steps = ticks = 0
-    t_pol = t_world = 0.0
+    t_pol = t_world = t_step = 0.0
     while time.perf_counter() - t_start < duration:
-        s, a, b = tick()
-        steps += s; ticks += 1; t_pol += a; t_world += b
-    return (idx, steps, ticks, t_pol, t_world, time.perf_counter() - t_start)
+        s, a, b, c = tick()
+        steps += s; ticks += 1; t_pol += a; t_world += b; t_step += c
+    return (idx, steps, ticks, t_pol, t_world, time.perf_counter() - t_start, t_step)
 
 
 def _run(n_procs, n_worlds, brains, static_families, seed, wfile, duration):
@@ -115,7 +117,10 @@ def _run(n_procs, n_worlds, brains, static_families, seed, wfile, duration):
     wall = max(r[5] for r in res)
     t_pol = sum(r[3] for r in res)
     t_world = sum(r[4] for r in res)
+    t_step = sum(r[6] for r in res)
     return {"full_tick": round(steps / wall, 1),
+            # variant (i) of SURVEY.md 8d / BASELINE.md 3: get_action + step only (update_env and the refill run, untimed)
+            "policy_plus_step": round(steps / ((t_pol + t_step) / n_procs), 1),
             # per-leg rates: agent-steps per second of that leg's own time, summed over the processes running in parallel
             "world_only": round(steps / (t_world / n_procs), 1), "policy_only": round(steps / (t_pol / n_procs), 1),
             "ticks": sum(r[2] for r in res), "agent_steps": steps, "seconds": round(wall, 2)}

@@ -196,6 +196,11 @@ class OracleWorlds:
         if rc:
             raise RuntimeError("rlo_reset_synthetic failed: %d" % rc)
 
+    def reset_families(self, w0=0, w1=None):
+        rc = lib().rlo_reset_families(C.byref(self.cfg), C.byref(self._state), _ptr(self.obs2), w0, self.R if w1 is None else w1)
+        if rc:
+            raise RuntimeError("rlo_reset_families failed: %d" % rc)
+
     def refill(self, threshold, n_agents, w0=0, w1=None):
         rc = lib().rlo_refill(C.byref(self.cfg), C.byref(self._state), threshold, n_agents, _ptr(self.obs2), w0,
                               self.R if w1 is None else w1)

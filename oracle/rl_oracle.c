@@ -538,7 +538,9 @@ int rlo_observe(const rlo_config* cfg, const rlo_state* st, float* obs, int w0, 
  *   n_food = #{c : u24(r.z) < 0.1}, n_poison = #{c : u24(r.w) < 0.05}  (the Binomial(H*W, p) counts that
  *   Environment._init_food's H*W coin flips produce, environment.py:741-761);
  *   rank < n_agents -> Agent (gene = brain = mulhi(r.y, n_brains), health 200, age 0), the next n_food ranks Food,
- *   the next n_poison ranks Poison, the next one SuperFood.  Agents are listed row-major; uid = list index. */
+ *   the next n_poison ranks Poison, the next one SuperFood.  Agents are listed row-major; uid = list index.
+ * families != 0: Environment.reset()'s population instead (environment.py:147-149: one agent per brain, gene = brain = its index,
+ *   each at a uniformly random cell): n_agents = n_brains and the agent of key rank p gets gene p. */
 typedef struct { uint32_t key; int cell; } keyed_t;
 static int cmp_keyed(const void* a, const void* b)
 {
@@ -546,7 +548,7 @@ static int cmp_keyed(const void* a, const void* b)
     return x < y ? -1 : (x > y ? 1 : 0);
 }
 
-static void reset_world(const rlo_config* cfg, rlo_state* st, int w, int n_agents, float* obs)
+static void reset_world(const rlo_config* cfg, rlo_state* st, int w, int n_agents, float* obs, int families)
 {
     world_t wd; memset(&wd, 0, sizeof(wd));
     wd.cfg = cfg; wd.W = cfg->width; wd.H = cfg->height; wd.C = wd.W * wd.H; wd.cap = cfg->slot_cap; wd.w = w;
@@ -572,11 +574,12 @@ static void reset_world(const rlo_config* cfg, rlo_state* st, int w, int n_agent
     const int na = n_agents < wd.C ? n_agents : wd.C;
     for (int p = 0; p < wd.C; ++p) {
         int c = ks[p].cell;
+        if (families && p < na) gdraw[c] = (uint32_t)p;   /* the gene itself */
         wd.type[c] = p < na ? RLO_AGENT : p < na + nf ? RLO_FOOD : p < na + nf + np_ ? RLO_POISON : p == na + nf + np_ ? RLO_SUPER : RLO_EMPTY;
     }
     int idx = 0;
     for (int c = 0; c < wd.C; ++c)
-        if (wd.type[c] == RLO_AGENT) { int g = (int)mulhi32(gdraw[c], (uint32_t)cfg->n_brains); new_agent(&wd, st, idx++, c, g, g); }
+        if (wd.type[c] == RLO_AGENT) { int g = families ? (int)gdraw[c] : (int)mulhi32(gdraw[c], (uint32_t)cfg->n_brains); new_agent(&wd, st, idx++, c, g, g); }
     free(ks); free(gdraw);
     int* l = (int*)malloc(sizeof(int) * (size_t)wd.cap);
     int n = grid_agents(&wd, l);
@@ -588,7 +591,14 @@ static void reset_world(const rlo_config* cfg, rlo_state* st, int w, int n_agent
 int rlo_reset_synthetic(const rlo_config* cfg, rlo_state* st, int n_agents, float* obs, int w0, int w1)
 {
     if (cfg->width * cfg->height > MAXC || n_agents > cfg->slot_cap) return -1;
-    for (int w = w0; w < w1; ++w) reset_world(cfg, st, w, n_agents, obs);
+    for (int w = w0; w < w1; ++w) reset_world(cfg, st, w, n_agents, obs, 0);
+    return 0;
+}
+
+int rlo_reset_families(const rlo_config* cfg, rlo_state* st, float* obs, int w0, int w1)
+{
+    if (cfg->width * cfg->height > MAXC || cfg->n_brains > cfg->slot_cap || cfg->n_brains > cfg->width * cfg->height) return -1;
+    for (int w = w0; w < w1; ++w) reset_world(cfg, st, w, cfg->n_brains, obs, 1);
     return 0;
 }
 
@@ -597,7 +607,7 @@ int rlo_refill(const rlo_config* cfg, rlo_state* st, int threshold, int n_agents
     int cnt = 0;
     if (cfg->width * cfg->height > MAXC || n_agents > cfg->slot_cap) return -1;
     for (int w = w0; w < w1; ++w)
-        if (st->n_agents[w] < threshold) { st->epoch[w] += 1; reset_world(cfg, st, w, n_agents, obs); ++cnt; }
+        if (st->n_agents[w] < threshold) { st->epoch[w] += 1; reset_world(cfg, st, w, n_agents, obs, 0); ++cnt; }
     return cnt;
 }
 

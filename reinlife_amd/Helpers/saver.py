@@ -57,6 +57,7 @@ class Saver:
             a.save_brain(paths[a])
             params = {n: v for n, v in inspect.getmembers(a.brain, lambda x: not inspect.isroutine(x))
                       if type(v) in (float, int, bool, str) and not n.startswith("__")}
+            params.setdefault("one", 1)   # a constant every reference brain carries (Models/utils.py:7) and therefore every parameters file
             d, f = os.path.split(paths[a])
             with open(os.path.join(d, f.replace("brain", "parameters") + ".json"), "w") as fh:
                 json.dump(params, fh, indent=4)

@@ -13,9 +13,12 @@ def tester(brains, width=30, height=30, max_agents=100, pastel_colors=False, sta
     env.render(fps=fps)  # tester.py:55
     step = 0
     while n_steps is None or step < n_steps:
-        env.act(0)  # tester.py:57-68: every brain is asked with n_epi = 0
-        env.step()
-        env.update_env()
+        if env.rng == "philox":
+            env.run(0, 1)   # one launch per frame: get_action (n_epi = 0, tester.py:57-68) + step + update_env
+        else:
+            env.act(0)  # tester.py:57-68: every brain is asked with n_epi = 0
+            env.step()
+            env.update_env()
         env.render(fps=fps)
         if on_frame is not None:
             on_frame(env)

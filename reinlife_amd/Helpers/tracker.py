@@ -46,7 +46,7 @@ class Tracker:
         s = w.trk_sum.sum(0)
         c = w.trk_cnt.sum(0).to(torch.float64)
         pop = w.trk_pop[:, 1:].sum(0)
-        if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
+        if self.dist is not None and self.dist.is_initialized():   # (also at world size 1: the collective is the same code path)
             buf = torch.cat([s.reshape(-1), c.reshape(-1), pop])
             self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM)  # one small fused buffer per interval
             n = s.numel()

@@ -7,31 +7,54 @@ loop exactly as the reference does, so the same seeds give the same run; replica
 INFERENCE ONLY: training=True (the reference's default) keeps the loop, the epsilon schedules and the Tracker, but the brains
 of this build do not learn -- Environment warns about it, and save=True writes the weights as they were loaded / initialised
 (settings.json says so).  Training is outside this build's scope (BASELINE.json north_star)."""
+import time
+
 from ..World.environment import Environment
 
 
 def trainer(brains, n_episodes=10_000, width=30, height=30, visualize_results=False, google_colab=False, update_interval=500,
             print_results=True, max_agents=100, render=False, static_families=True, training=True, save=True,
-            limit_reproduction=False, incentivize_killing=True, *, n_worlds=1, device="cuda:0", seed=0, rng=None, per_agent_api=False):
+            limit_reproduction=False, incentivize_killing=True, *, n_worlds=1, device="cuda:0", seed=0, rng=None, per_agent_api=False,
+            fused=None, synthetic_agents=None, refill_below=None):
+    """Extra keyword-only arguments: n_worlds / device / seed / rng / synthetic_agents / refill_below (Environment); per_agent_api=True makes the reference's literal
+    per-agent get_action / learn calls; fused (default: True for rng="philox" without per_agent_api) runs the loop through
+    Environment.run -- whole chunks of ticks per launch, ending where the Tracker closes an interval -- instead of three launches
+    and a host round trip per tick; fused=False keeps the tick-by-tick loop (same results, tests/test_hip_round3.py).
+    The wall time of the loop itself is left in env.loop_seconds."""
     env = Environment(width=width, height=height, max_agents=max_agents, brains=brains, grid_size=24,
                       static_families=static_families, update_interval=update_interval, print_results=print_results,
                       interactive_results=visualize_results, google_colab=google_colab, training=training,
                       limit_reproduction=limit_reproduction, incentivize_killing=incentivize_killing, n_worlds=n_worlds,
-                      device=device, seed=seed, rng=rng)
+                      device=device, seed=seed, rng=rng, synthetic_agents=synthetic_agents, refill_below=refill_below)
     env.reset()
-    for n_epi in range(n_episodes + 1):
-        if per_agent_api:  # the reference's literal per-agent calls (slow; API compatibility)
-            for agent in env.agents:
-                agent.get_action(n_epi)
-        else:
-            env.act(n_epi)
-        env.step()
-        if training and per_agent_api:
-            for agent in env.agents:
-                agent.learn(n_epi=n_epi)
-        env.update_env(n_epi)
-        if render:  # trainer.py:101-102
-            env.render(fps=120)
+    if fused is None:
+        fused = env.rng == "philox" and not per_agent_api
+    if fused and (env.rng != "philox" or per_agent_api):
+        raise ValueError("trainer(fused=True) needs rng='philox' and per_agent_api=False")
+    env._sync()
+    t0 = time.perf_counter()
+    if fused and not render:
+        env.run(0, n_episodes + 1)      # trainer.py:85-99, n_episodes + 1 iterations
+    else:
+        for n_epi in range(n_episodes + 1):
+            if fused:
+                env.run(n_epi, 1)
+            elif per_agent_api:  # the reference's literal per-agent calls (slow; API compatibility)
+                for agent in env.agents:
+                    agent.get_action(n_epi)
+                env.step()
+                if training:
+                    for agent in env.agents:
+                        agent.learn(n_epi=n_epi)
+                env.update_env(n_epi)
+            else:
+                env.act(n_epi)
+                env.step()
+                env.update_env(n_epi)
+            if render:  # trainer.py:101-102
+                env.render(fps=120)
+    env._sync()
+    env.loop_seconds = time.perf_counter() - t0
     if save:
         env.save_results()
     return env

@@ -3,7 +3,6 @@
 
 class BasicBrain:
     def __init__(self, input_dim, output_dim, method):
-        self.one = 1
         self._method = method
         self.input_dim = input_dim
         self.output_dim = output_dim

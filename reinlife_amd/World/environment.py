@@ -2,8 +2,9 @@
 
 Same constructor keywords, `reset() / step() / update_env(n_epi)`, `agents` (row-major list), `brains`, `max_gene`,
 `action_space = 8`, `observation_space = 153`.  Extras (keyword-only): `n_worlds` independent replicas on the device,
-`device`, `seed`.  `env.agents` are lightweight views of world 0; the batched fast path is `env.act(n_epi)`, which runs
-Agent.get_action for every agent of every world on the GPU.
+`device`, `seed`.  `env.agents` are lightweight views of world 0, built from the device state when they are first read after a change (a loop
+that never reads them never synchronises); the batched fast paths are `env.act(n_epi)` (Agent.get_action for every agent of every
+world on the GPU) and `env.run(n_epi, n_ticks)` (whole chunks of the trainer loop in one launch each).
 
 Random numbers.  `rng="reference"` (the default for a single world) makes the SAME draws from Python's `random`,
 `np.random` and torch's global generator, in the same order and with the same arguments, as the reference's
@@ -22,7 +23,8 @@ from .utils import Actions, EntityTypes
 
 
 class _WorldMirror:
-    """Host copy of ONE world's agent list and per-agent outputs, in env.agents order (refreshed after every step / update)."""
+    """Host copy of ONE world's agent list and per-agent outputs, in env.agents order.  Built on first use after a step() /
+    update_env() / run() (Environment._mat): a loop that never looks at env.agents never pays for it."""
 
     def __init__(self, world):
         self.world = world
@@ -41,7 +43,7 @@ class AgentView:
 
     def __init__(self, env, k, mirror=None):
         self._env, self._k = env, k
-        self._m = mirror if mirror is not None else env._mirror0
+        self._m = mirror if mirror is not None else env._mat(0)
         self.prob = None
         self.info = ""
 
@@ -66,10 +68,14 @@ class AgentView:
 
     @property
     def action(self):
+        if self._m.actions is None:   # act() ran after this view was built: the policy's choice is fetched on first use
+            self._env._mat(self._m.world)
         return int(self._m.actions[self._k])
 
     @action.setter
     def action(self, a):
+        if self._m.actions is None:
+            self._env._mat(self._m.world)
         self._m.actions[self._k] = int(a)
         self._m.dirty = True
 
@@ -117,7 +123,7 @@ class Environment:
     def __init__(self, width=30, height=30, brains=None, grid_size=16, max_agents=50, update_interval=500, print_results=True,
                  static_families=True, interactive_results=False, google_colab=False, training=True, save=False,
                  pastel_colors=False, limit_reproduction=False, incentivize_killing=True, *, n_worlds=1, device="cuda:0",
-                 seed=0, rng=None):
+                 seed=0, rng=None, synthetic_agents=None, refill_below=None):
         if not brains:
             raise ValueError("Environment needs a non-empty list of brains")
         self.width, self.height = width, height
@@ -138,6 +144,14 @@ class Environment:
         self.rng = rng or ("reference" if n_worlds == 1 else "philox")
         if self.rng not in ("reference", "philox") or (self.rng == "reference" and n_worlds != 1):
             raise ValueError("rng must be 'reference' (single world only) or 'philox'")
+        # SURVEY.md 8d's synthetic benchmark worlds through this API (keyword-only extras, rng="philox"): reset() fills every world with
+        # `synthetic_agents` agents at random cells (gene / brain uniform over the brains) instead of one agent per brain, and a world
+        # whose population drops below `refill_below` after update_env is re-generated (what bench.py times: 100 / 70)
+        self.synthetic_agents, self.refill_below = synthetic_agents, refill_below
+        if (synthetic_agents is not None or refill_below is not None) and self.rng != "philox":
+            raise ValueError("synthetic_agents / refill_below need rng='philox'")
+        if refill_below is not None and synthetic_agents is None:
+            raise ValueError("refill_below needs synthetic_agents (the population a re-generated world starts with)")
         self.best_agents = []
         # environment.py:118: the painter is built first (pastel colours draw from `random` here, its background tiles at
         # the first render() -- both matter for same-seed runs)
@@ -152,22 +166,45 @@ class Environment:
         from ..Helpers.tracker import Tracker
         self.tracker = Tracker(update_interval=update_interval, interactive=False, print_results=print_results, nr_genes=len(brains),
                                static_families=static_families, brains=brains, worlds=self.worlds if training else None)
-        self.agents = []
-        self._mirror0 = _WorldMirror(0)
-        self._mirror0.actions = np.full(self.worlds.cap, -1, np.int8)
-        self._mirrors = {}          # world -> _WorldMirror of replicas other than 0, built on demand (agents_of)
+        self._mirrors = {}          # world -> _WorldMirror, built on demand (_mat): env.agents is world 0's
+        self._grid = self._max_gene = None
         self._phase = "update"
+        self._acted = False         # act() ran since the last step() / update_env(): worlds.actions holds the policy's choice
+        self._empty = True          # no world has been built yet (before reset())
         self._brains_bound = False
+        self.loop_seconds = None    # wall time of the last trainer() / tester() loop on this environment (set by them)
         if training:
             warn_inference_only()
 
-    # world 0's mirror under the names the rest of this class (and older callers) use
-    _host = property(lambda s: s._mirror0.host)
-    _state_host = property(lambda s: s._mirror0.state, lambda s, v: setattr(s._mirror0, "state", v))
-    _state_prime_host = property(lambda s: s._mirror0.state_prime, lambda s, v: setattr(s._mirror0, "state_prime", v))
-    _reward_host = property(lambda s: s._mirror0.reward, lambda s, v: setattr(s._mirror0, "reward", v))
-    _done_host = property(lambda s: s._mirror0.done, lambda s, v: setattr(s._mirror0, "done", v))
-    _actions_host = property(lambda s: s._mirror0.actions, lambda s, v: setattr(s._mirror0, "actions", v))
+    # -- the host view of the device state: materialised on first read after every state change ------------------------------
+    @property
+    def agents(self):
+        """env.agents (environment.py:186, 214): world 0's agents in row-major order, as AgentView objects."""
+        return [] if self._empty else self._mat(0).views
+
+    @property
+    def grid(self):
+        """Grid.get_numpy() of world 0 (grid.py:49-57): [height, width] uint8 cell codes."""
+        if self._grid is None and not self._empty:
+            self._sync()
+            self._grid = self.worlds.s["cell_type"][0].cpu().numpy().reshape(self.height, self.width)
+        return self._grid
+
+    @property
+    def max_gene(self):
+        if self._max_gene is None:
+            self._sync()
+            self._max_gene = int(self.worlds.s["max_gene"][0].item())
+        return self._max_gene
+
+    @max_gene.setter
+    def max_gene(self, v):
+        self._max_gene = int(v)
+
+    # world 0's mirror under the names the rest of this class uses
+    _mirror0 = property(lambda s: s._mat(0))
+    _host = property(lambda s: s._mat(0).host)
+    _state_host = property(lambda s: s._mat(0).state)
 
     # -- brains -------------------------------------------------------------------------------------------------
     def _bind_brains(self):
@@ -177,16 +214,21 @@ class Environment:
     # -- reference protocol ---------------------------------------------------------------------------------------
     def reset(self):
         """environment.py:133-158.  World 0 follows the reference's np.random draw order exactly; further replicas are built
-        by the same rule from their own generators."""
+        by the same rule on the device (rl_reset_families)."""
+        if self.synthetic_agents is not None:
+            self.worlds.reset_synthetic(self.synthetic_agents)
+            self._empty = False
+            self._refresh(after="update")
+            return
+        # replicas: the same construction (one agent per brain, gene = its index; environment.py:147-149) on the device, from the
+        # Philox streams keyed by (seed, global replica id): ONE launch for any number of worlds ...
+        if self.n_worlds > 1:
+            self.worlds.reset_families()
+        # ... and world 0 alone consumes the process-global np.random, in the reference's order
         snap = host_reset(self.width, self.height, len(self.brains))
         self.worlds.load_world(0, snap)
-        # replicas 1..: the same construction (one agent per brain, gene = its index; environment.py:147-149), each from its
-        # own generator keyed by (seed, global replica id) so that world 0 alone consumes the process-global np.random
-        for w in range(1, self.n_worlds):
-            rs = np.random.RandomState((int(self.worlds.cfg.seed) * 1_000_003 + int(self.worlds.cfg.world_base) + w) % (2 ** 32))
-            self.worlds.load_world(w, host_reset(self.width, self.height, len(self.brains), rng=rs))
-        self.max_gene = len(self.brains)
         self.worlds.observe()
+        self._empty = False
         self._refresh(after="update")
 
     def act(self, n_epi=0):
@@ -211,15 +253,14 @@ class Environment:
             b.update_epsilon(n_epi)
         self._bind_brains()
         self.worlds.act()
-        self._mirror0.actions = self.worlds.actions[0].cpu().numpy().copy()
-        self._mirror0.dirty = False
-        for w, m in self._mirrors.items():
-            m.actions = self.worlds.actions[w].cpu().numpy().copy()
+        self._acted = True
+        for m in self._mirrors.values():   # mirrors built before this call: their actions are the policy's choice now
+            m.actions = None               # (fetched on first use: AgentView.action)
             m.dirty = False
 
     def step(self):
         """environment.py:160-186"""
-        dirty = [m for m in [self._mirror0] + list(self._mirrors.values()) if m.dirty]
+        dirty = [m for m in self._mirrors.values() if m.dirty]
         if dirty:
             full = self.worlds.actions.cpu().numpy()
             for m in dirty:
@@ -236,7 +277,7 @@ class Environment:
     def update_env(self, n_epi=0):
         """environment.py:188-215"""
         if self.training:
-            self.tracker.update_results(self.agents, n_epi)
+            self.tracker.update_results(None, n_epi)   # (the per-tick statistics were accumulated inside the step launch)
         if self.rng == "reference":
             tape, produced = self._draw_update()
             self.worlds.update(self.worlds.make_tape([tape]))
@@ -247,6 +288,8 @@ class Environment:
                     torch.randn((128, 153))  # PERD3QN.py:127-130; brains are shared by index here, only the stream advances
         else:
             self.worlds.update()
+            if self.refill_below is not None:
+                self.worlds.refill(self.refill_below, self.synthetic_agents)
             self._refresh(after="update")
 
     # -- the reference's random draws, made on the host from the global generators (rng="reference") -----------
@@ -330,17 +373,58 @@ class Environment:
             agents = [SavedAgent(int(self.max_gene), self.brains[int(b)]) for b in bb]
         return Saver(main_folder, google_colab=self.google_colab).save(agents, self.static_families, self.tracker.results, settings)
 
-    # -- host mirror of world 0 --------------------------------------------------------------------------------------
+    # -- fused loop ----------------------------------------------------------------------------------------------------
+    def run(self, n_epi=0, n_ticks=1, max_chunk=4096):
+        """`n_ticks` iterations of the trainer loop (trainer.py:85-99: get_action for every agent -> step -> update_env) starting at
+        episode `n_epi`, with as few launches as the configuration allows: rng="philox" runs whole chunks in ONE launch each
+        (rl_run_ex: worlds resident in LDS, the brains' per-episode epsilon as a schedule, the Tracker's statistics accumulated in the
+        launch); chunks end where the reference's Tracker closes an interval (n_epi % update_interval == 0, tracker.py:107-121); episode
+        0's statistics never reach an aggregate (tracker.py:279-282) and are left out inside the launch.  Same results as calling
+        act() / step() / update_env() tick by tick (tests/test_hip_round3.py)."""
+        if self.rng != "philox":
+            for t in range(n_ticks):
+                self.act(n_epi + t); self.step(); self.update_env(n_epi + t)
+            return
+        interval = self.tracker.update_interval
+        thr = -1 if self.refill_below is None else self.refill_below
+        while n_ticks > 0:
+            k = min(n_ticks, max_chunk)
+            if self.training and n_epi + k - 1 >= interval:   # up to and including the next episode that closes a Tracker interval
+                k = min(k, (max(n_epi, 1) + interval - 1) // interval * interval - n_epi + 1)
+            eps = np.empty((k, len(self.brains)), np.float32)
+            for t in range(k):
+                for b, brain in enumerate(self.brains):
+                    brain.update_epsilon(n_epi + t)
+                    eps[t, b] = getattr(brain, "epsilon", 0.0)
+            self._bind_brains()   # (the brains' current epsilon = the last row)
+            # episode 0 writes its statistics but stays out of the running sums (Tracker.update_results(n_epi=0) zeroes them)
+            self.worlds.run(k, thr, self.synthetic_agents or 0, eps_schedule=None if (eps == eps[-1]).all() else eps,
+                            trk_skip=1 if (self.training and n_epi == 0) else 0)
+            self._refresh(after="update")
+            last = n_epi + k - 1
+            if self.training and last > 0 and last % interval == 0:
+                self.tracker.update_results(None, last)
+            n_epi += k
+            n_ticks -= k
+
+    # -- host mirrors ----------------------------------------------------------------------------------------------------
     def agents_of(self, world):
         """env.agents of replica `world` (row-major list of AgentView): the same protocol as env.agents, which is world 0's.
-        Views are valid until the next step() / update_env()."""
-        if world == 0:
-            return self.agents
+        Views are valid until the next step() / update_env() / run()."""
         if not 0 <= world < self.n_worlds:
             raise IndexError("world %d of %d" % (world, self.n_worlds))
+        return self._mat(world).views
+
+    def _sync(self):
+        torch.cuda.synchronize(self.worlds.device)
+        self.worlds.check_error_flag()
+
+    def _mat(self, world):
+        """The host mirror of one world, built from the device state on first use."""
         m = self._mirrors.get(world)
         if m is None:
             w = self.worlds
+            self._sync()
             m = _WorldMirror(world)
             n = int(w.s["n_agents"][world].item())
             m.host = {k: w.s[k][world, :n].cpu().numpy() for k in w.s if k.startswith("a_")}
@@ -352,34 +436,20 @@ class Environment:
                 m.done = w.done[world, :n].cpu().numpy()
             else:
                 m.state = w.obs_state()[world, :n].cpu().numpy().astype(np.float64)
-            m.actions = np.concatenate([m.host["a_action"], np.full(w.cap - n, -1, np.int8)])
+            if not (self._phase == "update" and self._acted):   # Agent.action: the action last taken (-1 for newborns) ...
+                m.actions = np.concatenate([m.host["a_action"], np.full(w.cap - n, -1, np.int8)])
+            self._mirrors[world] = m   # (before the views: AgentView looks its mirror up)
             m.views = [AgentView(self, k, m) for k in range(n)]
-            self._mirrors[world] = m
-        return m.views
+        if m.actions is None:          # ... or, once act() has run, what the policy chose for this tick
+            m.actions = self.worlds.actions[world].cpu().numpy().copy()
+        return m
 
     def _refresh(self, after):
-        w = self.worlds
-        torch.cuda.synchronize(w.device)
-        w.check_error_flag()
+        """The device state changed: drop every host copy (they are rebuilt on first read -- no synchronisation here)."""
         self._phase = after
+        self._acted = False
         self._mirrors = {}
-        n = int(w.s["n_agents"][0].item())
-        self._mirror0.host = {k: w.s[k][0, :n].cpu().numpy() for k in w.s if k.startswith("a_")}
-        self.max_gene = int(w.s["max_gene"][0].item())
-        self.grid = w.s["cell_type"][0].cpu().numpy().reshape(self.height, self.width)
-        if after == "step":
-            self._state_prime_host = w.obs_state_prime()[0, :n].cpu().numpy().astype(np.float64)
-            self._reward_host = w.reward[0, :n].cpu().numpy()
-            self._done_host = w.done[0, :n].cpu().numpy()
-            src = w.src1[0, :n].cpu().numpy()
-            self._state_host = self._state_host[src] if len(src) else self._state_host[:0]
-            self._actions_host = np.concatenate([self._actions_host[src], np.full(w.cap - n, -1, np.int8)])
-        else:
-            self._state_host = w.obs_state()[0, :n].cpu().numpy().astype(np.float64)
-            self._state_prime_host = None
-            self._reward_host = self._done_host = None
-            self._actions_host = np.concatenate([self._host["a_action"], np.full(w.cap - n, -1, np.int8)])
-        self.agents = [AgentView(self, k) for k in range(n)]
+        self._grid = self._max_gene = None
 
 
 def warn_inference_only():

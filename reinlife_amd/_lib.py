@@ -53,6 +53,11 @@ class Replay(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("state", "state_prime", "action", "reward", "done", "prob", "age", "count")] + [("capacity", C.c_int64)]
 
 
+class RunOpts(C.Structure):  # rl_run_opts
+    _fields_ = [("threshold", C.c_int32), ("n_agents", C.c_int32), ("refill_count", C.c_void_p), ("eps_schedule", C.c_void_p),
+                ("trk_skip_ticks", C.c_int32)]
+
+
 class Brain(C.Structure):
     _fields_ = [("kind", C.c_int32), ("epsilon", C.c_float), ("packed", C.c_void_p)]
 
@@ -68,6 +73,7 @@ ABI = [
     ("rl_bind_error_flag", C.c_int, [_P, _P]),
     ("rl_bind_phase_profile", C.c_int, [_P, _P, C.c_int]),
     ("rl_reset_synthetic", C.c_int, [_P, C.c_int, _P, _P]),
+    ("rl_reset_families", C.c_int, [_P, _P, _P]),
     ("rl_refill", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
     ("rl_observe", C.c_int, [_P, _P, _P]),
     ("rl_step", C.c_int, [_P, _P, C.POINTER(Tape), C.POINTER(StepOut), _P]),
@@ -78,6 +84,7 @@ ABI = [
     ("rl_tick_refill", C.c_int, [_P, _P, C.POINTER(StepOut), C.POINTER(UpdateOut), C.c_int, C.c_int, _P, _P]),
     ("rl_run_supported", C.c_int, [_P, C.POINTER(Brain), C.c_int]),
     ("rl_run", C.c_int, [_P, C.POINTER(Brain), C.c_int, C.c_int, _P, C.POINTER(StepOut), C.POINTER(_P), C.c_int, _P, C.c_int, C.c_int, _P, _P]),
+    ("rl_run_ex", C.c_int, [_P, C.POINTER(Brain), C.c_int, C.c_int, _P, C.POINTER(StepOut), C.POINTER(_P), C.c_int, _P, C.POINTER(RunOpts), _P]),
     ("rl_capture_transitions", C.c_int, [_P, _P, _P, _P, C.POINTER(StepOut), C.POINTER(Replay), C.c_int, _P]),
     ("rl_policy_n_params", C.c_int64, [C.c_int]),
     ("rl_policy_packed_floats", C.c_int64, [C.c_int]),

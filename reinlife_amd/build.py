@@ -8,11 +8,22 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 PROFILE = bool(os.environ.get("RL_PHASE_PROFILE"))  # tuning build with in-kernel phase stamps
 LIB_PATH = os.path.join(LIB_DIR, "libreinlife_hip_prof.so" if PROFILE else "libreinlife_hip.so")
-SOURCES = ["rl_world.hip", "rl_policy.hip", "rl_capi.hip"]
-HEADERS = ["rl_common.h", "rl_policy_dev.h", os.path.join("..", "..", "include", "reinlife_hip.h")]
+SOURCES = ["rl_world.hip", "rl_run.hip", "rl_policy.hip", "rl_capi.hip"]
+HEADERS = ["rl_common.h", "rl_policy_dev.h", "rl_world_dev.h", os.path.join("..", "..", "include", "reinlife_hip.h")]
 # -ffp-contract=off: the world kernels' float64 reward / fitness arithmetic must round exactly like the CPU path
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("RL_EXTRA_HIPCC_FLAGS", "").split()
+
+
+def source_hash():
+    """sha256[:16] over the kernel sources and headers: stamps measurements that are only valid for the code they were taken on
+    (profiles/run_traffic.json; bench.py drops a stamped figure when the sources have changed since)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES) + sorted(HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def _stale(target, deps):
@@ -26,8 +37,8 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(LIB_DIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
-    objs = []
-    for src in SOURCES:
+    objs, jobs = [], []
+    for src in SOURCES:   # the translation units compile side by side (rl_world.hip alone takes over a minute)
         sp = os.path.join(CSRC, src)
         obj = os.path.join(LIB_DIR, src.replace(".hip", "_prof.o" if PROFILE else ".o"))
         objs.append(obj)
@@ -35,7 +46,10 @@ def build(force=False, verbose=False):
             cmd = [hipcc] + FLAGS + (["-DRL_PHASE_PROFILE"] if PROFILE else []) + ["-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, job in jobs:
+        if job.wait() != 0:
+            raise subprocess.CalledProcessError(job.returncode, cmd)
     if force or _stale(LIB_PATH, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
         if verbose:

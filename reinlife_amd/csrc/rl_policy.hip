@@ -134,11 +134,11 @@ __global__ __launch_bounds__(64, 2) void k_policy1(const PolicyArgs A)
     const int bi = blockIdx.y, tile = blockIdx.x;
     const BrainSlot B = A.b[bi];
     const int li = tile * 32 + j;
-    const int entry = B.rowlist ? B.rowlist[li] : 0;
+    const int n = B.count_ptr ? ((cint*)B.count_ptr)[0] : (int)A.n_rows;
+    if (tile * 32 >= n) return;   // (before the row list is touched: the grid is sized by the rows a brain COULD have)
+    const int entry = B.rowlist ? B.rowlist[min(li, n - 1)] : 0;   // lanes past the end: the brain's last row, not stored (as k_policy_dense)
     const int e_w = rl_list_world(entry), e_k = rl_list_slot(entry);
     const int64_t listed = B.rowlist ? (int64_t)e_w * A.cap + e_k : (int64_t)li;
-    const int n = B.count_ptr ? ((cint*)B.count_ptr)[0] : (int)A.n_rows;
-    if (tile * 32 >= n) return;
     TileIO io;
     io.packed = (gfloat*)B.packed;
     io.obs = A.obs;

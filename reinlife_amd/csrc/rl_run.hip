@@ -1,0 +1,752 @@
+// rl_run.hip -- the multi-tick kernel of the ReinLife hot path on MI355X (gfx950): k_run and its host launcher.
+#include "rl_world_dev.h"
+
+// Measurement switch of the multi-tick launch (bench.py's per-half timings, tools/): 1 = skip the policy half, 2 = skip the tick half,
+// 4 / 8 / 16 = at most 2 / 1 / 3 policy tiles, 32 = no staggered start.  Results are then WRONG, so this is an explicit call of the
+// measuring process -- never an environment variable a production run could inherit -- and rl_run says so in rl_last_error().
+static int g_run_debug = 0;
+extern "C" void rl_debug_set_run_mask(int mask) { g_run_debug = mask; }
+extern "C" int rl_debug_get_run_mask(void) { return g_run_debug; }
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_run: n_ticks iterations of the inference loop (Helpers/trainer.py:85-99 minus learn) in ONE launch.
+//
+//   for every tick:  Agent.get_action for the world's agents (policy_tile, rl_policy_dev.h)  ->  Environment.step  ->
+//                    update_env  ->  optional re-generation below the refill threshold
+//
+// A world never leaves its workgroup: the state is loaded once, every tick runs out of LDS (the same phase functions as
+// k_world), the agent list is re-packed in LDS between ticks (recycle_world = what store_world + load_world do through
+// HBM), and the state is stored once at the end.  Every API-visible per-tick output is still written every tick
+// (state_prime / state rows, reward, done, both permutations, actions), so a tick moves the same algorithmic bytes as
+// rl_policy_act + rl_tick_refill; what disappears is two launches, the world's load / store, the row lists, and the trip of
+// the observation rows through the fabric to another CU (the policy reads its own world's rows back from L2, sc1).
+// The 4-wave tile code runs on groups of four waves of the world's workgroup (T / 256 tiles at a time); every group executes
+// the same number of workgroup barriers per round.
+// ---------------------------------------------------------------------------------------------------------------
+#include "rl_policy_dev.h"
+
+constexpr int kRunMaxBrains = 8;
+
+#ifndef RL_RUN_COHERENT
+#define RL_RUN_COHERENT true
+#endif
+struct RunArgs {
+    const float* packed[kRunMaxBrains];   // device: packed weights per brains-list entry
+    float eps[kRunMaxBrains];
+    float* obs[2];                        // Agent.state ping-pong: tick i reads obs[(first + i) & 1], writes the other
+    int first;
+    int n_ticks;
+    int8_t* actions;                      // [R][cap] chosen actions of the LAST tick (API-visible)
+    const float* eps_sched;               // optional device [n_ticks][n_brains]: the brains' exploration rates tick by tick (else eps[])
+    int trk_skip;                         // the Tracker's running sums leave out the first trk_skip ticks of the launch
+    int debug;                            // measurement only (rl_debug_set_run_mask): 1 = skip the policy half, 2 = skip the tick half (results WRONG)
+};
+
+struct PolSmem {
+    char* group0;       // per-group block: lds_h | lds_aux | lds_part, group g at group0 + g * group_bytes
+    int group_bytes;
+    short* prow;        // [cap] list indices grouped by brain
+    int* bstart;        // [64] first entry of brain b in prow
+    int* bcnt;          // [64]
+    int* tstart;        // [64] first tile of brain b
+    short* trow;        // [kMaxTiles][32] list index of tile row j (| 0x8000: padding, repeats the brain's last row)
+    int* tbrain;        // [kMaxTiles] brain of tile t
+    int* meta;          // [8]  [0] number of tiles; loop state of k_run: [1] list length, [2] Agent.state parity, [3] ticks done,
+                        //      [4] the LDS mirror holds the current Agent.state rows
+    float* pairv;       // [4 tiles][32 row values | 2 x 64 partial row maxima] of the two-waves-per-tile policy (T = 512), or null
+    float* cconst;      // [n_brains][3][256] epilogue constants of the brains' three 128-wide layers for policy_tile1s (T = 512), or null
+    float* xmirror;     // [xrows][kXStride] Agent.state rows of this world for the one-wave policy tile (T <= 512), or null
+    int xrows;
+    double* trk_scr;    // [cap] scratch of the Tracker pass (track_world_wave0)
+    TrkLds trk;         // the Tracker's running sums for the length of the launch
+};
+template <int KIND>
+__host__ __device__ constexpr int policy_group_bytes()
+{
+    return (int)(align16(sizeof(f32x4) * (size_t)policy_lds_units(KIND)) + align16(sizeof(float) * kAuxFloats) + align16(sizeof(float) * 4 * 32 * 9));
+}
+// groups > 0: `groups` blocks for the 4-wave tile (T = 1024).  groups == 0: the one-wave tile needs no LDS of its own; with
+// mirror_budget > 0 the Agent.state rows are mirrored in LDS instead (as many rows as fit below the budget, at most cap).
+constexpr int kMaxTiles = 32;                // 32-row tiles of one brain per world: <= cap / 32 + n_brains
+constexpr int kPairFloats = 32 + 2 * 64;     // per tile pair: row values, partial row maxima of the two roles
+constexpr int kPairExBytes = 8 * kPlanes * 64 * 16;   // per tile pair: the split activations of the input layer (aliases the Agent.state mirror)
+template <int KIND>
+__host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o, int cap, int groups, size_t mirror_budget = 0, int n_cbrains = 0)
+{
+    o = align16(o);
+    ps.group0 = base + o; ps.group_bytes = policy_group_bytes<KIND>();
+    o += (size_t)groups * policy_group_bytes<KIND>();
+    ps.xmirror = nullptr; ps.xrows = 0;
+    // what follows the mirror: row lists and tile descriptors (2 * cap + ~3.5 KB), the Tracker's scratch and sums (8 * cap + ~0.8 KB), ...
+    const size_t tail = 10 * (size_t)cap + 5120 + sizeof(float) * 4 * kPairFloats + sizeof(float) * kTileConstFloats * (size_t)n_cbrains;
+    if (groups == 0 && mirror_budget > o + tail) {
+        const size_t rows = (mirror_budget - o - tail) / (sizeof(float) * kXStride);
+        ps.xrows = (int)(rows < (size_t)cap ? rows : (size_t)cap);
+        if (ps.xrows >= 32) { ps.xmirror = (float*)(base + o); o = align16(o + sizeof(float) * kXStride * (size_t)ps.xrows); }
+        else ps.xrows = 0;
+    }
+    ps.prow = (short*)(base + o); o = align16(o + sizeof(short) * (size_t)cap);
+    ps.bstart = (int*)(base + o); o = align16(o + sizeof(int) * 64);
+    ps.bcnt = (int*)(base + o); o = align16(o + sizeof(int) * 64);
+    ps.tstart = (int*)(base + o); o = align16(o + sizeof(int) * 64);
+    ps.trow = (short*)(base + o); o = align16(o + sizeof(short) * kMaxTiles * 32);
+    ps.tbrain = (int*)(base + o); o = align16(o + sizeof(int) * kMaxTiles);
+    ps.meta = (int*)(base + o); o = align16(o + sizeof(int) * 8);
+    ps.cconst = nullptr;
+    if (n_cbrains > 0) { ps.cconst = (float*)(base + o); o = align16(o + sizeof(float) * kTileConstFloats * (size_t)n_cbrains); }
+    ps.pairv = nullptr;
+    if (n_cbrains > 0) { ps.pairv = (float*)(base + o); o = align16(o + sizeof(float) * 4 * kPairFloats); }
+    ps.trk_scr = (double*)(base + o); o = align16(o + sizeof(double) * (size_t)cap);
+    ps.trk.sum = (double*)(base + o); o = align16(o + sizeof(double) * kRunMaxBrains * RL_TRK_VARS);
+    ps.trk.pop = (double*)(base + o); o = align16(o + sizeof(double) * 2);
+    ps.trk.cnt = (int*)(base + o); o = align16(o + sizeof(int) * kRunMaxBrains * RL_TRK_VARS);
+    return o;
+}
+template <int KIND> __device__ inline f32x4* pol_h(const PolSmem& ps, int g) { return (f32x4*)(ps.group0 + g * ps.group_bytes); }
+template <int KIND> __device__ inline float* pol_aux(const PolSmem& ps, int g)
+{
+    return (float*)(ps.group0 + g * ps.group_bytes + align16(sizeof(f32x4) * (size_t)policy_lds_units(KIND)));
+}
+template <int KIND> __device__ inline float (*pol_part(const PolSmem& ps, int g))[32][9]
+{
+    return (float (*)[32][9])(ps.group0 + g * ps.group_bytes + align16(sizeof(f32x4) * (size_t)policy_lds_units(KIND)) + align16(sizeof(float) * kAuxFloats));
+}
+
+// Agent.get_action for the n agents of this world (slot k == list index k): actions into s.action[] and the global
+// `actions` buffer.  Must be called by the whole workgroup; leaves with a barrier behind the last action store.
+// (Per-brain arguments are fetched from the kernel-argument block with a uniform index -- scalar loads; a by-value copy of the
+// argument struct indexed at run time would live in scratch, and at 1024 threads x 256 worlds every dword of scratch per thread
+// is 1 MB of memory traffic per tick.)
+struct RunParams;
+typedef const RunParams __attribute__((address_space(4))) RunParamsC;
+template <int T, int KIND, bool TRAIN>
+__device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base);
+
+// Between two ticks of k_run: the post-update list becomes slots 0..n-1 (slot == list index, what load_world establishes),
+// and every per-tick scratch is reset to what load_world leaves behind.  slot_cap <= T: one agent per thread.
+// (the reads are issued BEFORE the last observation pass, which leaves the agents alone: their dependent LDS round trips then
+// overlap that pass instead of forming an interval of their own)
+struct RecycleRegs {
+    unsigned short pos;
+    int h, age, ma, g, b, u;
+    uint8_t fl;
+    signed char act;
+    double f;
+};
+__device__ inline RecycleRegs recycle_read(Smem& s, int n)
+{
+    const int tid = rl_tidx();
+    const int a = tid < n ? s.order[tid] : 0;
+    RecycleRegs r;
+    r.pos = s.pos[a];
+    r.h = s.health[a]; r.age = s.age[a]; r.ma = s.max_age[a]; r.g = s.gene[a]; r.b = s.brain[a]; r.u = s.uid[a];
+    r.fl = s.flags[a];
+    r.act = s.action[a];
+    r.f = s.fitness[a];
+    return r;
+}
+template <int T, bool SPEC>
+__device__ __forceinline__ void recycle_world(const KParams& p, Smem& s, int n, int tick, int epoch, int next_uid, int max_gene, bool drain_stores, const RecycleRegs& rr)
+{
+    const int tid = rl_tidx();
+    const bool mine = tid < n;
+    const unsigned short r_pos = rr.pos;
+    const int r_h = rr.h, r_age = rr.age, r_ma = rr.ma, r_g = rr.g, r_b = rr.b, r_u = rr.u;
+    const uint8_t r_fl = rr.fl;
+    const signed char r_act = rr.act;
+    const double r_f = rr.f;
+    lds_barrier();   // every field is in registers; the planes were last read before the barrier that precedes this call
+    if (mine) {
+        s.pos[tid] = r_pos; s.health[tid] = r_h; s.age[tid] = r_age; s.max_age[tid] = r_ma; s.gene[tid] = r_g; s.brain[tid] = r_b;
+        s.uid[tid] = r_u; s.flags[tid] = r_fl; s.action[tid] = r_act; s.fitness[tid] = r_f;
+        s.aux[tid] = 0; s.src[tid] = (short)tid; s.order[tid] = (short)tid; s.newidx[tid] = (short)tid;
+    }
+    for (int c = tid; c < p.Cp; c += T) { s.occ[c] = -1; ((unsigned*)s.foodv)[c] = 0u; }
+    for (int i = tid; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
+    if (tid < RL_MAX_BRAINS) s.present[tid] = 0;
+    if (SPEC) for (int i = tid; i < 2 * p.cap; i += T) ((unsigned*)s.reward)[i] = 0u;
+    if (tid < S_COUNT)
+        s.scal[tid] = tid == S_NSLOTS ? n : tid == S_TICK ? tick : tid == S_EPOCH ? epoch : tid == S_NEXT_UID ? next_uid : tid == S_MAX_GENE ? max_gene : 0;
+    lds_barrier();
+    if (mine) s.occ[(r_pos & 255) * p.W + (r_pos >> 8)] = (short)tid;
+    if (drain_stores) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tick's observation rows are in L2 before any wave reads them back
+    lds_barrier();
+}
+
+// The kernel's only parameter.  The two halves of a tick are real (noinline) function calls, each with a register allocation
+// of its own (inlined into one body the tile code's ~126 VGPRs and the tick's hoisted loop invariants spill into each other's
+// loops), and the kernel body keeps NOTHING alive across them: the loop state lives in LDS (PolSmem::meta), because whatever a
+// caller holds in registers across a call of a 128-VGPR callee goes through scratch.
+struct RunParams {
+    KParams p;
+    RunArgs ra;
+};
+// Exploration rate of brains-list entry b in this tick: TRAIN launches may carry a schedule (one row per tick of the launch: the
+// reference's brains decay epsilon from episode to episode, D3QN.py:84-89, DQN.py:67-69), else the brain's constant one.  Uniform: scalar loads.
+template <bool TRAIN>
+__device__ inline float run_eps(RunParamsC* ka, int b, int n_brains, const PolSmem& ps)
+{
+    typedef const float __attribute__((address_space(4))) cfloat;
+    if (TRAIN) {
+        const float* es = *(const float* const __attribute__((address_space(4)))*)&ka->ra.eps_sched;
+        if (es) return ((cfloat*)es)[__builtin_amdgcn_readfirstlane(ps.meta[3]) * n_brains + b];
+    }
+    return ((cfloat*)ka->ra.eps)[b];
+}
+
+template <bool FIXED>
+__device__ inline KParams run_params(RunParamsC* ka)
+{
+    // A struct copy out of the CONSTANT address space: every field that is used becomes a scalar load of the kernel-argument
+    // block.  Only the device pass can express it (for the host pass the implicit copy constructor cannot bind an
+    // address-space-qualified reference).
+#if defined(__HIP_DEVICE_COMPILE__)
+    KParams p = *(const KParams __attribute__((address_space(4)))*)&ka->p;
+#else
+    KParams p{};
+#endif
+    if (FIXED) {
+        p.W = kFixW; p.H = kFixH; p.C = kFixC; p.Cp = kFixCp; p.nW = kFixCp / 64;
+        p.cap = kFixCap; p.hash_size = kFixHash; p.hash_mask = kFixHash - 1;
+    }
+    return p;
+}
+// LDS of the multi-tick kernel per workgroup size: T = 1024 runs the 4-wave policy tile (four tile blocks); T = 512 the one-wave
+// tile with the Agent.state rows mirrored in what is left of the CU's 160 KB; T = 256 (several worlds per CU) the one-wave tile
+// reading its rows back from L2.
+constexpr size_t kRunLdsBudget = 160 * 1024;
+__host__ __device__ constexpr int run_groups(int T) { return T == 1024 ? 4 : 0; }
+__host__ __device__ constexpr size_t run_mirror_budget(int T) { return T == 512 ? kRunLdsBudget : 0; }
+__host__ __device__ constexpr int run_cbrains(int T, int n_brains) { return T == 512 ? n_brains : 0; }   // the hand-scheduled tile keeps its epilogue constants in LDS
+template <bool FIXED, int KIND>
+__device__ inline void run_carve(const KParams& p, Smem& s, PolSmem& ps, char* smem_raw, int T)
+{
+    const size_t o0 = FIXED ? carve(s, smem_raw, kFixCp, kFixCap, kFixHash) : carve(s, smem_raw, p.Cp, p.cap, p.hash_size);
+    carve_policy<KIND>(ps, smem_raw, o0, p.cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, p.n_brains));
+}
+
+template <int T, int KIND, bool TRAIN>
+__device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base)
+{
+    constexpr int GROUPS = T / 256;
+    const int tid = rl_tidx(), lane = tid & 63, wave = tid >> 6, grp = wave >> 2, v = wave & 3, j = lane & 31;
+#ifdef RL_PHASE_PROFILE
+    if (p.prof && (int)blockIdx.x == p.prof_world && rl_tidx() == 0) p.prof[100] = (long long)clock64();
+#endif
+    if (wave == 0) {   // rows grouped by brain (ballots; lane b keeps brain b's count), tiles of 32 rows per brain
+        int cnt = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int k = base + lane;
+            const int b = k < n ? s.brain[k] : -1;
+            for (int bb = 0; bb < p.n_brains; ++bb) { const int c = __popcll(__ballot(b == bb)); if (lane == bb) cnt += c; }
+        }
+        const int mine = lane < p.n_brains ? cnt : 0;
+        const int incl = wave_incl_scan(mine);
+        const int tiles = (mine + 31) >> 5;
+        const int tincl = wave_incl_scan(tiles);
+        if (lane < p.n_brains) { ps.bstart[lane] = incl - mine; ps.bcnt[lane] = mine; ps.tstart[lane] = tincl - tiles; }
+        if (lane == 63) ps.meta[0] = tincl;
+        int pos = incl - mine;
+        for (int base = 0; base < n; base += 64) {
+            const int k = base + lane;
+            const int b = k < n ? s.brain[k] : -1;
+            for (int bb = 0; bb < p.n_brains; ++bb) {
+                const unsigned long long m = __ballot(b == bb);
+                const int start = read_lane(pos, bb);
+                if (b == bb) ps.prow[start + __popcll(m & lowmask(lane))] = (short)k;
+                if (lane == bb) pos += __popcll(m);
+            }
+        }
+    }
+    lds_barrier();
+    int ntiles = __builtin_amdgcn_readfirstlane(ps.meta[0]);
+    {   // measurement only (run mask & 4 / & 8): run at most 2 / 1 tiles (results WRONG)
+        const int dbg = *(const int __attribute__((address_space(4)))*)&ka->ra.debug;
+        if (dbg & 4) ntiles = min(ntiles, 2);
+        if (dbg & 8) ntiles = min(ntiles, 1);
+    }
+    for (int t0 = 0; t0 < ntiles; t0 += GROUPS) {   // uniform trip count: every group runs the same barriers
+        const int ti = t0 + grp;
+        const bool have = ti < ntiles;
+        int b = 0;
+        if (have) for (int bb = 1; bb < p.n_brains; ++bb) if (ps.tstart[bb] <= ti && ps.bcnt[bb] > 0) b = bb;
+        b = __builtin_amdgcn_readfirstlane(b);   // uniform per wave: the brain's arguments come by scalar loads
+        const int cntb = have ? ps.bcnt[b] : 0;
+        const int li = have ? (ti - ps.tstart[b]) * 32 + j : 0;
+        const bool valid = have && li < cntb;
+        const int k = (have && cntb > 0) ? ps.prow[ps.bstart[b] + min(li, cntb - 1)] : 0;
+        TileIO io;
+        io.packed = (gfloat*)((const float* const __attribute__((address_space(4)))*)ka->ra.packed)[b];
+        io.obs = obs_rows;
+        io.row = (int64_t)w * p.cap + k;
+        io.valid = valid;
+        io.eps = run_eps<TRAIN>(ka, b, p.n_brains, ps);
+        io.out = nullptr;
+        io.actions = *(int8_t* const __attribute__((address_space(4)))*)&ka->ra.actions;
+        io.seed = p.seed;
+        io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
+        io.key_index = (uint32_t)k;
+        io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
+        io.x_lds_off = -1; io.c_lds_off = -1;
+#ifdef RL_PHASE_PROFILE
+        io.prof = (p.prof && (int)blockIdx.x == p.prof_world) ? p.prof : nullptr;
+        if (io.prof && rl_tidx() == 0) io.prof[101] = (long long)clock64();
+#endif
+        policy_tile<KIND, false, RL_RUN_COHERENT>(io, pol_h<KIND>(ps, grp), pol_aux<KIND>(ps, grp), pol_part<KIND>(ps, grp), lane, v);
+    }
+}
+
+// Rows of a world grouped by brain, 32-row tiles per brain, by ONE wave (ballots; lane b keeps brain b's count): prow / bstart / bcnt /
+// tstart / meta[0].  `brain_of(k)`: brains-list index of list entry k.
+template <typename F>
+__device__ inline void policy_lists_wave0(const KParams& p, PolSmem& ps, int n, int lane, F brain_of)
+{
+    int cnt = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int k = base + lane;
+        const int b = k < n ? brain_of(k) : -1;
+        for (int bb = 0; bb < p.n_brains; ++bb) { const int c = __popcll(__ballot(b == bb)); if (lane == bb) cnt += c; }
+    }
+    const int mine = lane < p.n_brains ? cnt : 0;
+    const int incl = wave_incl_scan(mine);
+    const int tiles = (mine + 31) >> 5;
+    const int tincl = wave_incl_scan(tiles);
+    if (lane < p.n_brains) { ps.bstart[lane] = incl - mine; ps.bcnt[lane] = mine; ps.tstart[lane] = tincl - tiles; }
+    if (lane == 63) ps.meta[0] = tincl;
+    int pos = incl - mine;
+    for (int base = 0; base < n; base += 64) {
+        const int k = base + lane;
+        const int b = k < n ? brain_of(k) : -1;
+        for (int bb = 0; bb < p.n_brains; ++bb) {
+            const unsigned long long m = __ballot(b == bb);
+            const int start = read_lane(pos, bb);
+            if (b == bb) ps.prow[start + __popcll(m & lowmask(lane))] = (short)k;
+            if (lane == bb) pos += __popcll(m);
+        }
+    }
+    // tile descriptors: one LDS read per lane instead of a dependent chain of four at the start of every policy half
+    const int tt = min(read_lane(tincl, 63), kMaxTiles);
+    const int first_tile = tincl - tiles, first_row = incl - mine;
+    for (int e = lane; e < tt * 32; e += 64) {
+        const int t = e >> 5, j = e & 31;
+        int b = 0;
+        for (int bb = 1; bb < p.n_brains; ++bb) if (read_lane(first_tile, bb) <= t && read_lane(mine, bb) > 0) b = bb;
+        const int cntb = __shfl(mine, b), li = (t - __shfl(first_tile, b)) * 32 + j;
+        const int k = ps.prow[__shfl(first_row, b) + min(li, cntb - 1)];
+        ps.trow[e] = (short)(k | (li < cntb ? 0 : 0x8000));
+        if (j == 0) ps.tbrain[t] = b;
+    }
+}
+
+// The policy half for workgroups of at most 512 threads (the tiles below need the 256-VGPR budget).  T = 512, up to four tiles: TWO waves per
+// tile on one SIMD (policy_tile1s<PAIR>); five to eight tiles: one hand-scheduled tile per wave (policy_tile1s); T = 256: one
+// policy_tile1 per wave (no LDS, no barrier inside a tile), wave i takes tiles i, i + 4, ...  Tile rows, validity and brain come from the
+// descriptors wave 0 wrote next to the row lists (policy_lists_wave0).
+template <int T, int KIND, bool TRAIN>
+__device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base, int wave)
+{
+    // (`wave`: the wave's index in the workgroup, uniform -- computed once per launch and kept in an SGPR)
+    const int lane = rl_lane_fresh(), tid = wave * 64 + lane, j = lane & 31;
+#ifdef RL_PHASE_PROFILE
+    const long long t_entry = (long long)clock64();
+#endif
+    // (the per-brain row lists were built by wave 0 while the other waves wrote the previous tick's Agent.state rows: policy_lists_wave0)
+    int ntiles = __builtin_amdgcn_readfirstlane(ps.meta[0]);
+    {   // measurement only (run mask & 4 / & 8): run at most 2 / 1 tiles (results WRONG)
+        const int dbg = *(const int __attribute__((address_space(4)))*)&ka->ra.debug;
+        if (dbg & 4) ntiles = min(ntiles, 2);
+        if (dbg & 8) ntiles = min(ntiles, 1);
+        if (dbg & 16) ntiles = min(ntiles, 3);
+    }
+    const bool mirrored = ps.xmirror != nullptr && __builtin_amdgcn_readfirstlane(ps.meta[4]) != 0;
+    auto tile_io = [&](int ti, TileIO& io) {
+        const int b = __builtin_amdgcn_readfirstlane(ps.tbrain[ti]);
+        const int e = (unsigned short)ps.trow[ti * 32 + j], k = e & 0x7fff;
+        io.packed = (gfloat*)((const float* const __attribute__((address_space(4)))*)ka->ra.packed)[b];
+        io.obs = obs_rows;
+        io.row = (int64_t)w * p.cap + k;
+        io.valid = !(e & 0x8000);
+        io.eps = run_eps<TRAIN>(ka, b, p.n_brains, ps);
+        io.out = nullptr;
+        io.actions = *(int8_t* const __attribute__((address_space(4)))*)&ka->ra.actions;
+        io.seed = p.seed;
+        io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
+        io.key_index = (uint32_t)k;
+        io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
+        io.x_lds_off = (mirrored && k < ps.xrows) ? (int)((char*)(ps.xmirror + k * kXStride) - smem_base) : -1;
+        io.c_lds_off = ps.cconst ? (int)((char*)(ps.cconst + kTileConstFloats * b) - smem_base) : -1;
+#ifdef RL_PHASE_PROFILE
+        io.prof = (p.prof && (int)blockIdx.x == p.prof_world && wave == 0) ? p.prof : nullptr;
+        if (io.prof && lane == 0) { io.prof[100] = t_entry; io.prof[110] = (long long)clock64(); }
+#endif
+    };
+    if (T == 512 && ps.pairv != nullptr && ntiles <= 4 && (size_t)ps.xrows * kXStride * sizeof(float) >= 4 * (size_t)kPairExBytes) {
+        // TWO waves per tile, on the same SIMD (waves i and i + 4): policy_tile1s<PAIR>
+        const int role = __builtin_amdgcn_readfirstlane(wave >> 2), slot = wave & 3;
+        const bool have = slot < ntiles;
+        TileIO io;
+        Tile1Part part;
+        PairLds pl;
+        pl.val = ps.pairv + kPairFloats * slot; pl.pmax = pl.val + 32;
+        pl.ex = (f32x4*)((char*)ps.xmirror + (size_t)kPairExBytes * slot);
+        if (have) {
+            tile_io(slot, io);
+            policy_tile1s<KIND, RL_RUN_COHERENT, true>(io, lane, role, &pl, &part);
+        } else { lds_barrier(); lds_barrier(); }   // (the two exchanges inside the tile)
+#ifdef RL_PHASE_PROFILE
+        if (p.prof && (int)blockIdx.x == p.prof_world && lane == 0) p.prof[116 + wave] = (long long)clock64();   // (128 slots)
+#endif
+        lds_barrier();
+        if (have && role == 0) tile1_finish<KIND>(io, lane, part.head, pl.val[j], part.draw, *(const f32x4*)((const float*)(smem_base + io.c_lds_off) + 768 + 8 + 4 * (lane >> 5)));
+    } else
+    for (int ti = wave; ti < ntiles; ti += T / 64) {
+        TileIO io;
+        tile_io(ti, io);
+        if (T == 512) policy_tile1s<KIND, RL_RUN_COHERENT>(io, lane);
+        else policy_tile1<KIND, RL_RUN_COHERENT, true>(io, lane);
+    }
+#ifdef RL_PHASE_PROFILE
+    if (p.prof && (int)blockIdx.x == p.prof_world && tid == 0) p.prof[111] = (long long)clock64();
+#endif
+    lds_barrier();
+#ifdef RL_PHASE_PROFILE
+    if (p.prof && (int)blockIdx.x == p.prof_world && tid == 0) p.prof[112] = (long long)clock64();
+#endif
+}
+
+// First half of a tick: the policy.  Reads the list length and the Agent.state parity from LDS.
+template <int T, bool FIXED, int KIND, bool TRAIN>
+__device__ __forceinline__ void run_policy_half(RunParamsC* ka, int wave)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const KParams p = run_params<FIXED>(ka);
+    Smem s;
+    PolSmem ps;
+    run_carve<FIXED, KIND>(p, s, ps, smem_raw, T);
+    const int w = blockIdx.x;
+    const int n = __builtin_amdgcn_readfirstlane(ps.meta[1]), cur = __builtin_amdgcn_readfirstlane(ps.meta[2]);
+    const float* obs_in = ((float* const __attribute__((address_space(4)))*)ka->ra.obs)[cur];
+    if (T <= 512) run_policy1<T, KIND, TRAIN>(p, s, ps, ka, w, n, obs_in, smem_raw, wave);
+    else run_policy<T, KIND, TRAIN>(p, s, ps, ka, w, n, obs_in, smem_raw);
+}
+
+// The observation planes of the post-UPDATE grid are the post-step planes with two kinds of cells changed: a corpse's cell holds Food now
+// (environment.py:795-799) and a newborn's cell holds an agent of health 200 that is not dead (h = 1 in either dtype mode, f = 0, no gene
+// entry).  Patching those few cells replaces a sweep over the whole grid.  One exception: np.vectorize infers the health plane's dtype from
+// cell (0,0) (build_planes), so a birth or a death THERE changes every agent cell: the caller then rebuilds the planes (S_PLANES_DIRTY).
+// Runs after the barrier behind reproduce_wave0 (order[] still lists the post-step agents; the newborns occupy slots first_new .. end_new-1).
+template <int T>
+__device__ inline void patch_planes_after_update(const KParams& p, Smem& s, int n1, int first_new, int end_new)
+{
+    const int tid = rl_tidx();
+    bool cell0 = false;
+    for (int k = tid; k < n1; k += T) {
+        const int a = s.order[k];
+        const int fl = s.flags[a], ps = s.pos[a];  // one batch
+        if (fl & RL_F_DEAD) {
+            const int c = (ps & 255) * p.W + (ps >> 8);
+            s.foodv[c] = 0.5f; s.healthv[c] = -1.f; s.genev[c] = -2;
+            cell0 |= c == 0;
+        }
+    }
+    for (int i = first_new + tid; i < end_new; i += T) {
+        const int c = s.tgt[i];
+        s.foodv[c] = 0.f; s.healthv[c] = 1.f; s.genev[c] = -2;
+        cell0 |= c == 0;
+    }
+    if (cell0) s.scal[S_PLANES_DIRTY] = 1;
+}
+
+// Second half: Environment.step + update_env (+ re-generation) out of LDS, then recycle_world.  Same sequence as
+// k_world<T, MODE_TICK, LEAN>; writes Agent.state into ra.obs[cur ^ 1] and advances the loop state in LDS.
+template <int T, bool FIXED, int KIND, bool TRAIN>
+__device__ __forceinline__ void run_tick_body(RunParamsC* ka)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const KParams p = run_params<FIXED>(ka);
+    Smem s;
+    PolSmem ps;
+    run_carve<FIXED, KIND>(p, s, ps, smem_raw, T);
+    const int w = blockIdx.x;
+    const int n0 = __builtin_amdgcn_readfirstlane(ps.meta[1]), cur = __builtin_amdgcn_readfirstlane(ps.meta[2]);
+    const int ticks_done = __builtin_amdgcn_readfirstlane(ps.meta[3]);
+    float* const obs_out = ((float* const __attribute__((address_space(4)))*)ka->ra.obs)[cur ^ 1];
+    const int tid = rl_tidx();
+    constexpr bool kSpec = T == 1024;
+    int nslots = n0;
+    constexpr bool kPlanesEarly = T >= 256;
+    RL_MARK(60);
+    phase_step<T, true, kPlanesEarly, kSpec>(p, s, w, n0);
+    RL_MARK(61);
+    assign_order<T>(p, s, nslots);
+    if (kPlanesEarly) patch_placed_planes(s);
+    const int n1 = s.scal[S_N1];
+    lds_barrier();
+    RL_MARK(62);
+    const bool overlapped = !p.limit_reproduction;
+    const size_t b = (size_t)w * p.cap;
+    auto step_outputs = [&](int t, int nt) {
+        for (int k = t; k < n1; k += nt) {
+            const int a = s.order[k];
+            if (p.so.reward) p.so.reward[b + k] = (float)s.reward[a];
+            if (p.so.done) p.so.done[b + k] = (s.flags[a] & RL_F_DEAD) ? 1 : 0;
+            if (p.so.src) p.so.src[b + k] = (short)a;
+        }
+        if (t == 0 && p.so.n_acted) p.so.n_acted[w] = n0;
+        if (t == 0 && p.so.acted_total && n0) atomicAdd(p.so.acted_total, (unsigned long long)n0);
+    };
+    if (overlapped) {
+        if (tid < 64) {
+            if (!p.static_families) best_agents_wave(s, n1);
+            reproduce_wave0<T, true>(p, s, w, n1, nslots);
+        } else {
+            write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n1, p.so.obs, tid - 64);
+            step_outputs(tid - 64, T - 64);
+        }
+    } else {
+        write_observations<T>(p, s, w, n1, p.so.obs);
+        step_outputs(tid, T);
+    }
+    // Tracker._track_results over the post-step list (environment.py:206-207 -> tracker.py:178-266) on wave 1, behind its share of the
+    // rows: wave 0's serial section (_reproduce) is the longer one of this interval.  Reads only what that section leaves alone.
+    if (TRAIN && T > 64 && p.so.trk_tick && tid >= 64 && tid < 128)
+        track_world_wave0(p, s, w, n1, ps.trk_scr, &ps.trk, ticks_done >= *(const int __attribute__((address_space(4)))*)&ka->ra.trk_skip);
+    lds_barrier();
+    RL_MARK(63);
+    for (int a = tid; a < nslots; a += T) s.src[a] = s.newidx[a];
+    if (!overlapped) lds_barrier();
+    else { const int first_new = nslots; nslots = s.scal[S_NSLOTS]; patch_planes_after_update<T>(p, s, n1, first_new, nslots); }
+    if (!overlapped) phase_update<T, true>(p, s, w, n1, nslots, true);
+    for (int c = tid; c < p.Cp; c += T) {
+        const unsigned long long m = __ballot(s.type[c] == RL_AGENT);
+        if (lane_id() == 0) s.agbits[c >> 6] = m;
+    }
+    for (int i = tid; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
+    lds_barrier();
+    RL_MARK(64);
+    if (tid < 64) scan_order_wave(p, s, tid, S_N2);
+    lds_barrier();
+    RL_MARK(65);
+    int n2 = s.scal[S_N2];
+    int tick_next = s.scal[S_TICK] + 1, epoch_next = s.scal[S_EPOCH];
+    int next_uid = s.scal[S_NEXT_UID], max_gene = s.scal[S_MAX_GENE];
+    const bool refill = p.refill_threshold >= 0 && n2 < p.refill_threshold;
+    if (refill) {
+        const bool prepared = kSpec && s.scal[S_SPEC_DONE] != 0;
+        const uint32_t new_epoch = (uint32_t)epoch_next + 1u;
+        if (prepared) {
+            n2 = apply_spec_refill<T>(p, s, w, new_epoch);
+            const int np2 = (n2 + 63) & ~63;
+            for (int k = tid; k < np2; k += T) hash_insert_wave(s, p.hash_mask, k < n2, k, k < n2 ? s.gene[k] : 0, 1u << 16);
+        } else {
+            n2 = reset_world_lds<T>(p, s, w, new_epoch);
+            rebuild_gene_counts<T>(p, s, n2);
+        }
+        tick_next = 0; epoch_next = (int)new_epoch; next_uid = n2; max_gene = p.n_brains;
+    } else {
+        assign_order<T>(p, s, nslots);
+        const int nsp = (nslots + 63) & ~63;
+        for (int a = tid; a < nsp; a += T) {
+            const int aa = a < nslots ? a : 0;
+            const int ps_ = s.pos[aa], ge = s.gene[aa];
+            const bool on = a < nslots && s.occ[(ps_ & 255) * p.W + (ps_ >> 8)] == a;
+            hash_insert_wave(s, p.hash_mask, on, a, on ? ge : 0, 1u << 16);
+        }
+    }
+    RL_MARK(66);
+    if (refill || !overlapped || s.scal[S_PLANES_DIRTY]) build_planes<T>(p, s);   // (otherwise patched: patch_planes_after_update)
+    lds_barrier();
+    RL_MARK(67);
+    if (p.uo.src)
+        for (int k = tid; k < n2; k += T) p.uo.src[b + k] = refill ? (short)-1 : s.src[s.order[k]];
+    const RecycleRegs rr = recycle_read(s, n2);
+    if (T <= 512) {   // wave 0 prepares the next tick's policy (rows grouped by brain) while the others write the Agent.state rows
+        if (tid < 64) policy_lists_wave0(p, ps, n2, tid, [&](int k) { return s.brain[s.order[k]]; });
+        else write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n2, obs_out, tid - 64, ps.xmirror, ps.xrows);
+    } else
+        write_observations<T>(p, s, w, n2, obs_out, ps.xmirror, ps.xrows);
+    RL_MARK(68);
+    if (tid == 0) { ps.meta[1] = n2; ps.meta[2] = cur ^ 1; ps.meta[3] = ticks_done + 1; ps.meta[4] = ps.xmirror != nullptr; }
+    // (rows the policy will read back from memory must have reached L2 first; with every row mirrored in LDS the stores just drain)
+    recycle_world<T, kSpec>(p, s, n2, tick_next, epoch_next, next_uid, max_gene, ps.xmirror == nullptr || n2 > ps.xrows, rr);
+    RL_MARK(69);
+}
+
+template <int T, int KIND, bool TRAIN>
+__device__ __forceinline__ void run_tick_call_fixed(RunParamsC* ka) { run_tick_body<T, true, KIND, TRAIN>(ka); }
+template <int T, int KIND, bool TRAIN>
+__device__ __forceinline__ void run_tick_call_generic(RunParamsC* ka) { run_tick_body<T, false, KIND, TRAIN>(ka); }
+
+template <int T, bool FIXED, int KIND, bool TRAIN>
+__device__ __forceinline__ void run_load_call(RunParamsC* ka)   // (inlined: load_world reads the kernel-argument segment through the intrinsic)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    typedef const int __attribute__((address_space(4))) cint;
+    const KParams p = run_params<FIXED>(ka);
+    Smem s;
+    PolSmem ps;
+    run_carve<FIXED, KIND>(p, s, ps, smem_raw, T);
+    int n0;
+    load_world<T, (T == 1024)>(p, s, (int)blockIdx.x, n0);
+    // The first tick's policy input: rows written by the previous launch (or the reset / observe call).  With the mirror they are copied
+    // into LDS here, by the whole workgroup with coalesced loads, instead of being fetched row by row by the tile waves (the row phase of
+    // a launch's first tick: 12.2k cycles against 3.5k from the mirror).
+    const int first = *(cint*)&ka->ra.first;
+    const bool preload = ps.xmirror != nullptr && n0 <= ps.xrows;
+    if (preload) {
+        const float* rows = ((float* const __attribute__((address_space(4)))*)ka->ra.obs)[first] + (size_t)blockIdx.x * p.cap * RL_OBS_DIM;
+        for (int i = rl_tidx(); i < n0 * RL_OBS_DIM; i += T) {
+            const int r = i / RL_OBS_DIM;
+            ps.xmirror[r * kXStride + (i - r * RL_OBS_DIM)] = rows[i];
+        }
+    }
+    if (rl_tidx() == 0) { ps.meta[1] = n0; ps.meta[2] = first; ps.meta[3] = 0; ps.meta[4] = preload ? 1 : 0; }
+    if (TRAIN && p.so.trk_tick) {   // the Tracker's running sums live in LDS for the length of the launch
+        const int G = p.static_families ? p.n_brains : 1, t = rl_tidx();
+        const size_t o = (size_t)blockIdx.x * G * RL_TRK_VARS;
+        if (t < G * RL_TRK_VARS) { ps.trk.sum[t] = p.so.trk_sum[o + t]; ps.trk.cnt[t] = p.so.trk_cnt[o + t]; }
+        if (t < 2) ps.trk.pop[t] = p.so.trk_pop[(size_t)blockIdx.x * 3 + 1 + t];
+    }
+    if (T <= 512 && rl_tidx() < 64) policy_lists_wave0(p, ps, n0, rl_tidx(), [&](int k) { return s.brain[k]; });   // (slot == list index after load_world)
+    if (ps.cconst) {   // the brains' epilogue constants (three 128-wide layers x 256 floats) for policy_tile1s
+        const Layout L = layout_of(KIND);
+        for (int i = rl_tidx(); i < kTileConstFloats * p.n_brains; i += T) {
+            const int b = i / kTileConstFloats, j = i - kTileConstFloats * b, layer = j >> 8;
+            gfloat* pk = (gfloat*)((const float* const __attribute__((address_space(4)))*)ka->ra.packed)[b];
+            const int64_t off = layer == 0 ? L.l1 + frag_floats(kInChunks, 4) : layer == 1 ? L.l2a + frag_floats(8, 4) : layer == 2 ? L.l2b + frag_floats(8, 4)
+                              : (j < 768 + 16 ? L.ha : L.hb) + head_consts_off(4) - (j < 768 + 16 ? 768 : 768 + 16);
+            ps.cconst[i] = pk[off + (layer < 3 ? (j & 255) : j)];
+        }
+    }
+    lds_barrier();
+}
+template <int T, bool FIXED, int KIND, bool TRAIN>
+__device__ __forceinline__ void run_store_call(RunParamsC* ka)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const KParams p = run_params<FIXED>(ka);
+    Smem s;
+    PolSmem ps;
+    run_carve<FIXED, KIND>(p, s, ps, smem_raw, T);
+    store_world<T>(p, s, (int)blockIdx.x, ps.meta[1]);
+    if (TRAIN && p.so.trk_tick) {
+        const int G = p.static_families ? p.n_brains : 1, t = rl_tidx();
+        const size_t o = (size_t)blockIdx.x * G * RL_TRK_VARS;
+        if (t < G * RL_TRK_VARS) { p.so.trk_sum[o + t] = ps.trk.sum[t]; p.so.trk_cnt[o + t] = ps.trk.cnt[t]; }
+        if (t < 2) p.so.trk_pop[(size_t)blockIdx.x * 3 + 1 + t] = ps.trk.pop[t];
+    }
+    if (rl_tidx() == 0) { p.st.tick[blockIdx.x] = s.scal[S_TICK]; p.st.epoch[blockIdx.x] = s.scal[S_EPOCH]; p.st.next_uid[blockIdx.x] = s.scal[S_NEXT_UID]; p.st.max_gene[blockIdx.x] = s.scal[S_MAX_GENE]; }
+}
+
+// Kernel body = the policy half (inlined: a kernel saves no registers, and the tile code gets the 128-VGPR budget of a
+// 1024-thread workgroup to itself); the tick half, the initial load and the final store are callees.
+// TRAIN: the launch also serves a training loop -- per-tick exploration rates and the Tracker's statistics (rl_run_ex); the plain
+// inference launch (what bench.py times) does not carry that code.
+template <int T, bool FIXED, int KIND, bool TRAIN>
+__global__ __launch_bounds__(T) void k_run(const RunParams rp)
+{
+    RunParamsC* ka = (RunParamsC*)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef const int __attribute__((address_space(4))) cint;
+    const int n_ticks = *(cint*)&ka->ra.n_ticks;
+    const int dbg = *(cint*)&ka->ra.debug;
+    // Workgroups that start in exact lockstep stay in lockstep for tens of ticks (every world does the same work at the same moment:
+    // 256 CUs ask L2 for the same weight lines, then all write their observation rows), and such ticks are ~3 us slower than those of
+    // drifted-apart worlds: kernel time of a 20-tick launch 545 -> 518 us with the starts spread over 3.75 us (16 steps of 0.25 us; 0.5 / 1 us
+    // steps, 32 or 64 groups give the same), 100- and 500-tick launches unchanged.  run mask & 32 switches it off (measurements).
+    if (!(dbg & 32)) {
+        const long long until = (long long)clock64() + (long long)(blockIdx.x & 15) * 500;
+        while ((long long)clock64() < until) __builtin_amdgcn_s_sleep(2);
+    }
+    run_load_call<T, FIXED, KIND, TRAIN>(ka);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    for (int it = 0; it < n_ticks; ++it) {   // (`it` and the bounds are uniform: SGPRs, which a callee preserves)
+        if (!(dbg & 1)) run_policy_half<T, FIXED, KIND, TRAIN>(ka, wave);
+        if (!(dbg & 2)) {
+            if constexpr (FIXED) run_tick_call_fixed<T, KIND, TRAIN>(ka);
+            else run_tick_call_generic<T, KIND, TRAIN>(ka);
+        }
+    }
+    run_store_call<T, FIXED, KIND, TRAIN>(ka);
+}
+
+}  // namespace
+
+// rl_run: which kernel serves this handle / these brains, or 0
+static int run_kind_of(const rl_brain* brains, int n_brains)
+{
+    if (n_brains < 1 || n_brains > kRunMaxBrains) return -1;
+    bool duel = true;
+    for (int b = 0; b < n_brains; ++b) duel = duel && (brains[b].kind == RL_D3QN || brains[b].kind == RL_PERD3QN);
+    return duel ? RL_PERD3QN : -1;   // (D3QN and PERD3QN are the same network: PERD3QN.py:186-202, D3QN.py:149-165)
+}
+template <int KIND>
+static size_t run_smem_bytes(const rl_world* h, int T)
+{
+    PolSmem ps;
+    return carve_policy<KIND>(ps, nullptr, h->smem_bytes, h->cfg.slot_cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, h->cfg.n_brains));
+}
+// Workgroup size of the multi-tick kernel: 512 threads for few worlds (the one-wave policy tile needs the 256-VGPR budget; the
+// tick half alone would prefer 1024: 10.6 vs 13.1 us at 256 worlds), 256 when there are many worlds (several per CU).
+// RL_WORLD_BLOCK overrides it like for the other world kernels.
+static int run_block(const rl_world* h)
+{
+    const char* env = getenv("RL_WORLD_BLOCK");
+    const int forced = env ? atoi(env) : 0;
+    if (forced == 256 || forced == 512 || forced == 1024) return forced;
+    return h->cfg.n_worlds <= 768 ? 512 : 256;
+}
+int rl_world_run_supported(const rl_world* h, const rl_brain* brains, int n_brains)
+{
+    if (run_kind_of(brains, n_brains) < 0) return 0;
+    const int T = run_block(h);
+    if (h->cfg.slot_cap > T) return 0;
+    return run_smem_bytes<RL_PERD3QN>(h, T) <= 160 * 1024;
+}
+int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n_ticks, int8_t* actions, const rl_step_out* so,
+                        float* const obs[2], int first, int16_t* upd_src, int refill_threshold, int refill_n_agents,
+                        int32_t* refill_count, const float* eps_sched, int trk_skip, hipStream_t st)
+{
+    if (!rl_world_run_supported(h, brains, n_brains)) { rl_set_error("rl_run: unsupported configuration (brain kinds / slot_cap / LDS)"); return RL_E_UNSUPPORTED; }
+    KParams p = make_params(h);
+    set_list_production(h, p, false);   // the row lists describe the state BEFORE this launch
+    p.actions = actions;
+    if (so) p.so = *so;
+    p.uo.src = upd_src; p.uo.obs = obs[first ^ 1];
+    p.refill_threshold = refill_threshold; p.reset_n_agents = refill_n_agents; p.refill_count = refill_count;
+    RunParams rp{};
+    rp.p = p;
+    RunArgs& ra = rp.ra;
+    for (int b = 0; b < n_brains; ++b) { ra.packed[b] = brains[b].packed; ra.eps[b] = brains[b].epsilon; }
+    ra.obs[0] = obs[0]; ra.obs[1] = obs[1]; ra.first = first; ra.n_ticks = n_ticks; ra.actions = actions; ra.eps_sched = eps_sched; ra.trk_skip = trk_skip;
+    ra.debug = g_run_debug;
+    if (g_run_debug) rl_set_error("rl_run: measurement mask %d is set (rl_debug_set_run_mask): the results of this launch are not valid", g_run_debug);
+    const int T = run_block(h);
+    const size_t bytes = run_smem_bytes<RL_PERD3QN>(h, T);
+    const bool fixed = p.W == kFixW && p.H == kFixH && p.cap == kFixCap && p.hash_size == kFixHash && !getenv("RL_WORLD_GENERIC");
+    const bool train = eps_sched != nullptr || p.so.trk_tick != nullptr;
+    const void* fn = nullptr;
+#define RL_RUN_PICK(TT, FX, TR) if (T == TT && fixed == FX && train == TR) fn = (const void*)k_run<TT, FX, RL_PERD3QN, TR>;
+#ifdef RL_RUN_DEV_BUILD   /* tuning builds: only the instantiation bench.py times (compile time) */
+    RL_RUN_PICK(512, true, false)
+#else
+    RL_RUN_PICK(1024, true, false) RL_RUN_PICK(1024, false, false) RL_RUN_PICK(512, true, false) RL_RUN_PICK(512, false, false)
+    RL_RUN_PICK(256, true, false) RL_RUN_PICK(256, false, false)
+    RL_RUN_PICK(1024, true, true) RL_RUN_PICK(1024, false, true) RL_RUN_PICK(512, true, true) RL_RUN_PICK(512, false, true)
+    RL_RUN_PICK(256, true, true) RL_RUN_PICK(256, false, true)
+#endif
+#undef RL_RUN_PICK
+    if (!fn) { rl_set_error("rl_run: no kernel instantiation for T=%d fixed=%d train=%d in this build", T, (int)fixed, (int)train); return RL_E_UNSUPPORTED; }
+    if (bytes > 64 * 1024) {   // opt in to the large dynamic-LDS window (per device copy of the kernel: cheap, done every launch)
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) { rl_set_error("hipFuncSetAttribute(%zu bytes of LDS) failed: %s", bytes, hipGetErrorString(e)); return RL_E_LAUNCH; }
+    }
+    void* kargs[] = {(void*)&rp};
+    const hipError_t le = hipLaunchKernel(fn, dim3(h->cfg.n_worlds), dim3(T), kargs, bytes, st);
+    if (le != hipSuccess) { rl_set_error("run kernel launch failed: %s", hipGetErrorString(le)); return RL_E_LAUNCH; }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rl_set_error("run kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
+    return RL_OK;
+}
+

@@ -1,5 +1,5 @@
 """Replica sharding across the GPUs of a node: worlds are independent, so each rank owns a contiguous
-block of global replica ids and the only collective of a job is one all-reduce of the metric counters."""
+block of global replica ids and the only collective of a job is ONE all-gather of the metric counters (a row per rank)."""
 import torch
 
 
@@ -12,11 +12,17 @@ def shard(n_worlds_total, rank, world_size):
 
 
 def reduce_counters(counters, elapsed_s, dist=None):
-    """counters: 1-D float64 tensor of additive metrics; returns (summed counters, max elapsed) over all ranks.
-    With RCCL (backend 'nccl') the payload is O(100 B): pure latency, one fused buffer, never per step."""
-    t = torch.tensor([elapsed_s], dtype=torch.float64, device=counters.device)
-    c = counters.clone()
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return c, float(t.item())
+    """counters: 1-D float64 tensor of additive metrics; returns (summed counters, max elapsed, per-rank table) over all ranks.
+
+    ONE collective: every rank contributes a row [counters..., elapsed] to an all-gather of O(100 B) per rank (pure latency
+    over xGMI, never per step); sums, the maximum of the elapsed times and the per-rank table (straggler diagnosis: bench.py
+    prints min / max of the per-rank rates) all come out of it.  Runs whenever a process group exists -- also at world size 1,
+    where RCCL executes the same call."""
+    row = torch.cat([counters.to(torch.float64), torch.tensor([elapsed_s], dtype=torch.float64, device=counters.device)])
+    if dist is not None and dist.is_initialized():
+        flat = torch.empty(dist.get_world_size() * row.numel(), dtype=torch.float64, device=row.device)
+        dist.all_gather_into_tensor(flat, row)   # (flat output: the shape every backend accepts)
+        table = flat.view(dist.get_world_size(), row.numel())
+    else:
+        table = row[None, :].clone()
+    return table[:, :-1].sum(0), float(table[:, -1].max().item()), table.cpu()

@@ -82,6 +82,8 @@ class DeviceWorlds:
         self._ticked = False
         self._brains = None
         self._tape_keep = None
+        self._run_pair = None
+        self._eps_keep = None
 
     def __del__(self):
         try:
@@ -260,30 +262,48 @@ class DeviceWorlds:
     def run_supported(self):
         return self._brains is not None and bool(self.lib.rl_run_supported(self.handle, self._brains, self.n_brains))
 
-    def run(self, n_ticks, threshold=-1, n_agents=0):
+    def run(self, n_ticks, threshold=-1, n_agents=0, eps_schedule=None, trk_skip=0):
         """n_ticks x (act() + tick_refill(threshold, n_agents)) -- or + tick() when threshold < 0 -- in ONE launch when the
-        configuration allows it (rl_run: every world stays in LDS between ticks), else the same loop over the two launches.
-        Either way the buffers afterwards hold the last tick's outputs."""
+        configuration allows it (rl_run_ex: every world stays in LDS between ticks; the Tracker accumulators are maintained in
+        the launch when tracking is on), else the same loop over the two launches.  Either way the buffers afterwards hold the
+        last tick's outputs.
+        eps_schedule: optional [n_ticks, n_brains] float32 (host array or device tensor) -- the brains' exploration rate in every
+        tick (the reference's brains decay epsilon per episode); None = the rates given to set_brains().
+        trk_skip: the Tracker's running sums leave out the first trk_skip ticks (episode 0, tracker.py:279-282)."""
         if self._brains is None:
             raise _lib.ReinLifeHipError("set_brains() was not called")
         if n_ticks <= 0:
             return
+        if eps_schedule is not None:
+            eps_schedule = torch.as_tensor(eps_schedule, dtype=torch.float32).to(self.device).contiguous()
+            assert tuple(eps_schedule.shape) == (n_ticks, self.n_brains)
         # (with many worlds per GPU -- several per CU -- the two stand-alone launches are faster: 8.0e8 against 6.1e8 agent-steps/s
         # at 1024 worlds, the cross-world policy tiles waste fewer rows; RL_RUN_ALWAYS=1 forces the single launch)
         fused = self.run_supported() and (self.R <= 768 or bool(os.environ.get("RL_RUN_ALWAYS")))
-        if self.tracking or self.replays is not None or not fused:
-            for _ in range(n_ticks):
+        if self.replays is not None or not fused:
+            for t in range(n_ticks):
+                if eps_schedule is not None:
+                    self._set_epsilons(eps_schedule[t].tolist())
                 self.act()
                 if threshold >= 0:
                     self.tick_refill(threshold, n_agents)
                 else:
                     self.tick()
+                if self.tracking and t + 1 == trk_skip:
+                    self.reset_tracking()
             return
-        pair = (C.c_void_p * 2)(_ptr(self._obs2[0]), _ptr(self._obs2[1]))
-        _lib.check(self.lib.rl_run(self.handle, self._brains, self.n_brains, n_ticks, _ptr(self.actions), C.byref(self._step_out), pair,
-                                   self._cur, _ptr(self.src2), threshold, n_agents, _ptr(self.refill_count), self._stream()), "rl_run")
+        if self._run_pair is None:
+            self._run_pair = (C.c_void_p * 2)(_ptr(self._obs2[0]), _ptr(self._obs2[1]))
+        opts = _lib.RunOpts(threshold, n_agents, _ptr(self.refill_count), _ptr(eps_schedule), trk_skip)
+        _lib.check(self.lib.rl_run_ex(self.handle, self._brains, self.n_brains, n_ticks, _ptr(self.actions), C.byref(self._step_out),
+                                      self._run_pair, self._cur, _ptr(self.src2), C.byref(opts), self._stream()), "rl_run_ex")
+        self._eps_keep = eps_schedule   # the launch reads it asynchronously
         self._cur = (self._cur + n_ticks) & 1
         self._ticked = True
+
+    def _set_epsilons(self, eps):
+        for b, e in enumerate(eps):
+            self._brains[b].epsilon = float(e)
 
     def observe(self):
         _lib.check(self.lib.rl_observe(self.handle, _ptr(self.obs2), self._stream()), "rl_observe")
@@ -292,6 +312,10 @@ class DeviceWorlds:
     def reset_synthetic(self, n_agents):
         _lib.check(self.lib.rl_reset_synthetic(self.handle, n_agents, _ptr(self.obs2), self._stream()),
                    "rl_reset_synthetic")
+
+    def reset_families(self):
+        """Environment.reset() for every world on the device: one agent per brain (gene = its index) at random cells."""
+        _lib.check(self.lib.rl_reset_families(self.handle, _ptr(self.obs2), self._stream()), "rl_reset_families")
 
     def refill(self, threshold, n_agents):
         _lib.check(self.lib.rl_refill(self.handle, threshold, n_agents, _ptr(self.obs2), _ptr(self.refill_count),

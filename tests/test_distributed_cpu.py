@@ -34,8 +34,8 @@ def _worker(rank, world_size, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     first, count = rd.shard(TOTAL, rank, world_size)
     ow, acted = _run(first, count)
-    c, tmax = rd.reduce_counters(torch.tensor([float(acted), float(count)], dtype=torch.float64), 0.5 + rank, dist)
-    q.put((rank, first, count, ow.s["cell_type"].copy(), ow.s["a_health"].copy(), ow.s["n_agents"].copy(), c.tolist(), tmax))
+    c, tmax, table = rd.reduce_counters(torch.tensor([float(acted), float(count)], dtype=torch.float64), 0.5 + rank, dist)
+    q.put((rank, first, count, ow.s["cell_type"].copy(), ow.s["a_health"].copy(), ow.s["n_agents"].copy(), c.tolist(), tmax, table.numpy(), acted))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -55,8 +55,14 @@ def test_replica_sharding_is_layout_independent_and_counters_reduce():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, first, count, cells, health, n, c, tmax in res:
+    for rank, first, count, cells, health, n, c, tmax, table, acted in res:
         assert np.array_equal(cells, ref.s["cell_type"][first:first + count])
         assert np.array_equal(n, ref.s["n_agents"][first:first + count])
         assert np.array_equal(health, ref.s["a_health"][first:first + count])
         assert c == [float(ref_acted), float(TOTAL)] and tmax == 1.5
+        # the ONE collective also hands every rank the per-rank rows (bench.py's straggler report): [acted, count, elapsed] of rank r
+        assert table.shape == (2, 3) and table[rank].tolist() == [float(acted), float(count), 0.5 + rank]
+    assert sum(r[-1] for r in res) == ref_acted
+    # without a process group the same call degenerates to the caller's own row
+    c, tmax, table = rd.reduce_counters(torch.tensor([3.0, 4.0], dtype=torch.float64), 0.25, None)
+    assert c.tolist() == [3.0, 4.0] and tmax == 0.25 and table.shape == (1, 3)

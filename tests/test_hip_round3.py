@@ -1,0 +1,296 @@
+"""GPU, round 3: the multi-tick launch as a TRAINING loop (rl_run_ex: per-tick epsilon schedule + Tracker statistics inside the
+launch), trainer() / tester() / Environment.run on top of it, parity at the benched size (256 worlds), SURVEY C2 (step-only, 20
+seeds x 200 ticks against the oracle), rl_reset_families, and the host mirrors' action semantics."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from test_hip_round2 import _cmp_rows, _cmp_state, _run_pair, _same_device_state, _weights  # noqa: E402
+
+
+def _same_tracker(a, b, tag):
+    for name in ("trk_tick", "trk_sum", "trk_cnt", "trk_pop"):
+        x, y = getattr(a, name).cpu().numpy(), getattr(b, name).cpu().numpy()
+        assert np.array_equal(x, y, equal_nan=True), (tag, name, np.argwhere(x != y)[:4])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rl_run_ex: epsilon schedule + Tracker accumulators in the launch
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("static", [True, False], ids=["static", "nonstatic"])
+@pytest.mark.parametrize("block", [None, 256, 1024], ids=["T512", "T256", "T1024"])
+def test_training_launch_equals_the_two_launch_loop(static, block, monkeypatch):
+    """rl_run_ex with a per-tick epsilon schedule and the Tracker accumulators == n x (set epsilons, rl_policy_act, rl_tick_refill
+    with the Tracker outputs): worlds, observations, actions and trk_tick / trk_sum / trk_cnt / trk_pop, bit for bit, over launches
+    of 1 / 3 / 20 / 37 ticks, with the caller zeroing the running sums between some of them (interval boundaries)."""
+    if block:
+        monkeypatch.setenv("RL_WORLD_BLOCK", str(block))
+    monkeypatch.setenv("RL_POLICY_VARIANT", "wave" if block != 1024 else "nsplit")
+    (fused, loop), *_ = _run_pair(14, static, 4242)
+    for dw in (fused, loop):
+        dw.enable_tracking(True)
+    assert fused.run_supported()
+    rng = np.random.RandomState(7)
+    done = 0
+    for chunk in (1, 3, 20, 37, 1, 20):
+        eps = rng.uniform(0.0, 0.6, size=(chunk, 2)).astype(np.float32)
+        eps[:, 0] *= (rng.uniform(size=chunk) < 0.5)          # brain 0 is greedy in about half of the ticks
+        fused.run(chunk, 70, 100, eps_schedule=eps)
+        for t in range(chunk):
+            loop._set_epsilons(eps[t].tolist())
+            loop.act(); loop.tick_refill(70, 100)
+        done += chunk
+        fused.check_error_flag(); loop.check_error_flag()
+        tag = "after %d ticks" % done
+        _same_device_state(fused, loop, tag)
+        acted = fused.n_acted.cpu().numpy()
+        _cmp_rows(fused.actions.cpu().numpy(), loop.actions.cpu().numpy(), acted, tag + " actions")
+        _same_tracker(fused, loop, tag)
+        assert int(fused.acted_total.item()) == int(loop.acted_total.item())
+        if chunk == 20:
+            fused.reset_tracking(); loop.reset_tracking()
+    assert float(fused.trk_cnt.sum().item()) > 0 and int(fused.refill_count.item()) > 0
+
+
+def test_training_launch_tracker_matches_the_oracle():
+    """The Tracker values of rl_run_ex against the ORACLE's (tracker.py:178-266 restated sequentially), tick by tick."""
+    from oracle import oracle as orc
+    (fused, _), wts, names, eps, cfg = _run_pair(10, True, 99)
+    fused.enable_tracking(True)
+    ow = orc.OracleWorlds(n_worlds=10, seed=99, world_base=3, **cfg)
+    ow.reset_synthetic(100)
+    for t in range(30):
+        fused.run(1, 70, 100)
+        ow.step(fused.actions.cpu().numpy().copy())
+        assert np.array_equal(fused.trk_tick.cpu().numpy(), ow.trk_tick), t
+        assert np.array_equal(fused.trk_sum.cpu().numpy(), ow.trk_sum) and np.array_equal(fused.trk_cnt.cpu().numpy(), ow.trk_cnt), t
+        assert np.array_equal(fused.trk_pop.cpu().numpy(), ow.trk_pop), t
+        ow.update(); ow.refill(70, 100)
+        _cmp_state(fused, ow, "tick %d" % t)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# trainer() / tester() / Environment.run on the multi-tick launch
+# ---------------------------------------------------------------------------------------------------------------------
+def _brains(seed, training=True):
+    import torch
+    from reinlife_amd import Models
+    torch.manual_seed(seed)
+    return [Models.PERD3QN(training=training), Models.D3QN(training=training)]
+
+
+@pytest.mark.parametrize("static", [True, False], ids=["static", "nonstatic"])
+def test_trainer_fused_loop_equals_the_tick_by_tick_loop(static, monkeypatch):
+    """trainer(..., fused=True) -- whole Tracker intervals per launch -- against fused=False (act / step / update_env launches and a
+    host round trip per tick, the round-2 loop): identical Tracker.results, identical final worlds, identical brain epsilons.
+    training=True: the brains' epsilon decays per episode (x 0.99), i.e. the launch runs on a schedule."""
+    from reinlife_amd.Helpers.trainer import trainer
+    monkeypatch.setenv("RL_POLICY_VARIANT", "wave")   # the stand-alone policy launch with rl_run's tile arithmetic
+    proto = _brains(5)
+    envs = []
+    for fused in (True, False):
+        brains = copy.deepcopy(proto)
+        with pytest.warns(UserWarning):
+            env = trainer(brains, n_episodes=130, update_interval=25, print_results=False, static_families=static, save=False,
+                          n_worlds=6, seed=77, fused=fused)
+        envs.append(env)
+    a, b = envs
+    assert a.tracker.results == b.tracker.results or _results_equal(a.tracker.results, b.tracker.results)
+    assert len(a.tracker.results["Avg Number of Populations"]) == 5            # 130 // 25 closed intervals
+    _same_device_state(a.worlds, b.worlds, "final worlds")
+    assert [br.epsilon for br in a.brains] == [br.epsilon for br in b.brains] and a.brains[0].epsilon < 0.9 * 0.99 ** 129
+    assert a.loop_seconds > 0 and b.loop_seconds > 0
+    # the host view is built on demand and agrees
+    assert [(v.i, v.j, v.gene, v.health, v.age) for v in a.agents] == [(v.i, v.j, v.gene, v.health, v.age) for v in b.agents]
+    assert np.array_equal(a.grid, b.grid) and a.max_gene == b.max_gene
+
+
+def _results_equal(x, y):
+    """Tracker.results with nan-aware float comparison (an interval without a valid tick aggregates to nan, like np.mean([]))."""
+    if isinstance(x, dict):
+        return set(x) == set(y) and all(_results_equal(x[k], y[k]) for k in x)
+    return np.array_equal(np.asarray(x, np.float64), np.asarray(y, np.float64), equal_nan=True)
+
+
+def test_environment_run_is_lazy_and_splits_at_tracker_boundaries():
+    """Environment.run: arbitrary (n_epi, n_ticks) calls close the same Tracker intervals as the per-tick loop; nothing is copied to the
+    host until env.agents / env.grid are read."""
+    from reinlife_amd.World.environment import Environment
+    proto = _brains(9)
+    res = []
+    for pieces in ([(0, 61)], [(0, 1), (1, 7), (8, 30), (38, 23)]):
+        with pytest.warns(UserWarning):
+            env = Environment(width=30, height=30, brains=copy.deepcopy(proto), max_agents=100, update_interval=20, print_results=False,
+                              n_worlds=4, seed=3, rng="philox")
+        env.reset()
+        for n_epi, k in pieces:
+            env.run(n_epi, k)
+            assert env._mirrors == {} and env._grid is None
+        res.append(env)
+    assert _results_equal(res[0].tracker.results, res[1].tracker.results)
+    assert len(res[0].tracker.results["Avg Population Size"][0]) == 3
+    _same_device_state(res[0].worlds, res[1].worlds, "pieces")
+    assert len(res[0].agents) == int(res[0].worlds.s["n_agents"][0].item()) and res[0]._mirrors != {}
+
+
+def test_tester_runs_one_launch_per_frame():
+    from reinlife_amd.Helpers.tester import tester
+    frames = []
+    env = tester(_brains(2, training=False), n_steps=5, n_worlds=3, seed=1, on_frame=lambda e: frames.append(e.frame.copy()))
+    assert len(frames) == 5 and frames[0].shape == (30 * 24, 30 * 24, 3) and env.loop_seconds is None
+    assert int(env.worlds.s["tick"][0].item()) == 5
+
+
+def test_replica_mirror_holds_the_policys_actions_after_act():
+    """env.act(); env.agents_of(w) must show the actions the policy chose for this tick, and overriding ONE of them
+    must leave the others as chosen."""
+    from reinlife_amd.World.environment import Environment
+    with pytest.warns(UserWarning):
+        env = Environment(width=30, height=30, brains=_brains(4), max_agents=100, print_results=False, n_worlds=3, seed=8, rng="philox")
+    env.reset()
+    env.run(0, 12)                      # a few agents per world by now
+    early = env.agents_of(2)            # built BEFORE act(): must be refreshed by it
+    env.act(12)
+    chosen = env.worlds.actions.cpu().numpy().copy()
+    for w in (1, 2):
+        views = env.agents_of(w)
+        assert [v.action for v in views] == chosen[w, : len(views)].tolist(), w
+    assert early is env.agents_of(2)
+    views = env.agents_of(1)
+    other = (chosen[1, 0] + 3) % 8
+    views[0].action = int(other)
+    env.step()
+    taken = env.worlds.s["a_action"].cpu().numpy()
+    src = env.worlds.src1.cpu().numpy()
+    n1 = int(env.worlds.s["n_agents"][1].item())
+    want = chosen[1].copy(); want[0] = other
+    assert np.array_equal(taken[1, :n1], want[src[1, :n1]])          # every other agent acted as the policy chose
+    n2 = int(env.worlds.s["n_agents"][2].item())
+    assert np.array_equal(taken[2, :n2], chosen[2][src[2, :n2]])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Environment.reset on the device
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_brains,shape", [(2, (30, 30)), (5, (12, 9)), (8, (30, 20))])
+def test_reset_families_matches_the_oracle(n_brains, shape):
+    from oracle import oracle as orc
+    from reinlife_amd.worlds import DeviceWorlds
+    cfg = dict(width=shape[0], height=shape[1], max_agents=100, n_brains=n_brains, static_families=True)
+    dw = DeviceWorlds(n_worlds=40, seed=12, world_base=9, **cfg)
+    ow = orc.OracleWorlds(n_worlds=40, seed=12, world_base=9, **cfg)
+    dw.reset_families(); ow.reset_families()
+    dw.check_error_flag()
+    _cmp_state(dw, ow, "reset_families")
+    _cmp_rows(dw.obs_state().cpu().numpy(), ow.obs2, ow.s["n_agents"], "obs")
+    genes = dw.s["a_gene"].cpu().numpy()[:, :n_brains]
+    assert (dw.s["n_agents"].cpu().numpy() == n_brains).all() and (np.sort(genes, axis=1) == np.arange(n_brains)).all()
+    assert len({tuple(g) for g in genes}) > 1          # which brain lands where differs from world to world
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# parity at the benched size (BASELINE configs[3]: 256 worlds, two greedy PERD3QN brains, refill below 70) and SURVEY C2
+# ---------------------------------------------------------------------------------------------------------------------
+def _bench_worlds(seed=20260928):
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench.make_worlds(argparse.Namespace(worlds=256, workload="c4", seed=seed), 0, "cuda:0")
+
+
+def test_benched_size_multi_tick_launch_tracks_the_oracle_for_300_ticks():
+    """The instantiation bench.py times (k_run<512, fixed> on 256 workgroups) against the oracle fed the chosen actions: 300 launches
+    of one tick; integer state every tick, both observation passes and every per-agent output every 10 ticks."""
+    from oracle import oracle as orc
+    dw = _bench_worlds()
+    ow = orc.OracleWorlds(n_worlds=256, seed=20260928, width=30, height=30, max_agents=100, n_brains=2, static_families=True)
+    ow.reset_synthetic(100)
+    assert dw.run_supported()
+    steps = 0
+    for t in range(300):
+        n0 = ow.s["n_agents"].copy()
+        dw.run(1, 70, 100)
+        acts = dw.actions.cpu().numpy()
+        ow.step(acts)
+        full = t % 10 == 9
+        if full:
+            n1 = ow.s["n_agents"].copy()
+            _cmp_rows(dw.obs_state_prime().cpu().numpy(), ow.obs1, n1, "tick %d obs1" % t)
+            _cmp_rows(dw.reward.cpu().numpy(), ow.reward, n1, "tick %d reward" % t)
+            _cmp_rows(dw.done.cpu().numpy(), ow.done, n1, "tick %d done" % t)
+            _cmp_rows(dw.src1.cpu().numpy(), ow.src1, n1, "tick %d src1" % t)
+        ow.update(); ow.refill(70, 100)
+        assert np.array_equal(dw.n_acted.cpu().numpy(), n0)
+        steps += int(n0.sum())
+        for key in ("cell_type", "n_agents", "tick", "epoch", "next_uid"):
+            assert np.array_equal(dw.s[key].cpu().numpy().reshape(ow.s[key].shape), ow.s[key]), (t, key)
+        if full:
+            dw.check_error_flag()
+            _cmp_state(dw, ow, "tick %d" % t)
+            _cmp_rows(dw.obs_state().cpu().numpy(), ow.obs2, ow.s["n_agents"], "tick %d obs2" % t)
+    assert steps > 6_000_000 and int(dw.acted_total.item()) == steps and int(dw.refill_count.item()) > 500
+
+
+def test_benched_size_one_launch_of_300_ticks_equals_300_launches_of_one():
+    a, b = _bench_worlds(), _bench_worlds()
+    a.run(300, 70, 100)
+    for _ in range(300):
+        b.run(1, 70, 100)
+    a.check_error_flag(); b.check_error_flag()
+    _same_device_state(a, b, "300 ticks")
+    assert int(a.acted_total.item()) == int(b.acted_total.item()) and int(a.refill_count.item()) == int(b.refill_count.item()) > 500
+    acted = a.n_acted.cpu().numpy()
+    _cmp_rows(a.actions.cpu().numpy(), b.actions.cpu().numpy(), acted, "actions")
+    for name in ("reward", "done", "src1", "src2"):
+        assert np.array_equal(getattr(a, name).cpu().numpy(), getattr(b, name).cpu().numpy()), name
+    assert np.array_equal(a.obs_state_prime().cpu().numpy(), b.obs_state_prime().cpu().numpy())
+
+
+def test_c2_step_only_twenty_seeds_two_hundred_ticks_against_the_oracle():
+    """30x30, 100 agents, uniformly random actions, Environment.step (and update_env, so that the world goes on) against
+    the CPU restatement: 20 seeds x 200 ticks, integer state bit-exact after EVERY step and update, rewards / observations (float32
+    identical) every 20 ticks and at the end."""
+    from oracle import oracle as orc
+    from reinlife_amd.worlds import DeviceWorlds
+    cfg = dict(width=30, height=30, max_agents=100, n_brains=2, static_families=True, limit_reproduction=False, incentivize_killing=True)
+    agent_steps = 0
+    for seed in range(20):
+        dw = DeviceWorlds(n_worlds=1, seed=1000 + seed, **cfg)
+        ow = orc.OracleWorlds(n_worlds=1, seed=1000 + seed, **cfg)
+        dw.reset_synthetic(100); ow.reset_synthetic(100)
+        rng = np.random.RandomState(seed)
+        for t in range(200):
+            acts = rng.randint(0, 8, size=(1, dw.cap)).astype(np.int8)
+            agent_steps += int(ow.s["n_agents"][0])
+            dw.step(acts); ow.step(acts)
+            full = t % 20 == 19 or t == 199
+            keys = list(dw.s) if full else ("cell_type", "n_agents", "a_health", "a_age", "a_flags", "a_i", "a_j")
+            n1 = ow.s["n_agents"]
+            for key in keys:
+                got, want = dw.s[key].cpu().numpy(), ow.s[key]
+                if key.startswith("a_"):
+                    assert np.array_equal(got[0, : n1[0]], want[0, : n1[0]]), (seed, t, "step", key)
+                else:
+                    assert np.array_equal(got.reshape(want.shape), want), (seed, t, "step", key)
+            if full:
+                _cmp_rows(dw.obs_state_prime().cpu().numpy(), ow.obs1, n1, "seed %d tick %d obs1" % (seed, t))
+                _cmp_rows(dw.reward.cpu().numpy(), ow.reward, n1, "reward")
+                _cmp_rows(dw.done.cpu().numpy(), ow.done, n1, "done")
+            dw.update(); ow.update()
+            n2 = ow.s["n_agents"]
+            for key in keys:
+                got, want = dw.s[key].cpu().numpy(), ow.s[key]
+                if key.startswith("a_"):
+                    assert np.array_equal(got[0, : n2[0]], want[0, : n2[0]]), (seed, t, "update", key)
+                else:
+                    assert np.array_equal(got.reshape(want.shape), want), (seed, t, "update", key)
+            if full:
+                _cmp_rows(dw.obs_state().cpu().numpy(), ow.obs2, n2, "seed %d tick %d obs2" % (seed, t))
+        dw.check_error_flag()
+    assert agent_steps > 20 * 200 * 10

@@ -75,4 +75,7 @@ for name, d in res.items():
         summary["hbm_write_bytes_per_tick"] = wr
         summary["hbm_bytes_per_tick"] = rd + wr
         print("multi-tick launch: read %.2f MB + write %.2f MB = %.2f MB per tick (calibrated, %d ticks per launch)" % (rd / 1e6, wr / 1e6, (rd + wr) / 1e6, ticks_per_launch))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reinlife_amd import build as _build  # noqa: E402
+summary["kernel_src_sha16"] = _build.source_hash()   # bench.py reports `traffic` only while the kernel sources still hash to this
 json.dump(summary, open(os.path.join(out, "tick_traffic.json"), "w"), indent=1)

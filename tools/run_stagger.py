@@ -1,11 +1,11 @@
-"""Kernel time (HIP events) of rl_run launches of 1 .. 500 ticks with and without the staggered workgroup starts (RL_RUN_DEBUG & 32 switches
+"""Kernel time (HIP events) of rl_run launches of 1 .. 500 ticks with and without the staggered workgroup starts (rl_debug_set_run_mask & 32 switches
 them off; tuning; GPU)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 args = __import__("argparse").Namespace(worlds=256, workload="c4", seed=1)
 for dbg in ("32", "0"):
-    os.environ["RL_RUN_DEBUG"] = dbg
+    __import__("reinlife_amd._lib", fromlist=["lib"]).lib().rl_debug_set_run_mask(int(dbg))
     a = bench.make_worlds(args, 0, "cuda:0")
     a.run(300, 70, 100); torch.cuda.synchronize()
     for n in (1, 5, 20, 100, 500):

@@ -1,11 +1,11 @@
-"""rl_run per-tick time with the policy limited to 1 / 2 / 3 tiles per world (RL_RUN_DEBUG bits 8 / 4 / 16; tuning only; GPU)."""
+"""rl_run per-tick time with the policy limited to 1 / 2 / 3 tiles per world (rl_debug_set_run_mask bits 8 / 4 / 16; tuning only; GPU)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 args = __import__("argparse").Namespace(worlds=256, workload="c4", seed=1)
 for dbg, what in (("0", "all tiles"), ("16", "<= 3 tiles"), ("4", "<= 2 tiles"), ("8", "1 tile"), ("1", "no policy")):
-    os.environ["RL_RUN_DEBUG"] = dbg
+    __import__("reinlife_amd._lib", fromlist=["lib"]).lib().rl_debug_set_run_mask(int(dbg))
     a = bench.make_worlds(args, 0, "cuda:0")
     a.run(300, 70, 100); torch.cuda.synchronize()
     t0 = time.perf_counter(); a.run(300, 70, 100); torch.cuda.synchronize(); dt = time.perf_counter() - t0
