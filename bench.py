@@ -327,12 +327,15 @@ def main():
             if debug:
                 _lib.lib().rl_debug_set_run_mask(int(debug))   # explicit measurement switch of THIS process (never an environment variable)
             try:
-                dw.run(20, 70, 100)
-                before = int(dw.acted_total.item())
+                # two launches back to back in stream order, the second one between the events: the first keeps the chip at its
+                # working clocks (a launch that follows a host round trip starts on a chip that has begun to clock down:
+                # tools/launch_cost.py, "after a 2 ms sleep"), and nothing but the kernel lies between the events
+                dw.run(n, 70, 100)
+                before = dw.acted_total.clone()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); dw.run(n, 70, 100); e1.record()
                 torch.cuda.synchronize()
-                return e0.elapsed_time(e1) * 1e-3 / n, (int(dw.acted_total.item()) - before) / n
+                return e0.elapsed_time(e1) * 1e-3 / n, (int(dw.acted_total.item()) - int(before.item())) / n
             finally:
                 _lib.lib().rl_debug_set_run_mask(0)
         t_all, per_tick = timed_run(300)

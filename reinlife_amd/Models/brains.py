@@ -61,7 +61,8 @@ class _HipBrain(BasicBrain):
         """Packed MFMA layout of the current parameters on `device`, cached.  The cache key carries every parameter's storage
         address and in-place version counter, so load_state_dict(), optimizer steps, target/eval syncs or a replaced module
         repack automatically at the next use."""
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self._net().state_dict().values())
+        net = self._net()   # (parameters() + buffers(), not state_dict(): no per-call detach of every tensor -- this runs once per launch)
+        key = (str(device), id(net)) + tuple((p.data_ptr(), p._version) for p in net.parameters()) + tuple((b.data_ptr(), b._version) for b in net.buffers())
         if getattr(self, "_packed_key", None) != key:
             from ..worlds import pack_brain_weights
             self._packed = pack_brain_weights(self.kind, self.state_dict_flat(), device)

@@ -7,7 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 PROFILE = bool(os.environ.get("RL_PHASE_PROFILE"))  # tuning build with in-kernel phase stamps
-LIB_PATH = os.path.join(LIB_DIR, "libreinlife_hip_prof.so" if PROFILE else "libreinlife_hip.so")
+# A/B builds (tuning): RL_LIB_TAG=x RL_EXTRA_HIPCC_FLAGS=-D... -> lib/libreinlife_hip_x.so next to the product; load it with REINLIFE_HIP_LIB
+TAG = "_prof" if PROFILE else ("_" + os.environ["RL_LIB_TAG"] if os.environ.get("RL_LIB_TAG") else "")
+LIB_PATH = os.path.join(LIB_DIR, "libreinlife_hip%s.so" % TAG)
 SOURCES = ["rl_world.hip", "rl_run.hip", "rl_policy.hip", "rl_capi.hip"]
 HEADERS = ["rl_common.h", "rl_policy_dev.h", "rl_world_dev.h", os.path.join("..", "..", "include", "reinlife_hip.h")]
 # -ffp-contract=off: the world kernels' float64 reward / fitness arithmetic must round exactly like the CPU path
@@ -40,7 +42,7 @@ def build(force=False, verbose=False):
     objs, jobs = [], []
     for src in SOURCES:   # the translation units compile side by side (rl_world.hip alone takes over a minute)
         sp = os.path.join(CSRC, src)
-        obj = os.path.join(LIB_DIR, src.replace(".hip", "_prof.o" if PROFILE else ".o"))
+        obj = os.path.join(LIB_DIR, src.replace(".hip", TAG + ".o"))
         objs.append(obj)
         if force or _stale(obj, [sp] + hdrs):
             cmd = [hipcc] + FLAGS + (["-DRL_PHASE_PROFILE"] if PROFILE else []) + ["-c", sp, "-o", obj]

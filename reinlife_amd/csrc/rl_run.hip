@@ -655,20 +655,46 @@ __global__ __launch_bounds__(T) void k_run(const RunParams rp)
     // 256 CUs ask L2 for the same weight lines, then all write their observation rows), and such ticks are ~3 us slower than those of
     // drifted-apart worlds: kernel time of a 20-tick launch 545 -> 518 us with the starts spread over 3.75 us (16 steps of 0.25 us; 0.5 / 1 us
     // steps, 32 or 64 groups give the same), 100- and 500-tick launches unchanged.  run mask & 32 switches it off (measurements).
+#ifdef RL_PHASE_PROFILE
+#define RL_KMARK(i) do { long long* pf_ = *(long long* const __attribute__((address_space(4)))*)&ka->p.prof; \
+        if (pf_ && (int)blockIdx.x == *(cint*)&ka->p.prof_world && threadIdx.x == 0) RL_G(pf_)[i] = (long long)clock64(); } while (0)
+#else
+#define RL_KMARK(i) do { } while (0)
+#endif
+    RL_KMARK(70);
+#ifndef RL_STAGGER_BEFORE_LOAD
+    // (the delay runs next to the world's load: a workgroup whose load takes longer than its delay does not wait at all)
+    const long long t_entry = (long long)clock64();
+    run_load_call<T, FIXED, KIND, TRAIN>(ka);
+    RL_KMARK(71);
+    if (!(dbg & 32)) {
+        const long long until = t_entry + (long long)(blockIdx.x & 15) * 500;
+        while ((long long)clock64() < until) __builtin_amdgcn_s_sleep(2);
+    }
+#else
     if (!(dbg & 32)) {
         const long long until = (long long)clock64() + (long long)(blockIdx.x & 15) * 500;
         while ((long long)clock64() < until) __builtin_amdgcn_s_sleep(2);
     }
+    RL_KMARK(71);
     run_load_call<T, FIXED, KIND, TRAIN>(ka);
+#endif
+    RL_KMARK(72);
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     for (int it = 0; it < n_ticks; ++it) {   // (`it` and the bounds are uniform: SGPRs, which a callee preserves)
         if (!(dbg & 1)) run_policy_half<T, FIXED, KIND, TRAIN>(ka, wave);
+        if (it == 0) RL_KMARK(73);
         if (!(dbg & 2)) {
             if constexpr (FIXED) run_tick_call_fixed<T, KIND, TRAIN>(ka);
             else run_tick_call_generic<T, KIND, TRAIN>(ka);
         }
+        if (it == 0) RL_KMARK(74);
+        if (it == 1) RL_KMARK(75);
     }
+    RL_KMARK(76);
     run_store_call<T, FIXED, KIND, TRAIN>(ka);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RL_KMARK(77);
 }
 
 }  // namespace

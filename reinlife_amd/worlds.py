@@ -275,7 +275,10 @@ class DeviceWorlds:
         if n_ticks <= 0:
             return
         if eps_schedule is not None:
-            eps_schedule = torch.as_tensor(eps_schedule, dtype=torch.float32).to(self.device).contiguous()
+            if not torch.is_tensor(eps_schedule) or not eps_schedule.is_cuda:   # host array: pinned staging + asynchronous upload
+                host = torch.as_tensor(np.ascontiguousarray(eps_schedule, dtype=np.float32)) if not torch.is_tensor(eps_schedule) else eps_schedule.float()
+                eps_schedule = host.pin_memory().to(self.device, non_blocking=True)
+            eps_schedule = eps_schedule.to(torch.float32).contiguous()
             assert tuple(eps_schedule.shape) == (n_ticks, self.n_brains)
         # (with many worlds per GPU -- several per CU -- the two stand-alone launches are faster: 8.0e8 against 6.1e8 agent-steps/s
         # at 1024 worlds, the cross-world policy tiles waste fewer rows; RL_RUN_ALWAYS=1 forces the single launch)

@@ -53,9 +53,10 @@ def test_training_launch_equals_the_two_launch_loop(static, block, monkeypatch):
         _cmp_rows(fused.actions.cpu().numpy(), loop.actions.cpu().numpy(), acted, tag + " actions")
         _same_tracker(fused, loop, tag)
         assert int(fused.acted_total.item()) == int(loop.acted_total.item())
-        if chunk == 20:
+        assert int(fused.trk_cnt.sum().item()) > 0
+        if chunk == 20 and done < 60:
             fused.reset_tracking(); loop.reset_tracking()
-    assert float(fused.trk_cnt.sum().item()) > 0 and int(fused.refill_count.item()) > 0
+    assert int(fused.refill_count.item()) > 0
 
 
 def test_training_launch_tracker_matches_the_oracle():
