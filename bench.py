@@ -182,15 +182,15 @@ def api_trainer(args, device):
             out.append(b)
         return out
 
-    def one(k):
+    def one(k, **kw):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             env = trainer(brains(), n_episodes=k, n_worlds=args.worlds, save=False, print_results=False, static_families=wl["static_families"],
-                          device=device, seed=args.seed, synthetic_agents=100, refill_below=70)
+                          device=device, seed=args.seed, synthetic_agents=100, refill_below=70, **kw)
         steps = int(env.worlds.acted_total.item())
         env.worlds.check_error_flag()
         return steps, env.loop_seconds, env
-    one(20)                                    # warm-up: library, packed weights, first launches
+    one(40, update_interval=10)                # warm-up: the TRAIN kernel's first launch, the Tracker's torch reductions (first use loads their code objects: ~15 ms)
     k_long = max(2000, args.steps)
     s_long, t_long, env = one(k_long)
     s_win, t_win, _ = one(args.steps)          # the same window as the main line's --steps

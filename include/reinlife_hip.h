@@ -204,8 +204,9 @@ int rl_tick_refill(rl_world* h, const int8_t* actions, const rl_step_out* sout, 
  *               obs[(first_obs + n_ticks) & 1] and the rows the policy read for the last tick in the other buffer
  *   update_src  [R][cap] or NULL: rl_update_out.src of the last tick
  *   threshold   < 0: no re-generation; else worlds below `threshold` agents are re-generated with n_agents (rl_refill)
- * Supported (rl_run_supported() != 0): brains all of the dueling kinds (RL_D3QN / RL_PERD3QN), n_brains <= 8, slot_cap <= the
- * workgroup size (512 threads; 256 when n_worlds > 768).  Otherwise RL_E_UNSUPPORTED: loop over rl_policy_act + rl_tick_refill. */
+ * Supported (rl_run_supported() != 0): n_brains <= 8 and slot_cap <= the workgroup size (512 threads; 256 when n_worlds > 768);
+ * brains of any kinds with 512-thread workgroups, with 256 / 1024 threads only all of the dueling kinds (RL_D3QN / RL_PERD3QN).
+ * Otherwise RL_E_UNSUPPORTED: loop over rl_policy_act + rl_tick_refill. */
 /* rl_run_ex: rl_run with the options a TRAINING loop needs (Helpers/trainer.py:85-99 with training=True):
  *   eps_schedule  device [n_ticks][n_brains] or NULL: the brains' exploration rate in every tick of the launch -- the reference's brains
  *                 change epsilon from episode to episode (D3QN.py:84-89 / PERD3QN.py:82-86: x 0.99 per new n_epi; DQN.py:67-69);

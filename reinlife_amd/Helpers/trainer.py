@@ -31,6 +31,8 @@ def trainer(brains, n_episodes=10_000, width=30, height=30, visualize_results=Fa
         fused = env.rng == "philox" and not per_agent_api
     if fused and (env.rng != "philox" or per_agent_api):
         raise ValueError("trainer(fused=True) needs rng='philox' and per_agent_api=False")
+    if env.rng == "philox":
+        env._bind_brains()   # set-up like reset(): the brains' weights are packed for the matrix cores and uploaded once
     env._sync()
     t0 = time.perf_counter()
     if fused and not render:

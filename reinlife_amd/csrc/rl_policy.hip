@@ -205,6 +205,59 @@ __global__ __launch_bounds__(64 * kDenseTiles, 2) void k_policy_dense(const Poli
     policy_tile1ds<KIND>(io, lane, ws, lds_c);
 }
 
+// RL_POLICY_VARIANT=pair: TWO waves per 32-row tile -- policy_tile1s<PAIR> for the dueling kinds, policy_pair2 for DQN / PPO: the
+// tiles (and the arithmetic) of the multi-tick kernel's policy half, as a stand-alone launch for brains of any kinds: what rl_run is
+// compared with bit for bit, and the tiles' own check against the oracle.  128-thread workgroup per (tile, brain); dynamic LDS:
+// [the brain's constants kTileConstMax | partial row maxima 128 | role 1's head partials 256 | exchange buffer 32 KB].
+constexpr int kPairKernelLds = (kTileConstMax + 128 + kPairValFloats) * 4 + 16 * kPlanes * 64 * 16;
+__global__ __launch_bounds__(128) void k_policy_pair(const PolicyArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) char rl_dyn_lds[];
+    float* lds_c = (float*)rl_dyn_lds;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, role = __builtin_amdgcn_readfirstlane(tid >> 6);
+    typedef const int __attribute__((address_space(4))) cint;
+    const int bi = blockIdx.y, tile = blockIdx.x;
+    const BrainSlot B = A.b[bi];
+    const int n = B.count_ptr ? ((cint*)B.count_ptr)[0] : (int)A.n_rows;
+    if (tile * 32 >= n) return;   // (uniform: the whole workgroup)
+    const int li = tile * 32 + j, lic = min(li, n - 1);
+    const int entry = B.rowlist ? B.rowlist[lic] : 0;
+    const int e_w = rl_list_world(entry), e_k = rl_list_slot(entry);
+    TileIO io;
+    io.packed = (gfloat*)B.packed;
+    io.obs = A.obs;
+    io.valid = li < n;
+    io.row = B.rowlist ? (int64_t)e_w * A.cap + e_k : (int64_t)lic;
+    io.eps = B.eps; io.out = A.out; io.actions = A.actions; io.seed = A.seed;
+    io.key_world = io.key_tick = io.key_epoch = io.key_index = 0;
+    io.lds_actions_off = -1; io.lds_slot = 0; io.x_lds_off = -1; io.c_lds_off = 0;
+    if (A.actions && lane < 32) {
+        io.key_world = (uint32_t)(A.world_base + e_w); io.key_index = (uint32_t)e_k;
+        io.key_tick = (uint32_t)A.tick[e_w]; io.key_epoch = (uint32_t)A.epoch[e_w];
+    }
+#ifdef RL_PHASE_PROFILE
+    io.prof = nullptr;
+#endif
+    const int kind = B.kind;
+    {
+        gfloat* pk = (gfloat*)B.packed;
+        for (int i = tid; i < tile_const_floats(kind); i += 128) lds_c[i] = pk[tile_const_src(kind, i)];
+    }
+    lds_barrier();
+    PairLds pl;
+    pl.pmax = lds_c + kTileConstMax; pl.val = pl.pmax + 128; pl.ex = (f32x4*)(pl.val + kPairValFloats);
+    Tile1Part part;
+    if (kind == RL_DQN) policy_pair2<RL_DQN, false>(io, lane, role, &pl, &part);
+    else if (kind == RL_PPO) policy_pair2<RL_PPO, false>(io, lane, role, &pl, &part);
+    else policy_tile1s<RL_PERD3QN, false, true>(io, lane, role, &pl, &part);
+    lds_barrier();
+    if (role == 0) {
+        if (kind == RL_DQN) pair_finish<RL_DQN>(io, lane, part, &pl);
+        else if (kind == RL_PPO) pair_finish<RL_PPO>(io, lane, part, &pl);
+        else tile1_finish<RL_PERD3QN>(io, lane, part.head, pl.val[j], part.draw, *(const f32x4*)(lds_c + 768 + 8 + 4 * (lane >> 5)));
+    }
+}
+
 // Brains of DIFFERENT kinds in one launch (mixed populations, BASELINE configs[4]): one launch per kind ran them back to
 // back (PPO 16 us + PERD3QN 13.5 us for the two halves of 680 tiles); here every workgroup picks its brain's tile code at run
 // time, so the kinds overlap on the chip.  Register budget and LDS are the widest kind's (PPO: 2 waves per SIMD).
@@ -474,6 +527,12 @@ static int launch_policy(int kind, const PolicyArgs& a, int64_t max_rows, int64_
     // stand-alone launch: dense 680 tiles 17.6 us against 17.8; from freshly written rows 18.9 against 25.8 for the one-wave tile, whose
     // row reads are not coalesced).
     const char* variant = getenv("RL_POLICY_VARIANT");
+    if (variant && !strcmp(variant, "pair")) {   // two waves per tile, any kinds: the arithmetic of rl_run's policy half
+        hipLaunchKernelGGL(k_policy_pair, grid, dim3(128), kPairKernelLds, st, a);
+        const hipError_t e1 = hipGetLastError();
+        if (e1 != hipSuccess) { rl_set_error("policy kernel launch failed: %s", hipGetErrorString(e1)); return RL_E_LAUNCH; }
+        return RL_OK;
+    }
     if ((kind == RL_D3QN || kind == RL_PERD3QN) && !variant && expected_rows / 32 >= 1536) variant = "dense";
     if ((kind == RL_D3QN || kind == RL_PERD3QN) && variant && (!strcmp(variant, "wave") || !strcmp(variant, "dense"))) {
         if (!strcmp(variant, "dense")) {
@@ -507,7 +566,7 @@ static int launch_policy(int kind, const PolicyArgs& a, int64_t max_rows, int64_
 int rl_policy_forward_impl(int kind, const float* packed, const float* obs, int64_t n_rows, float* out, hipStream_t st)
 {
     PolicyArgs a{};
-    a.nb = 1; a.b[0].packed = packed; a.obs = obs; a.n_rows = n_rows; a.out = out; a.cap = 1;
+    a.nb = 1; a.b[0].packed = packed; a.b[0].kind = kind; a.obs = obs; a.n_rows = n_rows; a.out = out; a.cap = 1;
     return launch_policy(kind, a, n_rows, n_rows, st);
 }
 
@@ -563,6 +622,15 @@ int rl_policy_act_impl(rl_world* h, const rl_brain* brains, int n_brains, const 
     for (int b = 0; b < n_brains; ++b) {
         if (brains[b].kind < RL_DQN || brains[b].kind > RL_PPO) { rl_set_error("unknown brain kind %d", brains[b].kind); return RL_E_INVALID; }
         kinds |= 1u << brains[b].kind;
+    }
+    const char* variant = getenv("RL_POLICY_VARIANT");
+    if (variant && !strcmp(variant, "pair") && n_brains <= kMaxBrainsPerLaunch) {   // one launch, the tile code picked per workgroup
+        PolicyArgs a = base_args();
+        for (int b = 0; b < n_brains; ++b) a.b[a.nb++] = slot_of(b);
+        hipLaunchKernelGGL(k_policy_pair, dim3(policy_grid(bound), a.nb), dim3(128), kPairKernelLds, st, a);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { rl_set_error("policy kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
+        return RL_OK;
     }
     if ((kinds & (kinds - 1)) != 0 && n_brains <= kMaxBrainsPerLaunch && !getenv("RL_POLICY_PER_KIND")) {
         // several kinds: ONE launch, the tile code picked per workgroup (k_policy_mixed)

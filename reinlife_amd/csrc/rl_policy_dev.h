@@ -919,14 +919,14 @@ constexpr int kDenseTiles = 4;       // tiles (waves) per workgroup
 constexpr int kTileConstFloats = 3 * 256 + 2 * 16;
 
 // Weight ring over the 2 * NS steps of a layer taken as two passes: step i = K-chunk i % NS of output tiles 2 * (i / NS), +1.
-template <int NS, int D, int STEPS = 2 * NS>   // STEPS = NS: one pass only (the caller offsets the base by its tile pair)
+template <int NS, int D, int STEPS = 2 * NS, int TOUT = 4>   // STEPS = NS: one pass only (the caller offsets the base by its tile pair); TOUT: output tiles of the layer
 struct WRingH {
     f32x4 a[D][2][kPlanes];
     gf32x4* p;   // tile-pair fragment block of the step the next refill asks for
 #ifdef RL_ABL_WH  // tuning experiment (RL_EXTRA_HIPCC_FLAGS=-DRL_ABL_WH): every step re-reads the layer's first fragments (L1 hits; results WRONG)
     static __host__ __device__ constexpr int off(int i) { return 0; }
 #else
-    static __host__ __device__ constexpr int off(int i) { return ((i % NS) * 4 + 2 * (i / NS)) * kPlanes * 64; }   // in 16-byte units
+    static __host__ __device__ constexpr int off(int i) { return ((i % NS) * TOUT + 2 * (i / NS)) * kPlanes * 64; }   // in 16-byte units
 #endif
     __device__ inline void start(gfloat* __restrict__ pw, int lane)
     {
@@ -1041,27 +1041,27 @@ struct EpiStream {
 
 // head (8 / 1 outputs padded to one A tile) over K = 128, its input split chunk by chunk ahead of the MFMAs that use it.
 // raw(c, e): element e of B chunk c (= register 8 * (c & 1) + e of activation tile c >> 1).
-template <int D, typename Raw>
+template <int D, int NCH = 8, typename Raw>   // NCH: K-chunks of the head's input this wave holds (8 = 128 features)
 __device__ inline void head_stream(WRing<1, 1, 1, D>& w, const f32x4& un4, Raw&& raw, float sc, float row_un, float (&out)[4])
 {
     f32x16 a0, a1, a2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; a2[r] = 0.0f; }
-    f32x4 B[8][kPlanes];
+    f32x4 B[NCH][kPlanes];
 #pragma unroll
     for (int k = 0; k < 3; ++k) split_slice<3>(k, [&](int e) { return raw(0, e); }, sc, B[0][0], B[0][1]);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < NCH; ++s) {
         f32x4 ac[1][kPlanes];
-        w.template next<8>(s, ac);
+        w.template next<NCH>(s, ac);
         a0 = mfma16(ac[0][0], B[s][1], a0);
-        if (s + 1 < 8) split_slice<3>(0, [&](int e) { return raw(s + 1, e); }, sc, B[(s + 1) & 7][0], B[(s + 1) & 7][1]);
+        if (s + 1 < NCH) split_slice<3>(0, [&](int e) { return raw(s + 1, e); }, sc, B[(s + 1) % NCH][0], B[(s + 1) % NCH][1]);
         __builtin_amdgcn_sched_barrier(0);
         a1 = mfma16(ac[0][0], B[s][0], a1);
-        if (s + 1 < 8) split_slice<3>(1, [&](int e) { return raw(s + 1, e); }, sc, B[(s + 1) & 7][0], B[(s + 1) & 7][1]);
+        if (s + 1 < NCH) split_slice<3>(1, [&](int e) { return raw(s + 1, e); }, sc, B[(s + 1) % NCH][0], B[(s + 1) % NCH][1]);
         __builtin_amdgcn_sched_barrier(0);
         a2 = mfma16(ac[0][1], B[s][0], a2);
-        if (s + 1 < 8) split_slice<3>(2, [&](int e) { return raw(s + 1, e); }, sc, B[(s + 1) & 7][0], B[(s + 1) & 7][1]);
+        if (s + 1 < NCH) split_slice<3>(2, [&](int e) { return raw(s + 1, e); }, sc, B[(s + 1) % NCH][0], B[(s + 1) % NCH][1]);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -1257,6 +1257,299 @@ __device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, c
     head_stream<D>(wh, *(const f32x4*)(hconsts + 16 + 4 * h), araw, sc2, un2, val);
     RL_PMARK1(9);
     tile1_finish<KIND>(io, lane, adv, val[0] + hconsts[16 + 8], draw, *(const f32x4*)(hconsts + 8 + 4 * h));
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Two waves per tile for the plain kinds -- DQN (153 -> 128 -> 64 -> 8) and PPO (153 -> 256 -> 256 -> 8 -> softmax) -- with the protocol of
+// policy_tile1s<PAIR>: both roles meet two workgroup barriers inside (partial row maxima, then the split activations of the input layer
+// through pair_lds->ex), the caller adds a third, and role 0 finishes (pair_finish).  Every layer is split by OUTPUT features:
+//   input layer   role r: the upper / lower half of the output tiles (DQN: tiles 2r, 2r+1 -- exactly the dueling pair's; PPO: 4r .. 4r+3 in
+//                 two passes over K, the epilogue of the first pass in the shadow of the second);
+//   hidden layer  DQN: role r computes output tile r (24 MFMAs: main / cross accumulators); PPO: tiles 4r .. 4r+3 in two passes, its B
+//                 operand -- all 16 K-chunks of the 256 activations -- read chunk by chunk from pair_lds->ex, one step ahead of its use
+//                 (128 registers if held);
+//   head          each role multiplies ITS OWN features (the head's K-chunks 2r, 2r+1 / 8r .. 8r+7) and scales them with its own row
+//                 factor; role 1's four partial outputs per lane cross through pair_lds->val, role 0 adds them (pair_finish).
+// So no weight byte is fetched twice per tile and the two waves (any two SIMD slots: only LDS and the barriers connect them) fill each
+// other's waits.  Summation order differs from the 4-wave tile's (policy_tile): ~1e-7 apart, each checked against the oracle; the
+// stand-alone k_policy_pair runs THIS code, so rl_run and the two-launch loop can be compared bit for bit.
+// LDS constants of a brain (`c_lds_off`): per kind, see tile_const_floats / tile_const_src.
+// ---------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int tile_const_floats(int kind)
+{
+    return kind == RL_DQN ? 256 + 128 + 16 : kind == RL_PPO ? 512 + 512 + 16 : 3 * 256 + 2 * 16;
+}
+constexpr int kTileConstMax = 512 + 512 + 16;
+// element j of a brain's LDS constant block -> offset in its packed weights
+__host__ __device__ inline int64_t tile_const_src(int kind, int j)
+{
+    const Layout L = layout_of(kind);
+    if (kind == RL_DQN) {
+        if (j < 256) return L.l1 + frag_floats(kInChunks, 4) + j;
+        if (j < 384) return L.l2a + frag_floats(8, 2) + (j - 256);
+        return L.ha + head_consts_off(2) + (j - 384);
+    }
+    if (kind == RL_PPO) {
+        if (j < 512) return L.l1 + frag_floats(kInChunks, 8) + j;
+        if (j < 1024) return L.l2a + frag_floats(16, 8) + (j - 512);
+        return L.ha + head_consts_off(8) + (j - 1024);
+    }
+    if (j < 256) return L.l1 + frag_floats(kInChunks, 4) + j;
+    if (j < 512) return L.l2a + frag_floats(8, 4) + (j - 256);
+    if (j < 768) return L.l2b + frag_floats(8, 4) + (j - 512);
+    if (j < 784) return L.ha + head_consts_off(4) + (j - 768);
+    return L.hb + head_consts_off(4) + (j - 784);
+}
+__host__ __device__ constexpr int pair_ex_bytes(int kind) { return (kind == RL_PPO ? 16 : 8) * kPlanes * 64 * 16; }
+constexpr int kPairValFloats = 256;   // role 1's head partials: 4 per lane
+
+// One pass of the PPO hidden layer: K loop over 16 chunks for output tiles (pair HALF of the role's four), the B operand from LDS
+// (ex[chunk][plane][lane]), requested one step ahead.  shadow(slot) as in k_pass.
+template <int HALF, typename Ring, typename Shadow>
+__device__ inline void k_pass_lds16(Ring& w, const f32x4* __restrict__ ex, int lane, f32x16& a0, f32x16& a1, Shadow&& shadow)
+{
+    constexpr int NS = 16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; }
+    f32x4 B[2][kPlanes];
+#pragma unroll
+    for (int pl = 0; pl < kPlanes; ++pl) B[0][pl] = ex[(0 * kPlanes + pl) * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        f32x4 ac[2][kPlanes];
+        w.take(HALF * NS + s, ac);
+        if (s + 1 < NS) {
+#pragma unroll
+            for (int pl = 0; pl < kPlanes; ++pl) B[(s + 1) & 1][pl] = ex[((s + 1) * kPlanes + pl) * 64 + lane];
+        }
+        const f32x4 (&b)[kPlanes] = B[s & 1];
+        a0 = mfma16(ac[0][0], b[1], a0); shadow(6 * s + 0); __builtin_amdgcn_sched_barrier(0);   // hi.lo
+        a1 = mfma16(ac[1][0], b[1], a1); shadow(6 * s + 1); __builtin_amdgcn_sched_barrier(0);
+        a0 = mfma16(ac[0][0], b[0], a0); shadow(6 * s + 2); __builtin_amdgcn_sched_barrier(0);   // hi.hi
+        a1 = mfma16(ac[1][0], b[0], a1); shadow(6 * s + 3); __builtin_amdgcn_sched_barrier(0);
+        a0 = mfma16(ac[0][1], b[0], a0); shadow(6 * s + 4); __builtin_amdgcn_sched_barrier(0);   // lo.hi
+        a1 = mfma16(ac[1][1], b[0], a1); shadow(6 * s + 5); __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int KIND, bool COHERENT>
+__device__ inline void policy_pair2(const TileIO& io, int lane, int role, const PairLds* pair_lds, Tile1Part* part)
+{
+    static_assert(KIND == RL_DQN || KIND == RL_PPO, "the plain kinds (the dueling pair is policy_tile1s<PAIR>)");
+    extern __shared__ __attribute__((aligned(16))) char rl_dyn_lds[];
+    constexpr int D = 3;
+    constexpr int T1 = KIND == RL_PPO ? 8 : 4;             // output tiles of the input layer
+    constexpr int OWN1 = T1 / 2;                           // ... of which a role computes this many
+    const int h = lane >> 5;
+    const Layout L = layout_of(KIND);
+    gfloat* __restrict__ packed = io.packed;
+    const float* const cbase = (const float*)(rl_dyn_lds + io.c_lds_off);
+    const float* const c1 = cbase + 32 * h;                                   // input layer: [tile][half][unscale 16 | bias 16]
+    const float* const c2 = cbase + T1 * 64 + 32 * h;                         // hidden layer
+    const float* const hconsts = cbase + T1 * 64 + (KIND == RL_PPO ? 512 : 128);   // head: [unscale 8 | bias 8]
+    // ---- input layer: the role's OWN1 output tiles
+    WRingH<kInChunks, D, (OWN1 / 2) * kInChunks, T1> w1;
+    w1.start(packed + L.l1 + role * (OWN1 * kPlanes * 64 * 4), lane);
+    f32x4 X[kInChunks][2];
+    {
+        const int64_t rbase = io.row * RL_OBS_DIM;
+        if (io.x_lds_off >= 0) {
+            const float* xr = (const float*)(rl_dyn_lds + io.x_lds_off);
+#pragma unroll
+            for (int c = 0; c < kInChunks; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (c == kInChunks - 1 && h == 1) X[c][q] = f32x4{xr[149], xr[150], xr[151], xr[152]};
+                    else X[c][q] = *(const f32x4*)(xr + 16 * c + 8 * h + 4 * q);
+                }
+        } else
+#pragma unroll
+        for (int c = 0; c < kInChunks; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k0 = (c == kInChunks - 1 && h == 1) ? 149 : 16 * c + 8 * h + 4 * q;   // (see policy_tile1)
+                if (COHERENT) {
+                    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)io.obs, 0, 0x7fffffff, 0x00027000);
+                    X[c][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((rbase + k0) * 4), 0, 16 /* sc1 */));
+                } else
+                    X[c][q] = *(const f32x4u*)(io.obs + rbase + k0);
+            }
+    }
+    rl_u4 draw = {0u, 0u, 0u, 0u};
+    if (role == 0 && io.actions && (KIND == RL_PPO || io.eps > 0.0f))
+        draw = rl_philox4x32(io.seed, io.key_epoch, io.key_world, io.key_tick, RL_SITE_ACT, io.key_index);
+    if (h == 1) { X[kInChunks - 1][0] = f32x4{X[kInChunks - 1][0].w, 0.0f, 0.0f, 0.0f}; X[kInChunks - 1][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    float m4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < kInChunks; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            max3_abs(m4[(2 * c + q) & 3], X[c][q].x, X[c][q].y);
+            max3_abs(m4[(2 * c + q + 2) & 3], X[c][q].z, X[c][q].w);
+        }
+    float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sc0, un0;
+    row_scale(m, sc0, un0);
+    f32x4 B1[kInChunks][kPlanes];
+    auto xraw = [&](int c, int e) { return X[c][e >> 2][e & 3]; };
+#pragma unroll
+    for (int k = 0; k < 6; ++k) split_slice<6>(k, [&](int e) { return xraw(0, e); }, sc0, B1[0][0], B1[0][1]);
+    f32x16 F[OWN1];
+    EpiStream ep;
+    float mrow = 0.0f;
+    k_pass<kInChunks, 0>(w1, B1, F[0], F[1], [&](int slot) {
+        const int c = slot / 6 + 1;
+        if (c < kInChunks) split_slice<6>(slot % 6, [&](int e) { return xraw(c, e); }, sc0, B1[c][0], B1[c][1]);
+    });
+    ep.c = c1 + role * OWN1 * 64;
+    if (KIND == RL_PPO) {
+        k_pass<kInChunks, 1>(w1, B1, F[OWN1 - 2], F[OWN1 - 1], [&](int slot) {
+            if (slot == 0) ep.fetch(0, 0);
+            if (slot >= 2 && slot < 34) ep.step(0, slot - 2, F[0], F[1], un0, mrow);
+        });
+        ep.fetch(2, 0);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) ep.step(2, e, F[OWN1 - 2], F[OWN1 - 1], un0, mrow);
+    } else {
+        ep.fetch(0, 0);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) ep.step(0, e, F[0], F[1], un0, mrow);
+    }
+    // ---- the row's scale over ALL features of the layer, then the split activations of both roles through LDS
+    mrow = fmaxf(mrow, __shfl_xor(mrow, 32));
+    pair_lds->pmax[role * 64 + lane] = mrow;
+    lds_barrier();
+    mrow = fmaxf(mrow, pair_lds->pmax[(role ^ 1) * 64 + lane]);
+    float sc1, un1;
+    row_scale(mrow, sc1, un1);
+    auto fraw = [&](int c, int e) { return F[c >> 1][8 * (c & 1) + e]; };
+#pragma unroll
+    for (int c = 0; c < 2 * OWN1; ++c) {   // own chunks: registers 8 (c & 1) .. of own tile c >> 1 = chunk 2 * OWN1 * role + c of the layer
+        f32x4 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) split_slice<6>(k, [&](int e) { return fraw(c, e); }, sc1, hi, lo);
+        pair_lds->ex[((2 * OWN1 * role + c) * kPlanes + 0) * 64 + lane] = hi;
+        pair_lds->ex[((2 * OWN1 * role + c) * kPlanes + 1) * 64 + lane] = lo;
+    }
+    lds_barrier();
+    float head4[4];
+    float sc2, un2;
+    if (KIND == RL_DQN) {
+        // ---- hidden layer 128 -> 64: output tile `role`; main / cross accumulator chains (consecutive MFMAs independent)
+        f32x4 B2[8][kPlanes];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int pl = 0; pl < kPlanes; ++pl) B2[c][pl] = pair_lds->ex[(c * kPlanes + pl) * 64 + lane];
+        WRing<2, 1, 1, D> w2;
+        w2.start(packed + L.l2a, lane, role);
+        WRing<1, 1, 1, 2> wh;
+        wh.start(packed + L.ha, lane, 2 * role);
+        f32x16 acc, cross;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; cross[r] = 0.0f; }
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+            f32x4 ac[1][kPlanes];
+            w2.template next<8>(s2, ac);
+            cross = mfma16(ac[0][0], B2[s2][1], cross);   // hi.lo
+            acc = mfma16(ac[0][0], B2[s2][0], acc);       // hi.hi
+            cross = mfma16(ac[0][1], B2[s2][0], cross);   // lo.hi
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += cross[r];
+        f32x16 dummy = acc;
+        float m2 = 0.0f;
+        ep.c = c2 + role * 64;
+        ep.fetch(0, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ep.step(0, e, acc, dummy, un1, m2);
+        m2 = fmaxf(m2, __shfl_xor(m2, 32));
+        row_scale(m2, sc2, un2);
+        auto araw = [&](int c, int e) { return acc[8 * (c & 1) + e]; };
+        head_stream<2, 2>(wh, *(const f32x4*)(hconsts + 4 * h), araw, sc2, un2, head4);
+    } else {
+        // ---- hidden layer 256 -> 256: output tiles 4 role .. 4 role + 3 in two passes, B from LDS
+        WRingH<16, D, 32, 8> w2;
+        w2.start(packed + L.l2a + role * (4 * kPlanes * 64 * 4), lane);
+        f32x16 A[4];
+        float m2 = 0.0f;
+        k_pass_lds16<0>(w2, pair_lds->ex, lane, A[0], A[1], [&](int) {});
+        ep.c = c2 + role * 4 * 64;
+        k_pass_lds16<1>(w2, pair_lds->ex, lane, A[2], A[3], [&](int slot) {
+            if (slot == 0) ep.fetch(0, 0);
+            if (slot >= 2 && slot < 34) ep.step(0, slot - 2, A[0], A[1], un1, m2);
+        });
+        WRing<1, 1, 1, D> wh;
+        wh.start(packed + L.ha, lane, 8 * role);
+        ep.fetch(2, 0);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) ep.step(2, e, A[2], A[3], un1, m2);
+        m2 = fmaxf(m2, __shfl_xor(m2, 32));
+        row_scale(m2, sc2, un2);
+        auto araw = [&](int c, int e) { return A[c >> 1][8 * (c & 1) + e]; };
+        head_stream<D>(wh, *(const f32x4*)(hconsts + 4 * h), araw, sc2, un2, head4);
+    }
+    if (role) {
+        *(f32x4*)(pair_lds->val + 4 * lane) = f32x4{head4[0], head4[1], head4[2], head4[3]};
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part->head[r] = head4[r];
+        part->draw = draw;
+    }
+}
+
+// Role 0 after the caller's barrier: the two roles' head partials, bias, softmax (PPO.py:105) / Q values, the action (DQN.py:132-139:
+// epsilon-greedy, first maximum; PPO.py:164-169: Categorical(prob).sample() as inverse CDF over the Philox uniform).
+template <int KIND>
+__device__ inline void pair_finish(const TileIO& io, int lane, const Tile1Part& part, const PairLds* pair_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) char rl_dyn_lds[];
+    constexpr int T1 = KIND == RL_PPO ? 8 : 4;
+    const int h = lane >> 5;
+    const float* const hconsts = (const float*)(rl_dyn_lds + io.c_lds_off) + T1 * 64 + (KIND == RL_PPO ? 512 : 128);
+    const f32x4 other = *(const f32x4*)(pair_lds->val + 4 * lane), bias = *(const f32x4*)(hconsts + 8 + 4 * h);
+    float a4[4] = {(part.head[0] + other.x) + bias.x, (part.head[1] + other.y) + bias.y, (part.head[2] + other.z) + bias.z, (part.head[3] + other.w) + bias.w};
+    float o4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o4[r] = __shfl_xor(a4[r], 32);
+    if (h == 0) {
+        float q[8] = {a4[0], a4[1], a4[2], a4[3], o4[0], o4[1], o4[2], o4[3]};
+        if (KIND == RL_PPO) {
+            float mx = q[0], sm = 0.0f;
+#pragma unroll
+            for (int i = 1; i < 8; ++i) mx = fmaxf(mx, q[i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { q[i] = expf(q[i] - mx); sm += q[i]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[i] = q[i] / sm;
+        }
+        if (io.valid) {
+            if (io.out) {
+                f32x4* o = (f32x4*)(io.out + io.row * 8);
+                o[0] = f32x4{q[0], q[1], q[2], q[3]};
+                o[1] = f32x4{q[4], q[5], q[6], q[7]};
+            }
+            if (io.actions) {
+                const float u = (float)rl_u24(part.draw.x);
+                int a = 0;
+                if (KIND == RL_PPO) {
+                    float cum = 0.0f; a = 7; bool found = false;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { cum += q[i]; if (!found && u < cum) { a = i; found = true; } }
+                } else if (u < io.eps) a = (int)(part.draw.y >> 29);
+                else {
+#pragma unroll
+                    for (int i = 1; i < 8; ++i) if (q[i] > q[a]) a = i;   // first maximum
+                }
+                io.actions[io.row] = (int8_t)a;
+                if (io.lds_actions_off >= 0) ((signed char*)rl_dyn_lds)[io.lds_actions_off + io.lds_slot] = (signed char)a;
+            }
+        }
+    }
 }
 
 

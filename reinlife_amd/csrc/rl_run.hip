@@ -28,6 +28,10 @@ namespace {
 #include "rl_policy_dev.h"
 
 constexpr int kRunMaxBrains = 8;
+// k_run's KIND parameter: RL_PERD3QN = every brain is of a dueling kind (D3QN / PERD3QN: the kernel bench.py times, nothing but their tile
+// in it); kKindAll = any mix of DQN / D3QN / PERD3QN / PPO brains, the tile code picked per tile at run time (512-thread workgroups).
+constexpr int kKindAll = 4;
+__host__ __device__ constexpr int kind_widest(int KIND) { return KIND == kKindAll ? RL_PPO : KIND; }
 
 #ifndef RL_RUN_COHERENT
 #define RL_RUN_COHERENT true
@@ -35,6 +39,7 @@ constexpr int kRunMaxBrains = 8;
 struct RunArgs {
     const float* packed[kRunMaxBrains];   // device: packed weights per brains-list entry
     float eps[kRunMaxBrains];
+    int kind[kRunMaxBrains];              // RL_DQN .. RL_PPO per brains-list entry (kKindAll kernels)
     float* obs[2];                        // Agent.state ping-pong: tick i reads obs[(first + i) & 1], writes the other
     int first;
     int n_ticks;
@@ -61,17 +66,24 @@ struct PolSmem {
     int xrows;
     double* trk_scr;    // [cap] scratch of the Tracker pass (track_world_wave0)
     TrkLds trk;         // the Tracker's running sums for the length of the launch
+    // kKindAll kernels: the policy half's schedule, written by wave 0 next to the row lists (policy_schedule_wave0).  meta[5]: 0 = every
+    // tile gets a wave pair in ONE round (<= 4 tiles whose exchange buffers fit into the mirror), 1 = 4-wave tiles in rounds of two
+    short* wtask;       // [8]  per wave: tile | role << 8, or -1
+    int* texoff;        // [4]  per tile: byte offset of its exchange buffer inside the mirror
 };
 template <int KIND>
 __host__ __device__ constexpr int policy_group_bytes()
 {
-    return (int)(align16(sizeof(f32x4) * (size_t)policy_lds_units(KIND)) + align16(sizeof(float) * kAuxFloats) + align16(sizeof(float) * 4 * 32 * 9));
+    return (int)(align16(sizeof(f32x4) * (size_t)policy_lds_units(kind_widest(KIND))) + align16(sizeof(float) * kAuxFloats) + align16(sizeof(float) * 4 * 32 * 9));
 }
 // groups > 0: `groups` blocks for the 4-wave tile (T = 1024).  groups == 0: the one-wave tile needs no LDS of its own; with
 // mirror_budget > 0 the Agent.state rows are mirrored in LDS instead (as many rows as fit below the budget, at most cap).
 constexpr int kMaxTiles = 32;                // 32-row tiles of one brain per world: <= cap / 32 + n_brains
 constexpr int kPairFloats = 32 + 2 * 64;     // per tile pair: row values, partial row maxima of the two roles
 constexpr int kPairExBytes = 8 * kPlanes * 64 * 16;   // per tile pair: the split activations of the input layer (aliases the Agent.state mirror)
+constexpr int kPairFloatsAll = kPairValFloats + 2 * 64;   // kKindAll: role 1's head partials (4 per lane), then the partial row maxima
+template <int KIND> __host__ __device__ constexpr int run_const_floats() { return KIND == kKindAll ? kTileConstMax : kTileConstFloats; }
+template <int KIND> __host__ __device__ constexpr int run_pair_floats() { return KIND == kKindAll ? kPairFloatsAll : kPairFloats; }
 template <int KIND>
 __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o, int cap, int groups, size_t mirror_budget = 0, int n_cbrains = 0)
 {
@@ -80,7 +92,7 @@ __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o
     o += (size_t)groups * policy_group_bytes<KIND>();
     ps.xmirror = nullptr; ps.xrows = 0;
     // what follows the mirror: row lists and tile descriptors (2 * cap + ~3.5 KB), the Tracker's scratch and sums (8 * cap + ~0.8 KB), ...
-    const size_t tail = 10 * (size_t)cap + 5120 + sizeof(float) * 4 * kPairFloats + sizeof(float) * kTileConstFloats * (size_t)n_cbrains;
+    const size_t tail = 10 * (size_t)cap + 5120 + sizeof(float) * 4 * run_pair_floats<KIND>() + sizeof(float) * run_const_floats<KIND>() * (size_t)n_cbrains;
     if (groups == 0 && mirror_budget > o + tail) {
         const size_t rows = (mirror_budget - o - tail) / (sizeof(float) * kXStride);
         ps.xrows = (int)(rows < (size_t)cap ? rows : (size_t)cap);
@@ -95,9 +107,12 @@ __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o
     ps.tbrain = (int*)(base + o); o = align16(o + sizeof(int) * kMaxTiles);
     ps.meta = (int*)(base + o); o = align16(o + sizeof(int) * 8);
     ps.cconst = nullptr;
-    if (n_cbrains > 0) { ps.cconst = (float*)(base + o); o = align16(o + sizeof(float) * kTileConstFloats * (size_t)n_cbrains); }
+    if (n_cbrains > 0) { ps.cconst = (float*)(base + o); o = align16(o + sizeof(float) * run_const_floats<KIND>() * (size_t)n_cbrains); }
     ps.pairv = nullptr;
-    if (n_cbrains > 0) { ps.pairv = (float*)(base + o); o = align16(o + sizeof(float) * 4 * kPairFloats); }
+    if (n_cbrains > 0) { ps.pairv = (float*)(base + o); o = align16(o + sizeof(float) * 4 * run_pair_floats<KIND>()); }
+    ps.wtask = (short*)(base + o); o = align16(o + sizeof(short) * 8);
+    ps.texoff = (int*)(base + o); o = align16(o + sizeof(int) * 4);
+    if (KIND == kKindAll && groups == 0 && ps.xmirror) ps.group0 = (char*)ps.xmirror;   // the 4-wave tiles of the fall-back rounds work in the (then unused) mirror
     ps.trk_scr = (double*)(base + o); o = align16(o + sizeof(double) * (size_t)cap);
     ps.trk.sum = (double*)(base + o); o = align16(o + sizeof(double) * kRunMaxBrains * RL_TRK_VARS);
     ps.trk.pop = (double*)(base + o); o = align16(o + sizeof(double) * 2);
@@ -107,11 +122,11 @@ __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o
 template <int KIND> __device__ inline f32x4* pol_h(const PolSmem& ps, int g) { return (f32x4*)(ps.group0 + g * ps.group_bytes); }
 template <int KIND> __device__ inline float* pol_aux(const PolSmem& ps, int g)
 {
-    return (float*)(ps.group0 + g * ps.group_bytes + align16(sizeof(f32x4) * (size_t)policy_lds_units(KIND)));
+    return (float*)(ps.group0 + g * ps.group_bytes + align16(sizeof(f32x4) * (size_t)policy_lds_units(kind_widest(KIND))));
 }
 template <int KIND> __device__ inline float (*pol_part(const PolSmem& ps, int g))[32][9]
 {
-    return (float (*)[32][9])(ps.group0 + g * ps.group_bytes + align16(sizeof(f32x4) * (size_t)policy_lds_units(KIND)) + align16(sizeof(float) * kAuxFloats));
+    return (float (*)[32][9])(ps.group0 + g * ps.group_bytes + align16(sizeof(f32x4) * (size_t)policy_lds_units(kind_widest(KIND))) + align16(sizeof(float) * kAuxFloats));
 }
 
 // Agent.get_action for the n agents of this world (slot k == list index k): actions into s.action[] and the global
@@ -148,7 +163,8 @@ __device__ inline RecycleRegs recycle_read(Smem& s, int n)
     return r;
 }
 template <int T, bool SPEC>
-__device__ __forceinline__ void recycle_world(const KParams& p, Smem& s, int n, int tick, int epoch, int next_uid, int max_gene, bool drain_stores, const RecycleRegs& rr)
+__device__ __forceinline__ void recycle_world(const KParams& p, Smem& s, int n, int tick, int epoch, int next_uid, int max_gene, bool drain_stores, const RecycleRegs& rr,
+                                              const int* also_drain = nullptr)   // optional LDS flag, valid after the first barrier in here
 {
     const int tid = rl_tidx();
     const bool mine = tid < n;
@@ -171,7 +187,7 @@ __device__ __forceinline__ void recycle_world(const KParams& p, Smem& s, int n, 
         s.scal[tid] = tid == S_NSLOTS ? n : tid == S_TICK ? tick : tid == S_EPOCH ? epoch : tid == S_NEXT_UID ? next_uid : tid == S_MAX_GENE ? max_gene : 0;
     lds_barrier();
     if (mine) s.occ[(r_pos & 255) * p.W + (r_pos >> 8)] = (short)tid;
-    if (drain_stores) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tick's observation rows are in L2 before any wave reads them back
+    if (drain_stores || (also_drain && *also_drain)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tick's observation rows are in L2 before any wave reads them back
     lds_barrier();
 }
 
@@ -340,6 +356,49 @@ __device__ inline void policy_lists_wave0(const KParams& p, PolSmem& ps, int n, 
     }
 }
 
+// kKindAll kernels: the policy half's schedule for the tiles policy_lists_wave0 just described (same wave, program order).  Every tile
+// is handled by TWO waves (policy_tile1s<PAIR> / policy_pair2) when the world has at most four tiles and their exchange buffers fit into
+// the Agent.state mirror; the two roles of a tile may sit on any two wave slots (only LDS and the workgroup barriers connect them), so
+// the tiles are dealt heaviest first, each role onto the least loaded SIMD with a free slot (waves v and v + 4 share SIMD v): a PPO tile
+// (672 MFMAs) next to a dueling one (360) loads every SIMD with 516 instead of 672 / 360.  Otherwise: 4-wave tiles, two at a time.
+__device__ inline void policy_schedule_wave0(const KParams& p, PolSmem& ps, RunParamsC* ka, int lane)
+{
+    typedef const int __attribute__((address_space(4))) cint;
+    const int nt = read_lane(ps.meta[0], 0);
+    if (lane != 0) return;
+    int cost[4], ex[4], order[4];
+    int total_ex = 0;
+    bool pair_ok = nt <= 4 && ps.xmirror != nullptr && ps.pairv != nullptr;
+    for (int t = 0; t < 4 && t < nt; ++t) {
+        const int kind = ((cint*)ka->ra.kind)[ps.tbrain[t]];
+        cost[t] = kind == RL_PPO ? 672 : kind == RL_DQN ? 180 : 360;   // MFMAs per tile
+        ex[t] = pair_ex_bytes(kind);
+        ps.texoff[t] = total_ex;
+        total_ex += ex[t];
+        order[t] = t;
+    }
+    pair_ok = pair_ok && (size_t)total_ex <= (size_t)ps.xrows * kXStride * sizeof(float);
+    ps.meta[5] = pair_ok ? 0 : 1;
+    for (int v = 0; v < 8; ++v) ps.wtask[v] = (short)-1;
+    if (!pair_ok) return;
+    for (int a = 1; a < nt; ++a)   // insertion sort, heaviest first (stable)
+        for (int b = a; b > 0 && cost[order[b]] > cost[order[b - 1]]; --b) { const int x = order[b]; order[b] = order[b - 1]; order[b - 1] = x; }
+    int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
+    for (int a = 0; a < nt; ++a) {
+        const int t = order[a];
+        int taken = -1;
+        for (int role = 0; role < 2; ++role) {
+            int best = -1;
+            for (int sd = 0; sd < 4; ++sd)
+                if (used[sd] < 2 && sd != taken && (best < 0 || load[sd] < load[best])) best = sd;
+            if (best < 0)   // (cannot happen with <= 4 tiles: 8 slots, two roles on distinct SIMDs)
+                for (int sd = 0; sd < 4; ++sd) if (used[sd] < 2) best = sd;
+            ps.wtask[best + 4 * used[best]] = (short)(t | (role << 8));
+            used[best] += 1; load[best] += cost[t] / 2; taken = best;
+        }
+    }
+}
+
 // The policy half for workgroups of at most 512 threads (the tiles below need the 256-VGPR budget).  T = 512, up to four tiles: TWO waves per
 // tile on one SIMD (policy_tile1s<PAIR>); five to eight tiles: one hand-scheduled tile per wave (policy_tile1s); T = 256: one
 // policy_tile1 per wave (no LDS, no barrier inside a tile), wave i takes tiles i, i + 4, ...  Tile rows, validity and brain come from the
@@ -376,7 +435,7 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
         io.key_index = (uint32_t)k;
         io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
         io.x_lds_off = (mirrored && k < ps.xrows) ? (int)((char*)(ps.xmirror + k * kXStride) - smem_base) : -1;
-        io.c_lds_off = ps.cconst ? (int)((char*)(ps.cconst + kTileConstFloats * b) - smem_base) : -1;
+        io.c_lds_off = ps.cconst ? (int)((char*)(ps.cconst + run_const_floats<KIND>() * b) - smem_base) : -1;
 #ifdef RL_PHASE_PROFILE
         io.prof = (p.prof && (int)blockIdx.x == p.prof_world && wave == 0) ? p.prof : nullptr;
         if (io.prof && lane == 0) { io.prof[100] = t_entry; io.prof[110] = (long long)clock64(); }
@@ -416,6 +475,78 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
 #endif
 }
 
+// The policy half of the kKindAll kernels (512-thread workgroups): per tile, the code of its brain's kind.
+template <int T, bool TRAIN>
+__device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base, int wave)
+{
+    static_assert(T == 512, "kKindAll: 512-thread workgroups");
+    typedef const int __attribute__((address_space(4))) cint;
+    const int lane = rl_lane_fresh(), j = lane & 31;
+    const int ntiles = __builtin_amdgcn_readfirstlane(ps.meta[0]);
+    const bool mirrored = ps.xmirror != nullptr && __builtin_amdgcn_readfirstlane(ps.meta[4]) != 0;
+    const bool fallback = __builtin_amdgcn_readfirstlane(ps.meta[5]) != 0;
+    auto tile_io = [&](int ti, TileIO& io, bool from_mirror) {
+        const int b = __builtin_amdgcn_readfirstlane(ps.tbrain[ti]);
+        const int e = (unsigned short)ps.trow[ti * 32 + j], k = e & 0x7fff;
+        io.packed = (gfloat*)((const float* const __attribute__((address_space(4)))*)ka->ra.packed)[b];
+        io.obs = obs_rows;
+        io.row = (int64_t)w * p.cap + k;
+        io.valid = !(e & 0x8000);
+        io.eps = run_eps<TRAIN>(ka, b, p.n_brains, ps);
+        io.out = nullptr;
+        io.actions = *(int8_t* const __attribute__((address_space(4)))*)&ka->ra.actions;
+        io.seed = p.seed;
+        io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
+        io.key_index = (uint32_t)k;
+        io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
+        io.x_lds_off = (from_mirror && mirrored && k < ps.xrows) ? (int)((char*)(ps.xmirror + k * kXStride) - smem_base) : -1;
+        io.c_lds_off = (int)((char*)(ps.cconst + kTileConstMax * b) - smem_base);
+#ifdef RL_PHASE_PROFILE
+        io.prof = nullptr;
+#endif
+        return ((cint*)ka->ra.kind)[b];
+    };
+    if (!fallback) {
+        // every tile on a pair of waves, one round: policy_tile1s<PAIR> (dueling kinds) / policy_pair2 (DQN, PPO)
+        const int task = __builtin_amdgcn_readfirstlane((int)ps.wtask[wave]);
+        const bool have = task >= 0;
+        const int slot = task & 255, role = __builtin_amdgcn_readfirstlane((task >> 8) & 1);
+        TileIO io;
+        Tile1Part part;
+        PairLds pl;
+        int kind = -1;
+        if (have) {
+            kind = __builtin_amdgcn_readfirstlane(tile_io(slot, io, true));
+            pl.val = ps.pairv + kPairFloatsAll * slot; pl.pmax = pl.val + kPairValFloats;
+            pl.ex = (f32x4*)((char*)ps.xmirror + ps.texoff[slot]);
+            if (kind == RL_DQN) policy_pair2<RL_DQN, RL_RUN_COHERENT>(io, lane, role, &pl, &part);
+            else if (kind == RL_PPO) policy_pair2<RL_PPO, RL_RUN_COHERENT>(io, lane, role, &pl, &part);
+            else policy_tile1s<RL_PERD3QN, RL_RUN_COHERENT, true>(io, lane, role, &pl, &part);
+        } else { lds_barrier(); lds_barrier(); }   // (the two exchanges inside a tile)
+        lds_barrier();
+        if (have && role == 0) {
+            if (kind == RL_DQN) pair_finish<RL_DQN>(io, lane, part, &pl);
+            else if (kind == RL_PPO) pair_finish<RL_PPO>(io, lane, part, &pl);
+            else tile1_finish<RL_PERD3QN>(io, lane, part.head, pl.val[j], part.draw, *(const f32x4*)((const float*)(smem_base + io.c_lds_off) + 768 + 8 + 4 * (lane >> 5)));
+        }
+    } else {
+        // more than four tiles (crowded worlds, many brains) or exchange buffers beyond the mirror: the 4-wave tile (policy_tile), two
+        // tiles at a time, rows from memory (recycle_world drained the stores); its LDS blocks lie in the mirror, which nobody reads now.
+        // Every kind's tile meets the same five workgroup barriers; a group without a tile repeats the last one with nothing valid.
+        const int grp = wave >> 2, v = wave & 3;
+        for (int t0 = 0; t0 < ntiles; t0 += 2) {
+            const int ti = t0 + grp;
+            TileIO io;
+            const int kind = __builtin_amdgcn_readfirstlane(tile_io(min(ti, ntiles - 1), io, false));
+            if (ti >= ntiles) io.valid = false;
+            if (kind == RL_DQN) policy_tile<RL_DQN, false, RL_RUN_COHERENT>(io, pol_h<kKindAll>(ps, grp), pol_aux<kKindAll>(ps, grp), pol_part<kKindAll>(ps, grp), lane, v);
+            else if (kind == RL_PPO) policy_tile<RL_PPO, false, RL_RUN_COHERENT>(io, pol_h<kKindAll>(ps, grp), pol_aux<kKindAll>(ps, grp), pol_part<kKindAll>(ps, grp), lane, v);
+            else policy_tile<RL_PERD3QN, false, RL_RUN_COHERENT>(io, pol_h<kKindAll>(ps, grp), pol_aux<kKindAll>(ps, grp), pol_part<kKindAll>(ps, grp), lane, v);
+        }
+    }
+    lds_barrier();
+}
+
 // First half of a tick: the policy.  Reads the list length and the Agent.state parity from LDS.
 template <int T, bool FIXED, int KIND, bool TRAIN>
 __device__ __forceinline__ void run_policy_half(RunParamsC* ka, int wave)
@@ -428,7 +559,8 @@ __device__ __forceinline__ void run_policy_half(RunParamsC* ka, int wave)
     const int w = blockIdx.x;
     const int n = __builtin_amdgcn_readfirstlane(ps.meta[1]), cur = __builtin_amdgcn_readfirstlane(ps.meta[2]);
     const float* obs_in = ((float* const __attribute__((address_space(4)))*)ka->ra.obs)[cur];
-    if (T <= 512) run_policy1<T, KIND, TRAIN>(p, s, ps, ka, w, n, obs_in, smem_raw, wave);
+    if constexpr (KIND == kKindAll) run_policy_all<T, TRAIN>(p, s, ps, ka, w, n, obs_in, smem_raw, wave);
+    else if constexpr (T <= 512) run_policy1<T, KIND, TRAIN>(p, s, ps, ka, w, n, obs_in, smem_raw, wave);
     else run_policy<T, KIND, TRAIN>(p, s, ps, ka, w, n, obs_in, smem_raw);
 }
 
@@ -497,22 +629,36 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
         if (t == 0 && p.so.n_acted) p.so.n_acted[w] = n0;
         if (t == 0 && p.so.acted_total && n0) atomicAdd(p.so.acted_total, (unsigned long long)n0);
     };
+    // TRAIN launches with Tracker outputs: Tracker._track_results over the post-step list (environment.py:206-207 -> tracker.py:178-266)
+    // runs on wave 1 ALONE, next to wave 0's serial section (_reproduce) and the other waves' state_prime rows: as one more job of a
+    // row-writing wave it made that wave the longest of the interval (+4 us per tick).  It reads only what _reproduce leaves alone.
+    const bool trk = TRAIN && T >= 256 && p.so.trk_tick != nullptr;   // uniform
+    auto track = [&]() { track_world_wave0(p, s, w, n1, ps.trk_scr, &ps.trk, ticks_done >= *(const int __attribute__((address_space(4)))*)&ka->ra.trk_skip); };
     if (overlapped) {
         if (tid < 64) {
             if (!p.static_families) best_agents_wave(s, n1);
             reproduce_wave0<T, true>(p, s, w, n1, nslots);
+        } else if (TRAIN && trk) {
+            if (tid < 128) track();
+            else {
+                write_observations<(T >= 256 ? T - 128 : 64)>(p, s, w, n1, p.so.obs, tid - 128);
+                step_outputs(tid - 128, T - 128);
+            }
         } else {
             write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n1, p.so.obs, tid - 64);
             step_outputs(tid - 64, T - 64);
+        }
+    } else if (TRAIN && trk) {
+        if (tid >= 64 && tid < 128) track();
+        else {
+            const int t = tid < 64 ? tid : tid - 64;
+            write_observations<(T >= 256 ? T - 64 : 64)>(p, s, w, n1, p.so.obs, t);
+            step_outputs(t, T - 64);
         }
     } else {
         write_observations<T>(p, s, w, n1, p.so.obs);
         step_outputs(tid, T);
     }
-    // Tracker._track_results over the post-step list (environment.py:206-207 -> tracker.py:178-266) on wave 1, behind its share of the
-    // rows: wave 0's serial section (_reproduce) is the longer one of this interval.  Reads only what that section leaves alone.
-    if (TRAIN && T > 64 && p.so.trk_tick && tid >= 64 && tid < 128)
-        track_world_wave0(p, s, w, n1, ps.trk_scr, &ps.trk, ticks_done >= *(const int __attribute__((address_space(4)))*)&ka->ra.trk_skip);
     lds_barrier();
     RL_MARK(63);
     for (int a = tid; a < nslots; a += T) s.src[a] = s.newidx[a];
@@ -563,14 +709,17 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
         for (int k = tid; k < n2; k += T) p.uo.src[b + k] = refill ? (short)-1 : s.src[s.order[k]];
     const RecycleRegs rr = recycle_read(s, n2);
     if (T <= 512) {   // wave 0 prepares the next tick's policy (rows grouped by brain) while the others write the Agent.state rows
-        if (tid < 64) policy_lists_wave0(p, ps, n2, tid, [&](int k) { return s.brain[s.order[k]]; });
-        else write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n2, obs_out, tid - 64, ps.xmirror, ps.xrows);
+        if (tid < 64) {
+            policy_lists_wave0(p, ps, n2, tid, [&](int k) { return s.brain[s.order[k]]; });
+            if constexpr (KIND == kKindAll) policy_schedule_wave0(p, ps, ka, tid);
+        } else write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n2, obs_out, tid - 64, ps.xmirror, ps.xrows);
     } else
         write_observations<T>(p, s, w, n2, obs_out, ps.xmirror, ps.xrows);
     RL_MARK(68);
     if (tid == 0) { ps.meta[1] = n2; ps.meta[2] = cur ^ 1; ps.meta[3] = ticks_done + 1; ps.meta[4] = ps.xmirror != nullptr; }
     // (rows the policy will read back from memory must have reached L2 first; with every row mirrored in LDS the stores just drain)
-    recycle_world<T, kSpec>(p, s, n2, tick_next, epoch_next, next_uid, max_gene, ps.xmirror == nullptr || n2 > ps.xrows, rr);
+    recycle_world<T, kSpec>(p, s, n2, tick_next, epoch_next, next_uid, max_gene, ps.xmirror == nullptr || n2 > ps.xrows, rr,
+                            KIND == kKindAll ? &ps.meta[5] : nullptr);   // (4-wave fall-back rounds read their rows from memory)
     RL_MARK(69);
 }
 
@@ -589,38 +738,92 @@ __device__ __forceinline__ void run_load_call(RunParamsC* ka)   // (inlined: loa
     PolSmem ps;
     run_carve<FIXED, KIND>(p, s, ps, smem_raw, T);
     int n0;
-    load_world<T, (T == 1024)>(p, s, (int)blockIdx.x, n0);
-    // The first tick's policy input: rows written by the previous launch (or the reset / observe call).  With the mirror they are copied
-    // into LDS here, by the whole workgroup with coalesced loads, instead of being fetched row by row by the tile waves (the row phase of
-    // a launch's first tick: 12.2k cycles against 3.5k from the mirror).
+    RL_MARK(90);
+    // Everything this call needs from memory is REQUESTED before load_world waits for its own loads -- the first tick's policy input (the
+    // Agent.state rows written by the previous launch / the reset, copied into the LDS mirror: fetched row by row by the tile waves
+    // they cost the first tick 12.2k cycles against 3.5k from the mirror) and the brains' epilogue constants -- so a launch pays ONE trip
+    // to memory, not three in a row (stamps: load_world 7.2k, rows 7.4k, constants 2.9k cycles of a launch's fixed 23k).  Wave 0
+    // builds the first tick's row lists meanwhile (4.3k cycles) and stays out of the copying.
+    const int tid = rl_tidx();
     const int first = *(cint*)&ka->ra.first;
-    const bool preload = ps.xmirror != nullptr && n0 <= ps.xrows;
-    if (preload) {
-        const float* rows = ((float* const __attribute__((address_space(4)))*)ka->ra.obs)[first] + (size_t)blockIdx.x * p.cap * RL_OBS_DIM;
-        for (int i = rl_tidx(); i < n0 * RL_OBS_DIM; i += T) {
-            const int r = i / RL_OBS_DIM;
-            ps.xmirror[r * kXStride + (i - r * RL_OBS_DIM)] = rows[i];
+    const int n_pre = ((cint*)ka->p.st.n_agents)[blockIdx.x];   // (the scalar load load_world makes as well)
+    const bool preload = ps.xmirror != nullptr && n_pre <= ps.xrows;
+    constexpr int NT = T > 64 ? T - 64 : T;            // copying threads: everybody but wave 0
+    const int pt = T > 64 ? tid - 64 : tid;
+    typedef const f32x4 __attribute__((address_space(1))) gvec;
+    gvec* rows4 = (gvec*)(((float* const __attribute__((address_space(4)))*)ka->ra.obs)[first] + (size_t)blockIdx.x * p.cap * RL_OBS_DIM);
+    // (16-byte loads over the world's contiguous rows: a world's block of cap rows starts 16-byte aligned; the last vector may reach into
+    // row n0 -- inside the world's block, or the buffer's padding row)
+    const int total = n_pre * RL_OBS_DIM, nvec = (total + 3) >> 2;
+    constexpr int U = 8, UC = 4;
+    f32x4 rv[U];
+    float cv[UC];
+    if (preload && pt >= 0 && nvec > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) rv[u] = rows4[min(u * NT + pt, nvec - 1)];
+    }
+    constexpr int CF = run_const_floats<KIND>();   // per-brain block of epilogue / head constants in LDS (layout: tile_const_src)
+    const int ctotal = ps.cconst ? CF * p.n_brains : 0;
+    auto const_src = [&](int i) -> gfloat* {
+        const int b = i / CF, j = i - CF * b;
+        gfloat* pk = (gfloat*)((const float* const __attribute__((address_space(4)))*)ka->ra.packed)[b];
+        if constexpr (KIND == kKindAll) {
+            const int kind = ((const int __attribute__((address_space(4)))*)ka->ra.kind)[b];
+            return pk + tile_const_src(kind, min(j, tile_const_floats(kind) - 1));
+        } else
+            return pk + tile_const_src(KIND, j);
+    };
+    if (ctotal > 0) {
+#pragma unroll
+        for (int u = 0; u < UC; ++u) cv[u] = *const_src(min(u * T + tid, ctotal - 1));
+    }
+    load_world<T, (T == 1024)>(p, s, (int)blockIdx.x, n0);
+    RL_MARK(91);
+    auto put_rows = [&](int q, const f32x4& v) {
+        if (q < nvec) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * q + e, r = i / RL_OBS_DIM;
+                if (i < total) ps.xmirror[r * kXStride + (i - r * RL_OBS_DIM)] = v[e];
+            }
+        }
+    };
+    if (preload && pt >= 0 && nvec > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) put_rows(u * NT + pt, rv[u]);
+        for (int base = NT * U; base < nvec; base += NT * U) {   // (worlds above ~90 agents: further batches)
+#pragma unroll
+            for (int u = 0; u < U; ++u) rv[u] = rows4[min(base + u * NT + pt, nvec - 1)];
+#pragma unroll
+            for (int u = 0; u < U; ++u) put_rows(base + u * NT + pt, rv[u]);
         }
     }
-    if (rl_tidx() == 0) { ps.meta[1] = n0; ps.meta[2] = first; ps.meta[3] = 0; ps.meta[4] = preload ? 1 : 0; }
+    RL_MARK(92);
+    if (tid == 0) { ps.meta[1] = n0; ps.meta[2] = first; ps.meta[3] = 0; ps.meta[4] = preload ? 1 : 0; }
     if (TRAIN && p.so.trk_tick) {   // the Tracker's running sums live in LDS for the length of the launch
-        const int G = p.static_families ? p.n_brains : 1, t = rl_tidx();
+        const int G = p.static_families ? p.n_brains : 1, t = tid;
         const size_t o = (size_t)blockIdx.x * G * RL_TRK_VARS;
         if (t < G * RL_TRK_VARS) { ps.trk.sum[t] = p.so.trk_sum[o + t]; ps.trk.cnt[t] = p.so.trk_cnt[o + t]; }
         if (t < 2) ps.trk.pop[t] = p.so.trk_pop[(size_t)blockIdx.x * 3 + 1 + t];
     }
-    if (T <= 512 && rl_tidx() < 64) policy_lists_wave0(p, ps, n0, rl_tidx(), [&](int k) { return s.brain[k]; });   // (slot == list index after load_world)
-    if (ps.cconst) {   // the brains' epilogue constants (three 128-wide layers x 256 floats) for policy_tile1s
-        const Layout L = layout_of(KIND);
-        for (int i = rl_tidx(); i < kTileConstFloats * p.n_brains; i += T) {
-            const int b = i / kTileConstFloats, j = i - kTileConstFloats * b, layer = j >> 8;
-            gfloat* pk = (gfloat*)((const float* const __attribute__((address_space(4)))*)ka->ra.packed)[b];
-            const int64_t off = layer == 0 ? L.l1 + frag_floats(kInChunks, 4) : layer == 1 ? L.l2a + frag_floats(8, 4) : layer == 2 ? L.l2b + frag_floats(8, 4)
-                              : (j < 768 + 16 ? L.ha : L.hb) + head_consts_off(4) - (j < 768 + 16 ? 768 : 768 + 16);
-            ps.cconst[i] = pk[off + (layer < 3 ? (j & 255) : j)];
+    if (T <= 512 && tid < 64) {
+        policy_lists_wave0(p, ps, n0, tid, [&](int k) { return s.brain[k]; });   // (slot == list index after load_world)
+        if constexpr (KIND == kKindAll) policy_schedule_wave0(p, ps, ka, tid);
+    }
+    RL_MARK(93);
+    if (ctotal > 0) {   // the brains' epilogue constants (three 128-wide layers x 256 floats + the heads') for policy_tile1s
+#pragma unroll
+        for (int u = 0; u < UC; ++u) { const int i = u * T + tid; if (i < ctotal) ps.cconst[i] = cv[u]; }
+        for (int base = T * UC; base < ctotal; base += T * UC) {   // (more than two brains)
+#pragma unroll
+            for (int u = 0; u < UC; ++u) cv[u] = *const_src(min(base + u * T + tid, ctotal - 1));
+#pragma unroll
+            for (int u = 0; u < UC; ++u) { const int i = base + u * T + tid; if (i < ctotal) ps.cconst[i] = cv[u]; }
         }
     }
+    RL_MARK(94);
     lds_barrier();
+    RL_MARK(95);
 }
 template <int T, bool FIXED, int KIND, bool TRAIN>
 __device__ __forceinline__ void run_store_call(RunParamsC* ka)
@@ -699,19 +902,24 @@ __global__ __launch_bounds__(T) void k_run(const RunParams rp)
 
 }  // namespace
 
-// rl_run: which kernel serves this handle / these brains, or 0
+// rl_run: which kernel serves these brains -- RL_PERD3QN (all of a dueling kind), kKindAll (any mix), or -1
 static int run_kind_of(const rl_brain* brains, int n_brains)
 {
     if (n_brains < 1 || n_brains > kRunMaxBrains) return -1;
     bool duel = true;
-    for (int b = 0; b < n_brains; ++b) duel = duel && (brains[b].kind == RL_D3QN || brains[b].kind == RL_PERD3QN);
-    return duel ? RL_PERD3QN : -1;   // (D3QN and PERD3QN are the same network: PERD3QN.py:186-202, D3QN.py:149-165)
+    for (int b = 0; b < n_brains; ++b) {
+        if (brains[b].kind < RL_DQN || brains[b].kind > RL_PPO) return -1;
+        duel = duel && (brains[b].kind == RL_D3QN || brains[b].kind == RL_PERD3QN);
+    }
+    return duel ? RL_PERD3QN : kKindAll;   // (D3QN and PERD3QN are the same network: PERD3QN.py:186-202, D3QN.py:149-165)
 }
 template <int KIND>
-static size_t run_smem_bytes(const rl_world* h, int T)
+static size_t run_smem_bytes(const rl_world* h, int T, int* xrows = nullptr)
 {
     PolSmem ps;
-    return carve_policy<KIND>(ps, nullptr, h->smem_bytes, h->cfg.slot_cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, h->cfg.n_brains));
+    const size_t b = carve_policy<KIND>(ps, nullptr, h->smem_bytes, h->cfg.slot_cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, h->cfg.n_brains));
+    if (xrows) *xrows = ps.xrows;
+    return b;
 }
 // Workgroup size of the multi-tick kernel: 512 threads for few worlds (the one-wave policy tile needs the 256-VGPR budget; the
 // tick half alone would prefer 1024: 10.6 vs 13.1 us at 256 worlds), 256 when there are many worlds (several per CU).
@@ -725,9 +933,17 @@ static int run_block(const rl_world* h)
 }
 int rl_world_run_supported(const rl_world* h, const rl_brain* brains, int n_brains)
 {
-    if (run_kind_of(brains, n_brains) < 0) return 0;
+    const int kind = run_kind_of(brains, n_brains);
+    if (kind < 0) return 0;
     const int T = run_block(h);
     if (h->cfg.slot_cap > T) return 0;
+    if (kind == kKindAll) {
+        // the mixed-kind kernel exists for 512-thread workgroups; its fall-back rounds put two 4-wave tile blocks into the mirror
+        if (T != 512) return 0;
+        int xrows = 0;
+        if (run_smem_bytes<kKindAll>(h, T, &xrows) > 160 * 1024) return 0;
+        return (size_t)xrows * kXStride * sizeof(float) >= 2 * (size_t)policy_group_bytes<kKindAll>();
+    }
     return run_smem_bytes<RL_PERD3QN>(h, T) <= 160 * 1024;
 }
 int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n_ticks, int8_t* actions, const rl_step_out* so,
@@ -744,26 +960,32 @@ int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n
     RunParams rp{};
     rp.p = p;
     RunArgs& ra = rp.ra;
-    for (int b = 0; b < n_brains; ++b) { ra.packed[b] = brains[b].packed; ra.eps[b] = brains[b].epsilon; }
+    for (int b = 0; b < n_brains; ++b) { ra.packed[b] = brains[b].packed; ra.eps[b] = brains[b].epsilon; ra.kind[b] = brains[b].kind; }
     ra.obs[0] = obs[0]; ra.obs[1] = obs[1]; ra.first = first; ra.n_ticks = n_ticks; ra.actions = actions; ra.eps_sched = eps_sched; ra.trk_skip = trk_skip;
     ra.debug = g_run_debug;
     if (g_run_debug) rl_set_error("rl_run: measurement mask %d is set (rl_debug_set_run_mask): the results of this launch are not valid", g_run_debug);
     const int T = run_block(h);
-    const size_t bytes = run_smem_bytes<RL_PERD3QN>(h, T);
+    const int kind = run_kind_of(brains, n_brains);
+    const size_t bytes = kind == kKindAll ? run_smem_bytes<kKindAll>(h, T) : run_smem_bytes<RL_PERD3QN>(h, T);
     const bool fixed = p.W == kFixW && p.H == kFixH && p.cap == kFixCap && p.hash_size == kFixHash && !getenv("RL_WORLD_GENERIC");
     const bool train = eps_sched != nullptr || p.so.trk_tick != nullptr;
     const void* fn = nullptr;
-#define RL_RUN_PICK(TT, FX, TR) if (T == TT && fixed == FX && train == TR) fn = (const void*)k_run<TT, FX, RL_PERD3QN, TR>;
-#ifdef RL_RUN_DEV_BUILD   /* tuning builds: only the instantiation bench.py times (compile time) */
-    RL_RUN_PICK(512, true, false)
+#define RL_RUN_PICK(TT, FX, KD, TR) if (T == TT && fixed == FX && kind == KD && train == TR) fn = (const void*)k_run<TT, FX, KD, TR>;
+#ifdef RL_RUN_DEV_BUILD   /* tuning builds: only the instantiations bench.py times (compile time) */
+    RL_RUN_PICK(512, true, RL_PERD3QN, false)
+#ifdef RL_RUN_DEV_ALL
+    RL_RUN_PICK(512, true, kKindAll, false)
+#endif
 #else
-    RL_RUN_PICK(1024, true, false) RL_RUN_PICK(1024, false, false) RL_RUN_PICK(512, true, false) RL_RUN_PICK(512, false, false)
-    RL_RUN_PICK(256, true, false) RL_RUN_PICK(256, false, false)
-    RL_RUN_PICK(1024, true, true) RL_RUN_PICK(1024, false, true) RL_RUN_PICK(512, true, true) RL_RUN_PICK(512, false, true)
-    RL_RUN_PICK(256, true, true) RL_RUN_PICK(256, false, true)
+    RL_RUN_PICK(1024, true, RL_PERD3QN, false) RL_RUN_PICK(1024, false, RL_PERD3QN, false) RL_RUN_PICK(512, true, RL_PERD3QN, false)
+    RL_RUN_PICK(512, false, RL_PERD3QN, false) RL_RUN_PICK(256, true, RL_PERD3QN, false) RL_RUN_PICK(256, false, RL_PERD3QN, false)
+    RL_RUN_PICK(1024, true, RL_PERD3QN, true) RL_RUN_PICK(1024, false, RL_PERD3QN, true) RL_RUN_PICK(512, true, RL_PERD3QN, true)
+    RL_RUN_PICK(512, false, RL_PERD3QN, true) RL_RUN_PICK(256, true, RL_PERD3QN, true) RL_RUN_PICK(256, false, RL_PERD3QN, true)
+    RL_RUN_PICK(512, true, kKindAll, false) RL_RUN_PICK(512, false, kKindAll, false)
+    RL_RUN_PICK(512, true, kKindAll, true) RL_RUN_PICK(512, false, kKindAll, true)
 #endif
 #undef RL_RUN_PICK
-    if (!fn) { rl_set_error("rl_run: no kernel instantiation for T=%d fixed=%d train=%d in this build", T, (int)fixed, (int)train); return RL_E_UNSUPPORTED; }
+    if (!fn) { rl_set_error("rl_run: no kernel instantiation for T=%d fixed=%d kind=%d train=%d in this build", T, (int)fixed, kind, (int)train); return RL_E_UNSUPPORTED; }
     if (bytes > 64 * 1024) {   // opt in to the large dynamic-LDS window (per device copy of the kernel: cheap, done every launch)
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) { rl_set_error("hipFuncSetAttribute(%zu bytes of LDS) failed: %s", bytes, hipGetErrorString(e)); return RL_E_LAUNCH; }

@@ -455,10 +455,12 @@ def test_multi_tick_launch_tracks_the_oracle_tick_by_tick():
         _cmp_rows(fused.obs_state().cpu().numpy(), ow.obs2, ow.s["n_agents"], "tick %d obs2" % t)
 
 
-def test_multi_tick_launch_falls_back_when_unsupported():
-    """PPO brains (or tracking / capture) are outside rl_run's scope: DeviceWorlds.run loops over the two launches instead."""
+def test_multi_tick_launch_falls_back_when_unsupported(monkeypatch):
+    """Mixed-kind brains at a workgroup size other than 512 threads (or capture outputs) are outside rl_run's scope: DeviceWorlds.run
+    loops over the two launches instead."""
     from reinlife_amd import _lib
     from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights
+    monkeypatch.setenv("RL_WORLD_BLOCK", "256")
     cfg = dict(width=30, height=30, max_agents=100, n_brains=2, static_families=True)
     pair = []
     for _ in range(2):

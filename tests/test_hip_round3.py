@@ -97,6 +97,7 @@ def test_trainer_fused_loop_equals_the_tick_by_tick_loop(static, monkeypatch):
     envs = []
     for fused in (True, False):
         brains = copy.deepcopy(proto)
+        np.random.seed(1234)   # world 0 is built by Environment.reset from the process-global np.random, like the reference's
         with pytest.warns(UserWarning):
             env = trainer(brains, n_episodes=130, update_interval=25, print_results=False, static_families=static, save=False,
                           n_worlds=6, seed=77, fused=fused)
@@ -126,6 +127,7 @@ def test_environment_run_is_lazy_and_splits_at_tracker_boundaries():
     proto = _brains(9)
     res = []
     for pieces in ([(0, 61)], [(0, 1), (1, 7), (8, 30), (38, 23)]):
+        np.random.seed(99)
         with pytest.warns(UserWarning):
             env = Environment(width=30, height=30, brains=copy.deepcopy(proto), max_agents=100, update_interval=20, print_results=False,
                               n_worlds=4, seed=3, rng="philox")
@@ -295,3 +297,141 @@ def test_c2_step_only_twenty_seeds_two_hundred_ticks_against_the_oracle():
                 _cmp_rows(dw.obs_state().cpu().numpy(), ow.obs2, n2, "seed %d tick %d obs2" % (seed, t))
         dw.check_error_flag()
     assert agent_steps > 20 * 200 * 10
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the multi-tick launch for brains of ANY kind (DQN, PPO, mixed): two waves per tile, the tile code picked per tile
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind_name", ["DQN", "PPO", "D3QN", "PERD3QN"])
+def test_pair_tiles_against_the_oracle_forward(kind_name, monkeypatch):
+    """RL_POLICY_VARIANT=pair (k_policy_pair: the two-waves-per-tile code rl_run's policy half runs, for every kind) against the oracle's
+    f32 forward (1e-5) for ragged row counts; for the dueling kinds the pair IS the one-wave tile bit for bit."""
+    import torch
+    from oracle import oracle as orc
+    from reinlife_amd import _lib
+    from reinlife_amd.worlds import pack_brain_weights, policy_forward
+    kind = _lib.KIND_BY_METHOD[kind_name]
+    w = _weights(kind_name, 31)
+    packed = pack_brain_weights(kind, w)
+    g = torch.Generator(device="cuda:0").manual_seed(17)
+    for n in (1, 31, 33, 257, 4099):
+        obs = (torch.randn(n + 1, 153, device="cuda:0", generator=g) * torch.rand(n + 1, 1, device="cuda:0", generator=g) * 3)[:n].contiguous()
+        monkeypatch.setenv("RL_POLICY_VARIANT", "pair")
+        out = torch.full((n, 8), float("nan"), device="cuda:0")
+        policy_forward(kind, packed, obs, out)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        want = orc.policy_forward(orc.KIND_BY_NAME[kind_name], w, obs.cpu().numpy())
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-5, err_msg="%s n=%d" % (kind_name, n))
+        if kind_name in ("D3QN", "PERD3QN"):
+            monkeypatch.setenv("RL_POLICY_VARIANT", "wave")
+            ref = torch.full((n, 8), float("nan"), device="cuda:0")
+            policy_forward(kind, packed, obs, ref)
+            torch.cuda.synchronize()
+            assert np.array_equal(got, ref.cpu().numpy()), n
+        if kind_name == "PPO":
+            np.testing.assert_allclose(got.sum(1), 1.0, rtol=0, atol=1e-5)
+
+
+def _kind_pair(names, eps, R, static, seed, **extra):
+    from reinlife_amd import _lib
+    from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights
+    cfg = dict(width=30, height=30, max_agents=100, n_brains=len(names), static_families=static, limit_reproduction=False, incentivize_killing=True)
+    cfg.update(extra)
+    wts = [_weights(n, 300 + k) for k, n in enumerate(names)]
+    out = []
+    for _ in range(2):
+        dw = DeviceWorlds(n_worlds=R, seed=seed, world_base=11, **cfg)
+        dw.set_brains([(_lib.KIND_BY_METHOD[n], e, pack_brain_weights(_lib.KIND_BY_METHOD[n], w)) for n, e, w in zip(names, eps, wts)])
+        dw.reset_synthetic(cfg["max_agents"])
+        out.append(dw)
+    return out, wts, cfg
+
+
+KIND_SETS = [(("DQN", "DQN"), (0.0, 0.2), True), (("PPO", "PERD3QN"), (0.0, 0.05), False), (("PPO", "DQN", "D3QN"), (0.0, 0.1, 0.0), True),
+             (("PPO", "PPO"), (0.0, 0.0), True), (("DQN", "PERD3QN", "PPO", "D3QN"), (0.3, 0.0, 0.0, 0.2), False)]
+
+
+@pytest.mark.parametrize("names,eps,static", KIND_SETS, ids=["+".join(k[0]) for k in KIND_SETS])
+def test_multi_tick_launch_any_brain_kinds_equals_the_two_launch_loop(names, eps, static, monkeypatch):
+    """rl_run with DQN / PPO / mixed-kind brains (the kKindAll kernel: per tile two waves running its kind's code, the waves dealt over
+    the SIMDs by cost) == n x (rl_policy_act + rl_tick_refill) with the same tiles as a stand-alone launch (RL_POLICY_VARIANT=pair):
+    worlds, observations, actions (PPO: the sampled ones), outputs, counters, for launches of 1 / 2 / 7 / 30 / 45 ticks with refills."""
+    monkeypatch.setenv("RL_POLICY_VARIANT", "pair")
+    (fused, loop), wts, cfg = _kind_pair(names, eps, 14, static, 2026)
+    assert fused.run_supported()
+    done = 0
+    for chunk in (1, 2, 7, 30, 45):
+        fused.run(chunk, 70, 100)
+        for _ in range(chunk):
+            loop.act(); loop.tick_refill(70, 100)
+        done += chunk
+        fused.check_error_flag(); loop.check_error_flag()
+        tag = "%s after %d ticks" % ("+".join(names), done)
+        _same_device_state(fused, loop, tag)
+        acted = fused.n_acted.cpu().numpy()
+        _cmp_rows(fused.actions.cpu().numpy(), loop.actions.cpu().numpy(), acted, tag + " actions")
+        assert int(fused.acted_total.item()) == int(loop.acted_total.item()) and int(fused.refill_count.item()) == int(loop.refill_count.item())
+        for name in ("reward", "done", "src1", "src2"):
+            assert np.array_equal(getattr(fused, name).cpu().numpy(), getattr(loop, name).cpu().numpy()), (tag, name)
+        assert np.array_equal(fused.obs_state_prime().cpu().numpy(), loop.obs_state_prime().cpu().numpy()), tag + " obs1"
+    assert int(fused.refill_count.item()) > 0
+
+
+def test_multi_tick_launch_mixed_kinds_tracks_the_oracle_with_tracker_and_schedule():
+    """PPO + PERD3QN, non-static families (BASELINE configs[4] per GPU), as a TRAINING launch (epsilon schedule + Tracker): run(1) per
+    tick against the oracle fed the chosen actions; every 8th tick the actions themselves against the oracle's selection rule applied
+    to the oracle's f32 forward (PPO: where the inverse-CDF sample is not within 1e-5 of a bin edge; PERD3QN: where the top two Q
+    values are 1e-5 apart)."""
+    from oracle import oracle as orc
+    names, eps0 = ("PPO", "PERD3QN"), (0.0, 0.0)
+    (fused, _), wts, cfg = _kind_pair(names, eps0, 12, False, 515)
+    fused.enable_tracking(True)
+    ow = orc.OracleWorlds(n_worlds=12, seed=515, world_base=11, **cfg)
+    ow.reset_synthetic(100)
+    checked = 0
+    for t in range(48):
+        n = ow.s["n_agents"].copy()
+        e1 = 0.0 if t % 8 == 0 else 0.3
+        fused.run(1, 70, 100, eps_schedule=np.array([[0.0, e1]], np.float32))
+        acts = fused.actions.cpu().numpy().copy()
+        if t % 8 == 0:
+            for b, name in enumerate(names):
+                ws, ks = np.nonzero((np.arange(fused.cap)[None, :] < n[:, None]) & (ow.s["a_brain"] == b))
+                q = orc.policy_forward(orc.KIND_BY_NAME[name], wts[b], ow.obs2[ws, ks])
+                want = orc.select_actions(ow.cfg, orc.KIND_BY_NAME[name], q, ws, ks, ow.s["tick"], ow.s["epoch"], 0.0)
+                if name == "PPO":   # a sample that lies within 1e-5 of a CDF edge may fall either way
+                    u = np.array([(orc.philox(515, int(ow.s["epoch"][w]), 11 + int(w), int(ow.s["tick"][w]), 5, int(k))[0] >> 8) / 16777216.0
+                                  for w, k in zip(ws, ks)])
+                    clear = np.abs(np.cumsum(q, axis=1) - u[:, None]).min(1) > 1e-5
+                else:
+                    srt = np.sort(q, axis=1)
+                    clear = srt[:, -1] - srt[:, -2] > 1e-5
+                assert np.array_equal(acts[ws, ks][clear], want[clear]), (t, name)
+                checked += int(clear.sum())
+        ow.step(acts)
+        assert np.array_equal(fused.trk_tick.cpu().numpy(), ow.trk_tick), t
+        ow.update(); ow.refill(70, 100)
+        fused.check_error_flag()
+        _cmp_state(fused, ow, "tick %d" % t)
+        _cmp_rows(fused.obs_state().cpu().numpy(), ow.obs2, ow.s["n_agents"], "tick %d obs2" % t)
+    assert checked > 1000
+
+
+def test_multi_tick_launch_many_tiles_run_the_four_wave_rounds(monkeypatch):
+    """Eight brains of all four kinds: every world has more than four tiles, so the kKindAll kernel runs its fall-back rounds (4-wave
+    tiles, two at a time, rows from memory, LDS blocks inside the mirror) in every tick -- the arithmetic of the stand-alone mixed-kind
+    launch, with which it must agree bit for bit; plus a crowded configuration (200 agents: slot capacity 448)."""
+    names = ("DQN", "PPO", "D3QN", "PERD3QN", "PPO", "DQN", "PERD3QN", "D3QN")
+    eps = (0.1, 0.0, 0.0, 0.2, 0.0, 0.0, 0.0, 0.0)
+    monkeypatch.delenv("RL_POLICY_VARIANT", raising=False)
+    for extra, thr in ((dict(), 70), (dict(max_agents=200), 120)):
+        (fused, loop), wts, cfg = _kind_pair(names, eps, 10, True, 77, **extra)
+        assert fused.run_supported()
+        for chunk in (1, 5, 24):
+            fused.run(chunk, thr, cfg["max_agents"])
+            for _ in range(chunk):
+                loop.act(); loop.tick_refill(thr, cfg["max_agents"])
+            fused.check_error_flag(); loop.check_error_flag()
+            _same_device_state(fused, loop, "8 brains, chunk %d" % chunk)
+            _cmp_rows(fused.actions.cpu().numpy(), loop.actions.cpu().numpy(), fused.n_acted.cpu().numpy(), "actions")
