@@ -67,7 +67,7 @@ struct PolSmem {
     double* trk_scr;    // [cap] scratch of the Tracker pass (track_world_wave0)
     TrkLds trk;         // the Tracker's running sums for the length of the launch
     // kKindAll kernels: the policy half's schedule, written by wave 0 next to the row lists (policy_schedule_wave0).  meta[5]: 0 = every
-    // tile gets a wave pair in ONE round (<= 4 tiles whose exchange buffers fit into the mirror), 1 = 4-wave tiles in rounds of two
+    // tile gets a wave pair in ONE round (<= 4 tiles whose exchange buffers fit into the mirror), 1 = rounds of meta[6] tiles
     short* wtask;       // [8]  per wave: tile | role << 8, or -1
     int* texoff;        // [4]  per tile: byte offset of its exchange buffer inside the mirror
 };
@@ -112,7 +112,6 @@ __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o
     if (n_cbrains > 0) { ps.pairv = (float*)(base + o); o = align16(o + sizeof(float) * 4 * run_pair_floats<KIND>()); }
     ps.wtask = (short*)(base + o); o = align16(o + sizeof(short) * 8);
     ps.texoff = (int*)(base + o); o = align16(o + sizeof(int) * 4);
-    if (KIND == kKindAll && groups == 0 && ps.xmirror) ps.group0 = (char*)ps.xmirror;   // the 4-wave tiles of the fall-back rounds work in the (then unused) mirror
     ps.trk_scr = (double*)(base + o); o = align16(o + sizeof(double) * (size_t)cap);
     ps.trk.sum = (double*)(base + o); o = align16(o + sizeof(double) * kRunMaxBrains * RL_TRK_VARS);
     ps.trk.pop = (double*)(base + o); o = align16(o + sizeof(double) * 2);
@@ -360,7 +359,7 @@ __device__ inline void policy_lists_wave0(const KParams& p, PolSmem& ps, int n, 
 // is handled by TWO waves (policy_tile1s<PAIR> / policy_pair2) when the world has at most four tiles and their exchange buffers fit into
 // the Agent.state mirror; the two roles of a tile may sit on any two wave slots (only LDS and the workgroup barriers connect them), so
 // the tiles are dealt heaviest first, each role onto the least loaded SIMD with a free slot (waves v and v + 4 share SIMD v): a PPO tile
-// (672 MFMAs) next to a dueling one (360) loads every SIMD with 516 instead of 672 / 360.  Otherwise: 4-wave tiles, two at a time.
+// (672 MFMAs) next to a dueling one (360) loads every SIMD with 516 instead of 672 / 360.  Otherwise: the same tiles in several rounds.
 __device__ inline void policy_schedule_wave0(const KParams& p, PolSmem& ps, RunParamsC* ka, int lane)
 {
     typedef const int __attribute__((address_space(4))) cint;
@@ -379,6 +378,8 @@ __device__ inline void policy_schedule_wave0(const KParams& p, PolSmem& ps, RunP
     }
     pair_ok = pair_ok && (size_t)total_ex <= (size_t)ps.xrows * kXStride * sizeof(float);
     ps.meta[5] = pair_ok ? 0 : 1;
+    const int fit = (int)(((size_t)ps.xrows * kXStride * sizeof(float)) / (size_t)pair_ex_bytes(RL_PPO));
+    ps.meta[6] = fit < 1 ? 1 : (fit > 4 ? 4 : fit);   // tiles per round when the tiles take several rounds
     for (int v = 0; v < 8; ++v) ps.wtask[v] = (short)-1;
     if (!pair_ok) return;
     for (int a = 1; a < nt; ++a)   // insertion sort, heaviest first (stable)
@@ -506,19 +507,16 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
 #endif
         return ((cint*)ka->ra.kind)[b];
     };
-    if (!fallback) {
-        // every tile on a pair of waves, one round: policy_tile1s<PAIR> (dueling kinds) / policy_pair2 (DQN, PPO)
-        const int task = __builtin_amdgcn_readfirstlane((int)ps.wtask[wave]);
-        const bool have = task >= 0;
-        const int slot = task & 255, role = __builtin_amdgcn_readfirstlane((task >> 8) & 1);
+    // One tile on a pair of waves: policy_tile1s<PAIR> (dueling kinds) / policy_pair2 (DQN, PPO); every wave meets the same barriers.
+    auto pair_round = [&](bool have, int ti, int role, int slot, int ex_off, bool from_mirror) {
         TileIO io;
         Tile1Part part;
         PairLds pl;
         int kind = -1;
         if (have) {
-            kind = __builtin_amdgcn_readfirstlane(tile_io(slot, io, true));
+            kind = __builtin_amdgcn_readfirstlane(tile_io(ti, io, from_mirror));
             pl.val = ps.pairv + kPairFloatsAll * slot; pl.pmax = pl.val + kPairValFloats;
-            pl.ex = (f32x4*)((char*)ps.xmirror + ps.texoff[slot]);
+            pl.ex = (f32x4*)((char*)ps.xmirror + ex_off);
             if (kind == RL_DQN) policy_pair2<RL_DQN, RL_RUN_COHERENT>(io, lane, role, &pl, &part);
             else if (kind == RL_PPO) policy_pair2<RL_PPO, RL_RUN_COHERENT>(io, lane, role, &pl, &part);
             else policy_tile1s<RL_PERD3QN, RL_RUN_COHERENT, true>(io, lane, role, &pl, &part);
@@ -529,20 +527,22 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
             else if (kind == RL_PPO) pair_finish<RL_PPO>(io, lane, part, &pl);
             else tile1_finish<RL_PERD3QN>(io, lane, part.head, pl.val[j], part.draw, *(const f32x4*)((const float*)(smem_base + io.c_lds_off) + 768 + 8 + 4 * (lane >> 5)));
         }
-    } else {
-        // more than four tiles (crowded worlds, many brains) or exchange buffers beyond the mirror: the 4-wave tile (policy_tile), two
-        // tiles at a time, rows from memory (recycle_world drained the stores); its LDS blocks lie in the mirror, which nobody reads now.
-        // Every kind's tile meets the same five workgroup barriers; a group without a tile repeats the last one with nothing valid.
-        const int grp = wave >> 2, v = wave & 3;
-        for (int t0 = 0; t0 < ntiles; t0 += 2) {
-            const int ti = t0 + grp;
-            TileIO io;
-            const int kind = __builtin_amdgcn_readfirstlane(tile_io(min(ti, ntiles - 1), io, false));
-            if (ti >= ntiles) io.valid = false;
-            if (kind == RL_DQN) policy_tile<RL_DQN, false, RL_RUN_COHERENT>(io, pol_h<kKindAll>(ps, grp), pol_aux<kKindAll>(ps, grp), pol_part<kKindAll>(ps, grp), lane, v);
-            else if (kind == RL_PPO) policy_tile<RL_PPO, false, RL_RUN_COHERENT>(io, pol_h<kKindAll>(ps, grp), pol_aux<kKindAll>(ps, grp), pol_part<kKindAll>(ps, grp), lane, v);
-            else policy_tile<RL_PERD3QN, false, RL_RUN_COHERENT>(io, pol_h<kKindAll>(ps, grp), pol_aux<kKindAll>(ps, grp), pol_part<kKindAll>(ps, grp), lane, v);
-        }
+    };
+    // meta[5] == 0: every tile in ONE round, the waves dealt over the SIMDs by cost (policy_schedule_wave0), rows from the mirror.
+    // Otherwise (crowded worlds, many brains): rounds of meta[6] tiles on fixed wave pairs (waves s and s + 4), a 32 KB exchange buffer
+    // per slot; round 1's buffers overwrite the mirror, so every tile reads its rows from memory (recycle_world drained the stores).
+    // The same tiles, hence the same bits, either way.  (ONE call site: the tile code exists once in the kernel.)
+    const int pr = __builtin_amdgcn_readfirstlane(ps.meta[6]);
+    const int task = __builtin_amdgcn_readfirstlane((int)ps.wtask[wave]);
+    const int n_rounds = fallback ? (ntiles + pr - 1) / pr : 1;
+    for (int r = 0; r < n_rounds; ++r) {
+        const int slot = fallback ? (wave & 3) : (task & 255);
+        const int ti = fallback ? r * pr + slot : slot;
+        const bool have = fallback ? (slot < pr && ti < ntiles) : task >= 0;
+        const int role = __builtin_amdgcn_readfirstlane(fallback ? (wave >> 2) : ((task >> 8) & 1));
+        const int ex_off = fallback ? slot * pair_ex_bytes(RL_PPO) : (have ? ps.texoff[slot] : 0);
+        pair_round(have, ti, role, slot, ex_off, !fallback);
+        if (fallback) lds_barrier();   // (the finish read this round's partials; the next round overwrites them)
     }
     lds_barrier();
 }
@@ -719,7 +719,7 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     if (tid == 0) { ps.meta[1] = n2; ps.meta[2] = cur ^ 1; ps.meta[3] = ticks_done + 1; ps.meta[4] = ps.xmirror != nullptr; }
     // (rows the policy will read back from memory must have reached L2 first; with every row mirrored in LDS the stores just drain)
     recycle_world<T, kSpec>(p, s, n2, tick_next, epoch_next, next_uid, max_gene, ps.xmirror == nullptr || n2 > ps.xrows, rr,
-                            KIND == kKindAll ? &ps.meta[5] : nullptr);   // (4-wave fall-back rounds read their rows from memory)
+                            KIND == kKindAll ? &ps.meta[5] : nullptr);   // (tiles that take several rounds read their rows from memory)
     RL_MARK(69);
 }
 
@@ -938,11 +938,11 @@ int rl_world_run_supported(const rl_world* h, const rl_brain* brains, int n_brai
     const int T = run_block(h);
     if (h->cfg.slot_cap > T) return 0;
     if (kind == kKindAll) {
-        // the mixed-kind kernel exists for 512-thread workgroups; its fall-back rounds put two 4-wave tile blocks into the mirror
+        // the mixed-kind kernel exists for 512-thread workgroups; the tiles' exchange buffers (32 KB for a PPO tile) lie in the mirror
         if (T != 512) return 0;
         int xrows = 0;
         if (run_smem_bytes<kKindAll>(h, T, &xrows) > 160 * 1024) return 0;
-        return (size_t)xrows * kXStride * sizeof(float) >= 2 * (size_t)policy_group_bytes<kKindAll>();
+        return (size_t)xrows * kXStride * sizeof(float) >= (size_t)pair_ex_bytes(RL_PPO);   // (at least one tile per round)
     }
     return run_smem_bytes<RL_PERD3QN>(h, T) <= 160 * 1024;
 }

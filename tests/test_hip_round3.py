@@ -418,13 +418,13 @@ def test_multi_tick_launch_mixed_kinds_tracks_the_oracle_with_tracker_and_schedu
     assert checked > 1000
 
 
-def test_multi_tick_launch_many_tiles_run_the_four_wave_rounds(monkeypatch):
-    """Eight brains of all four kinds: every world has more than four tiles, so the kKindAll kernel runs its fall-back rounds (4-wave
-    tiles, two at a time, rows from memory, LDS blocks inside the mirror) in every tick -- the arithmetic of the stand-alone mixed-kind
-    launch, with which it must agree bit for bit; plus a crowded configuration (200 agents: slot capacity 448)."""
+def test_multi_tick_launch_many_tiles_take_several_rounds(monkeypatch):
+    """Eight brains of all four kinds: every world has more than four tiles, so the kKindAll kernel runs the tiles in rounds (fixed wave
+    pairs, 32 KB exchange buffer per slot, rows from memory) -- the same tiles, the same bits as the stand-alone pair launch; plus a
+    crowded configuration (200 agents: slot capacity 448, a smaller mirror)."""
     names = ("DQN", "PPO", "D3QN", "PERD3QN", "PPO", "DQN", "PERD3QN", "D3QN")
     eps = (0.1, 0.0, 0.0, 0.2, 0.0, 0.0, 0.0, 0.0)
-    monkeypatch.delenv("RL_POLICY_VARIANT", raising=False)
+    monkeypatch.setenv("RL_POLICY_VARIANT", "pair")
     for extra, thr in ((dict(), 70), (dict(max_agents=200), 120)):
         (fused, loop), wts, cfg = _kind_pair(names, eps, 10, True, 77, **extra)
         assert fused.run_supported()
