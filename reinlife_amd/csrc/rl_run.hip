@@ -70,6 +70,7 @@ struct PolSmem {
     // tile gets a wave pair in ONE round (<= 4 tiles whose exchange buffers fit into the mirror), 1 = rounds of meta[6] tiles
     short* wtask;       // [8]  per wave: tile | role << 8, or -1
     int* texoff;        // [4]  per tile: byte offset of its exchange buffer inside the mirror
+    int* bkind;         // [8]  the brains' kinds (filled once per launch)
 };
 template <int KIND>
 __host__ __device__ constexpr int policy_group_bytes()
@@ -112,6 +113,7 @@ __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o
     if (n_cbrains > 0) { ps.pairv = (float*)(base + o); o = align16(o + sizeof(float) * 4 * run_pair_floats<KIND>()); }
     ps.wtask = (short*)(base + o); o = align16(o + sizeof(short) * 8);
     ps.texoff = (int*)(base + o); o = align16(o + sizeof(int) * 4);
+    ps.bkind = (int*)(base + o); o = align16(o + sizeof(int) * kRunMaxBrains);
     ps.trk_scr = (double*)(base + o); o = align16(o + sizeof(double) * (size_t)cap);
     ps.trk.sum = (double*)(base + o); o = align16(o + sizeof(double) * kRunMaxBrains * RL_TRK_VARS);
     ps.trk.pop = (double*)(base + o); o = align16(o + sizeof(double) * 2);
@@ -362,41 +364,36 @@ __device__ inline void policy_lists_wave0(const KParams& p, PolSmem& ps, int n, 
 // (672 MFMAs) next to a dueling one (360) loads every SIMD with 516 instead of 672 / 360.  Otherwise: the same tiles in several rounds.
 __device__ inline void policy_schedule_wave0(const KParams& p, PolSmem& ps, RunParamsC* ka, int lane)
 {
-    typedef const int __attribute__((address_space(4))) cint;
-    const int nt = read_lane(ps.meta[0], 0);
-    if (lane != 0) return;
-    int cost[4], ex[4], order[4];
-    int total_ex = 0;
-    bool pair_ok = nt <= 4 && ps.xmirror != nullptr && ps.pairv != nullptr;
-    for (int t = 0; t < 4 && t < nt; ++t) {
-        const int kind = ((cint*)ka->ra.kind)[ps.tbrain[t]];
-        cost[t] = kind == RL_PPO ? 672 : kind == RL_DQN ? 180 : 360;   // MFMAs per tile
-        ex[t] = pair_ex_bytes(kind);
-        ps.texoff[t] = total_ex;
-        total_ex += ex[t];
-        order[t] = t;
+    // Lane-parallel and in closed form (as serial single-lane code with a memory load per tile this cost 5.5k cycles on the wave that is
+    // the longest of its interval): lane t < 4 owns tile t.  With at most four tiles the balanced deal has a fixed shape -- the heaviest
+    // tile's roles on SIMDs 0 and 1, the second's on SIMDs 2 and 3, the lightest joins the heaviest, the third the second -- so a wave
+    // only needs the tile of the cost RANK its slot stands for.
+    const int nt = __builtin_amdgcn_readfirstlane(ps.meta[0]);
+    const int t = lane & 3;
+    const int kind = ps.bkind[ps.tbrain[t] & (kRunMaxBrains - 1)];
+    const int cost = t < nt ? (kind == RL_PPO ? 672 : kind == RL_DQN ? 180 : 360) : 0;   // MFMAs per tile
+    const int ex = t < nt ? pair_ex_bytes(kind) : 0;
+    int rank = 0, off = 0, total_ex = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int cu = __builtin_amdgcn_readlane(cost, u), eu = __builtin_amdgcn_readlane(ex, u);
+        rank += (cu > cost || (cu == cost && u < t)) ? 1 : 0;
+        off += u < t ? eu : 0;
+        total_ex += eu;
     }
-    pair_ok = pair_ok && (size_t)total_ex <= (size_t)ps.xrows * kXStride * sizeof(float);
-    ps.meta[5] = pair_ok ? 0 : 1;
-    const int fit = (int)(((size_t)ps.xrows * kXStride * sizeof(float)) / (size_t)pair_ex_bytes(RL_PPO));
-    ps.meta[6] = fit < 1 ? 1 : (fit > 4 ? 4 : fit);   // tiles per round when the tiles take several rounds
-    for (int v = 0; v < 8; ++v) ps.wtask[v] = (short)-1;
-    if (!pair_ok) return;
-    for (int a = 1; a < nt; ++a)   // insertion sort, heaviest first (stable)
-        for (int b = a; b > 0 && cost[order[b]] > cost[order[b - 1]]; --b) { const int x = order[b]; order[b] = order[b - 1]; order[b - 1] = x; }
-    int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
-    for (int a = 0; a < nt; ++a) {
-        const int t = order[a];
-        int taken = -1;
-        for (int role = 0; role < 2; ++role) {
-            int best = -1;
-            for (int sd = 0; sd < 4; ++sd)
-                if (used[sd] < 2 && sd != taken && (best < 0 || load[sd] < load[best])) best = sd;
-            if (best < 0)   // (cannot happen with <= 4 tiles: 8 slots, two roles on distinct SIMDs)
-                for (int sd = 0; sd < 4; ++sd) if (used[sd] < 2) best = sd;
-            ps.wtask[best + 4 * used[best]] = (short)(t | (role << 8));
-            used[best] += 1; load[best] += cost[t] / 2; taken = best;
-        }
+    const size_t mirror_bytes = (size_t)ps.xrows * kXStride * sizeof(float);
+    const bool pair_ok = nt <= 4 && ps.xmirror != nullptr && ps.pairv != nullptr && (size_t)total_ex <= mirror_bytes;
+    const int fit = (int)(mirror_bytes / (size_t)pair_ex_bytes(RL_PPO));
+    // wave v = slot (v >> 2) of SIMD v & 3: ranks 0 0 1 1 / 3 3 2 2 (heaviest with lightest, second with third), role = v & 1
+    const int want = (0x22331100 >> (4 * (lane & 7))) & 15;
+    int tile = -1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (u < nt && __builtin_amdgcn_readlane(rank, u) == want) tile = u;
+    if (lane < 4) ps.texoff[lane] = off;
+    if (lane < 8) ps.wtask[lane] = (short)((pair_ok && tile >= 0) ? (tile | ((lane & 1) << 8)) : -1);
+    if (lane == 0) {
+        ps.meta[5] = pair_ok ? 0 : 1;
+        ps.meta[6] = fit < 1 ? 1 : (fit > 4 ? 4 : fit);   // tiles per round when the tiles take several rounds
     }
 }
 
@@ -483,6 +480,9 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
     static_assert(T == 512, "kKindAll: 512-thread workgroups");
     typedef const int __attribute__((address_space(4))) cint;
     const int lane = rl_lane_fresh(), j = lane & 31;
+#ifdef RL_PHASE_PROFILE
+    if (p.prof && (int)blockIdx.x == p.prof_world && wave == 0 && lane == 0) p.prof[100] = (long long)clock64();
+#endif
     const int ntiles = __builtin_amdgcn_readfirstlane(ps.meta[0]);
     const bool mirrored = ps.xmirror != nullptr && __builtin_amdgcn_readfirstlane(ps.meta[4]) != 0;
     const bool fallback = __builtin_amdgcn_readfirstlane(ps.meta[5]) != 0;
@@ -544,7 +544,14 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
         pair_round(have, ti, role, slot, ex_off, !fallback);
         if (fallback) lds_barrier();   // (the finish read this round's partials; the next round overwrites them)
     }
+#ifdef RL_PHASE_PROFILE
+    if (p.prof && (int)blockIdx.x == p.prof_world && lane == 0) p.prof[116 + wave] = (long long)clock64();   // (128 slots)
+    if (p.prof && (int)blockIdx.x == p.prof_world && wave == 0 && lane == 0) p.prof[111] = (long long)clock64();
+#endif
     lds_barrier();
+#ifdef RL_PHASE_PROFILE
+    if (p.prof && (int)blockIdx.x == p.prof_world && wave == 0 && lane == 0) p.prof[112] = (long long)clock64();
+#endif
 }
 
 // First half of a tick: the policy.  Reads the list length and the Agent.state parity from LDS.
@@ -711,8 +718,13 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     if (T <= 512) {   // wave 0 prepares the next tick's policy (rows grouped by brain) while the others write the Agent.state rows
         if (tid < 64) {
             policy_lists_wave0(p, ps, n2, tid, [&](int k) { return s.brain[s.order[k]]; });
+            RL_MARK_T(96, 0);
             if constexpr (KIND == kKindAll) policy_schedule_wave0(p, ps, ka, tid);
-        } else write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n2, obs_out, tid - 64, ps.xmirror, ps.xrows);
+            RL_MARK_T(97, 0);
+        } else {
+            write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n2, obs_out, tid - 64, ps.xmirror, ps.xrows);
+            RL_MARK_T(98, 64); RL_MARK_T(99, T - 64);
+        }
     } else
         write_observations<T>(p, s, w, n2, obs_out, ps.xmirror, ps.xrows);
     RL_MARK(68);
@@ -807,6 +819,7 @@ __device__ __forceinline__ void run_load_call(RunParamsC* ka)   // (inlined: loa
         if (t < 2) ps.trk.pop[t] = p.so.trk_pop[(size_t)blockIdx.x * 3 + 1 + t];
     }
     if (T <= 512 && tid < 64) {
+        if constexpr (KIND == kKindAll) { if (tid < kRunMaxBrains) ps.bkind[tid] = tid < p.n_brains ? ((const int __attribute__((address_space(4)))*)ka->ra.kind)[tid] : RL_D3QN; }
         policy_lists_wave0(p, ps, n0, tid, [&](int k) { return s.brain[k]; });   // (slot == list index after load_world)
         if constexpr (KIND == kKindAll) policy_schedule_wave0(p, ps, ka, tid);
     }

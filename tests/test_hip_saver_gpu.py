@@ -80,4 +80,6 @@ def test_reference_pretrained_brains_load_and_forward_through_hip(tmp_path):
         np.testing.assert_allclose(out / scale, want / scale, rtol=0, atol=1e-5, err_msg=name)
         # the scalar attributes the reference's Saver wrote next to the brain are the ones this build's brains expose
         for k in meta[name]["parameters"]:
+            if k == "one":   # a constant of the reference's BasicBrain (Models/utils.py:7): not an attribute here, the Saver writes it
+                continue
             assert hasattr(b, k), (name, k)

@@ -6,7 +6,7 @@ code = r'''
 import os, sys, time
 sys.path.insert(0, %r)
 import torch, bench
-args = __import__("argparse").Namespace(worlds=256, workload="c4", seed=1)
+args = __import__("argparse").Namespace(worlds=256, workload=os.environ.get("RL_AB_WORKLOAD", "c4"), seed=1)
 a = bench.make_worlds(args, 0, "cuda:0")
 a.run(600, 70, 100); torch.cuda.synchronize()
 before = int(a.acted_total.item()); t0 = time.perf_counter(); a.run(2000, 70, 100); torch.cuda.synchronize(); dt = time.perf_counter() - t0

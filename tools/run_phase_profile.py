@@ -12,7 +12,7 @@ NAMES = ["entry -> tile known (lists were built during the previous tick)", "til
          "barrier (partner wave, other tiles)", "dueling combine, argmax, stores, barrier"]
 IDX = [100, 110, 101, 102, 104, 105, 106, 109, 111, 112]
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-args = __import__("argparse").Namespace(worlds=R, workload="c4", seed=1)
+args = __import__("argparse").Namespace(worlds=R, workload=os.environ.get("RL_AB_WORKLOAD", "c4"), seed=1)
 dw = bench.make_worlds(args, 0, "cuda:0")
 stamps = torch.zeros(128, dtype=torch.int64, device="cuda:0")
 lib = _lib.lib()

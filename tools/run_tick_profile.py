@@ -13,12 +13,13 @@ IDX = [112, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69]
 SUB = [60, 2, 3, 35, 36, 37, 4, 5, 6, 61]   # inside Environment.step
 SUBN = ["act + attack + prep", "conflict loop", "eat + vanish flags (+bar)", "clear old cells (+bar)", "place + death + hash", "(mark 4)", "rewards", "food count + bitmap", "food placement .. end"]
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-args = __import__("argparse").Namespace(worlds=R, workload="c4", seed=1)
+args = __import__("argparse").Namespace(worlds=R, workload=os.environ.get("RL_AB_WORKLOAD", "c4"), seed=1)
 dw = bench.make_worlds(args, 0, "cuda:0")
 stamps = torch.zeros(128, dtype=torch.int64, device="cuda:0")
 lib = _lib.lib()
 dw.run(50, 70, 100)
 acc = []
+iv = []
 sub = []
 sub2 = []
 SUB2 = [62, 14, 41, 42, 63]   # inside the reproduce interval (wave 0)
@@ -28,6 +29,9 @@ for t in range(40):
     dw.run(int(os.environ.get("RL_PROFILE_TICKS", "0")) or (20 + t % 5), 70, 100)   # the stamps of the LAST tick remain (RL_PROFILE_TICKS=1: a launch's FIRST tick)
     torch.cuda.synchronize()
     st = stamps.cpu().numpy()[IDX]
+    raw_all = stamps.cpu().numpy().astype(np.float64)
+    if raw_all[96] and raw_all[67]:
+        iv.append([raw_all[96] - raw_all[67], raw_all[97] - raw_all[96], raw_all[98] - raw_all[67], raw_all[99] - raw_all[67], raw_all[68] - raw_all[67]])
     if st.all() and (np.diff(st) > 0).all():
         acc.append(np.diff(st))
         sub.append(np.diff(stamps.cpu().numpy()[SUB]))
@@ -43,3 +47,6 @@ for n, v in zip(SUBN, ms):
     print("      %-60s %8.0f" % (n, v))
 if sub2:
     print("inside reproduce (wave 0): gates + parents | placements | produce | newborns, dead -> food, barrier:", np.mean(sub2, axis=0).round(0))
+
+if iv:
+    print("the lists || obs2 interval (cycles from its start): wave 0 lists done %.0f, + schedule %.0f | wave 1 rows done %.0f, last wave rows done %.0f | thread 0 leaves %.0f" % tuple(np.mean(iv, axis=0)))
