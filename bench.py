@@ -100,12 +100,19 @@ def one_step(dw):
 FUSED_CHUNK = 2000  # ticks per rl_run launch (a launch of 2000 ticks lasts ~50 ms; each launch costs ~40 us of start-up)
 
 
-def run_ticks(dw, n, fused):
-    """n trainer-loop ticks of every world of `dw`."""
+def run_ticks(dw, n, fused, events=None):
+    """n trainer-loop ticks of every world of `dw`.  events: a list that receives (start, end, ticks) HIP-event pairs recorded on the
+    launch stream around every multi-tick launch (the kernel's duration over the timed region)."""
     if fused:
         while n > 0:
             k = min(n, FUSED_CHUNK)
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             dw.run(k, 70, 100)      # k_run: policy + step + update_env + refill, k ticks in one launch
+            if events is not None:
+                e1.record()
+                events.append((e0, e1, k))
             n -= k
     else:
         for _ in range(n):
@@ -274,12 +281,14 @@ def main():
     if args.path == "fused" and not fused:
         raise SystemExit("bench.py: --path fused is not available for this workload (brain kinds) / --groups")
 
-    def advance(n):
+    timed_events = []
+
+    def advance(n, events=None):
         if grp:
             for _ in range(n):
                 step_all()
         else:
-            run_ticks(dw, n, fused)
+            run_ticks(dw, n, fused, events)
 
     advance(args.burnin)   # set-up, untimed: past the start-up transient (see the module docstring)
     torch.cuda.synchronize()
@@ -301,7 +310,10 @@ def main():
             pass
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    advance(args.steps)
+    # (HIP events around the launches of the timed region itself when it is long; a short region -- the driver's 20 steps are ONE launch
+    # of ~0.5 ms -- is not burdened with the two event records (~1 % of it): its launch is replayed right afterwards, see below)
+    events_in_region = fused and not args.no_kernel_timing and args.steps >= 200
+    advance(args.steps, timed_events if events_in_region else None)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -338,14 +350,25 @@ def main():
                 return e0.elapsed_time(e1) * 1e-3 / n, (int(dw.acted_total.item()) - int(before.item())) / n
             finally:
                 _lib.lib().rl_debug_set_run_mask(0)
-        t_all, per_tick = timed_run(300)
+        # the dominant kernel over the TIMED REGION: HIP events around its launches there (recorded on the launch stream); for a short
+        # region, around a replay of its launch (same number of ticks) queued directly behind a warm launch, so that the events see
+        # the kernel and not the host's launch latency in front of it
+        if events_in_region:
+            t_all = sum(e0.elapsed_time(e1) for e0, e1, _ in timed_events) * 1e-3 / sum(k for _, _, k in timed_events)
+            per_tick = float(rank_table[rank, 0]) / args.steps
+            launches = [k for _, _, k in timed_events]
+        else:
+            t_all, per_tick = timed_run(min(args.steps, FUSED_CHUNK))
+            launches = [min(args.steps, FUSED_CHUNK)]
         wl = WORKLOADS[args.workload]
         flop = float(np.mean([POLICY_FLOP_PER_AGENT[n] for n in wl["brains"]]))
         by = TICK_BYTES_PER_AGENT_STEP + POLICY_BYTES_PER_AGENT
         fused_roof = {"kernel": "k_run (rl_run: policy + step + update_env + refill, worlds resident in LDS)", "bound": "hbm",
                       "achieved": round(per_tick * by / t_all / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": round(per_tick * by / t_all / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
-                      "avg_tick_us": round(t_all * 1e6, 2), "ticks_per_launch": 300, "agent_steps_per_tick": round(per_tick, 1),
+                      "avg_tick_us": round(t_all * 1e6, 2), "ticks_per_launch": launches, "agent_steps_per_tick": round(per_tick, 1),
+                      "how": "HIP events on the launch stream around " + ("the launches of the timed region" if events_in_region else
+                             "a replay of the timed region's launch, queued directly behind a warm launch (the region itself is too short to carry event records)"),
                       "bytes_per_agent_step": by,
                       "mfma_tflops": round(per_tick * flop / t_all / 1e12, 2), "mfma_frac": round(per_tick * flop / t_all / 1e12 / MFMA_F32_EQUIV_PEAK_TFLOPS, 5)}
         # PMC bytes need rocprofv3 (tools/pmc_traffic.sh), so they come from a tracked file -- stamped with the hash of the kernel
