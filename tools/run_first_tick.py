@@ -12,7 +12,7 @@ stamps = torch.zeros(128, dtype=torch.int64, device="cuda:0")
 lib = _lib.lib()
 dw.run(300, 70, 100)
 NAMES = ["entry -> world loaded, mirror / lists / constants ready", "stagger wait", "policy half of tick 0", "tick half of tick 0", "tick 1 (policy + tick)", "ticks 2 .. n-1", "store_world + drain"]
-for n in (1, 2, 20):
+for n in (1, 2, 20, 100, 500):
     acc, lacc = [], []
     for t in range(48):
         _lib.check(lib.rl_bind_phase_profile(dw.handle, C.c_void_p(stamps.data_ptr()), (37 * t + 5) % 256), "bind")
@@ -33,5 +33,7 @@ for n in (1, 2, 20):
         print("   inside the load: kernel entry -> params/carve %.0f | load_world (HBM trip, LDS init, 2 barriers) %.0f [of it: loads issued -> LDS init done %.0f, consume %.0f, barrier+occ %.0f] | mirror preload %.0f | lists (wave 0) %.0f | constants %.0f | barrier %.0f" % (
               ld[0], ld[1], ld[6], ld[7], ld[8], ld[2], ld[3], ld[4], ld[5]))
     print("launch of %d tick(s): %d samples (different worlds), mean total %.0f counts" % (n, len(acc), m.sum()))
+    if n > 2:
+        print("   ticks 2 .. n-1: %.0f counts per tick" % (m[5] / (n - 2)))
     for name, v, x in zip(NAMES, m, mx):
         print("   %-60s mean %8.0f   max %8.0f" % (name, v, x))
