@@ -197,8 +197,8 @@ int rl_tick_refill(rl_world* h, const int8_t* actions, const rl_step_out* sout, 
  * rl_tick_refill (same Philox streams), and every per-tick output is written every tick, so after the call the buffers hold
  * the LAST tick's values:
  *   actions     [R][cap]      the actions chosen in the last tick (its pre-step list order)
- *   sout        reward / done / src / obs (state_prime) / n_acted / acted_total and the Tracker accumulators as in rl_tick (the
- *               capture outputs n_post / age / brain are not produced here: RL_E_UNSUPPORTED)
+ *   sout        reward / done / src / obs (state_prime) / n_acted / acted_total and the Tracker accumulators as in rl_tick (n_post / age /
+ *               brain, the inputs of rl_capture_transitions, are not written here: rl_run_ex captures inside the launch instead)
  *   obs[2]      Agent.state ping-pong pair: tick i READS obs[(first_obs + i) & 1] (the policy's input; for i = 0 it must hold
  *               the current Agent.state rows) and WRITES the other one; after the call the current rows are in
  *               obs[(first_obs + n_ticks) & 1] and the rows the policy read for the last tick in the other buffer
@@ -221,6 +221,11 @@ typedef struct {
     int32_t trk_skip_ticks;          /* the first trk_skip_ticks ticks of the launch write trk_tick but stay out of the running sums:
                                       * episode 0 of a training run never reaches an aggregate (tracker.py:279-282 keeps the last
                                       * update_interval entries of update_interval + 1) */
+    const rl_replay* replays;        /* host array [n_brains] or NULL: every tick's transitions are appended to the brains' replay rings
+                                      * inside the launch -- what rl_capture_transitions does after a stand-alone tick (trainer.py:95-96,
+                                      * entities.py:194-208); the rings' order is Agent.learn call order per world, worlds interleaved */
+    float* policy_out;               /* device [R][cap][8] or NULL: the policy's outputs (Q values / PPO probabilities) of the LAST tick,
+                                      * indexed like `actions`; with `replays`, rl_replay.prob gets the taken action's entry every tick */
 } rl_run_opts;
 int rl_run_supported(const rl_world* h, const rl_brain* brains, int n_brains);
 int rl_run(rl_world* h, const rl_brain* brains, int n_brains, int n_ticks, int8_t* actions, const rl_step_out* sout,

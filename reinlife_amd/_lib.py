@@ -55,7 +55,7 @@ class Replay(C.Structure):
 
 class RunOpts(C.Structure):  # rl_run_opts
     _fields_ = [("threshold", C.c_int32), ("n_agents", C.c_int32), ("refill_count", C.c_void_p), ("eps_schedule", C.c_void_p),
-                ("trk_skip_ticks", C.c_int32)]
+                ("trk_skip_ticks", C.c_int32), ("replays", C.c_void_p), ("policy_out", C.c_void_p)]
 
 
 class Brain(C.Structure):

@@ -46,6 +46,9 @@ struct RunArgs {
     int8_t* actions;                      // [R][cap] chosen actions of the LAST tick (API-visible)
     const float* eps_sched;               // optional device [n_ticks][n_brains]: the brains' exploration rates tick by tick (else eps[])
     int trk_skip;                         // the Tracker's running sums leave out the first trk_skip ticks of the launch
+    int capture;                          // TRAIN launches: append every tick's transitions to the brains' replay rings (rp[])
+    float* policy_out;                    // [R][cap][8] or null: the policy's outputs of the tick (PPO: probabilities) for rl_replay.prob
+    rl_replay rp[kRunMaxBrains];
     int debug;                            // measurement only (rl_debug_set_run_mask): 1 = skip the policy half, 2 = skip the tick half (results WRONG)
 };
 
@@ -300,7 +303,7 @@ __device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& p
         io.row = (int64_t)w * p.cap + k;
         io.valid = valid;
         io.eps = run_eps<TRAIN>(ka, b, p.n_brains, ps);
-        io.out = nullptr;
+        io.out = TRAIN ? *(float* const __attribute__((address_space(4)))*)&ka->ra.policy_out : nullptr;
         io.actions = *(int8_t* const __attribute__((address_space(4)))*)&ka->ra.actions;
         io.seed = p.seed;
         io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
@@ -426,7 +429,7 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
         io.row = (int64_t)w * p.cap + k;
         io.valid = !(e & 0x8000);
         io.eps = run_eps<TRAIN>(ka, b, p.n_brains, ps);
-        io.out = nullptr;
+        io.out = TRAIN ? *(float* const __attribute__((address_space(4)))*)&ka->ra.policy_out : nullptr;
         io.actions = *(int8_t* const __attribute__((address_space(4)))*)&ka->ra.actions;
         io.seed = p.seed;
         io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
@@ -494,7 +497,7 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
         io.row = (int64_t)w * p.cap + k;
         io.valid = !(e & 0x8000);
         io.eps = run_eps<TRAIN>(ka, b, p.n_brains, ps);
-        io.out = nullptr;
+        io.out = TRAIN ? *(float* const __attribute__((address_space(4)))*)&ka->ra.policy_out : nullptr;
         io.actions = *(int8_t* const __attribute__((address_space(4)))*)&ka->ra.actions;
         io.seed = p.seed;
         io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
@@ -598,6 +601,110 @@ __device__ inline void patch_planes_after_update(const KParams& p, Smem& s, int 
     if (cell0) s.scal[S_PLANES_DIRTY] = 1;
 }
 
+// trainer.py:95-96 + entities.py:194-208 inside the multi-tick launch (TRAIN, ra.capture): what rl_capture_transitions does after a
+// stand-alone tick.  Two parts.  capture_reserve (ONE wave, next to _reproduce on wave 0): the post-step agents with age > 1 are counted
+// per brain with ballots, one 64-bit atomic per brain reserves their ring slots, slot[k] (or -1) goes to LDS.  capture_rows (the whole
+// workgroup, an interval of its own before the planes are patched for the post-update grid): every captured agent's state_prime row is
+// produced once more from the post-step planes straight into its ring slot, its state row -- the observation the policy read, still in
+// the Agent.state buffer of this tick: slot a of the pre-step list -- is copied from memory (sc1: written by this workgroup a tick ago,
+// or by the previous launch), and the scalars follow.  Order within a brain's ring: Agent.learn call order per world, worlds interleaved
+// by the atomics (as with rl_capture_transitions).
+__device__ inline rl_replay load_replay(RunParamsC* ka, int b)   // (a struct copy out of the constant address space: device pass only, like run_params)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const rl_replay __attribute__((address_space(4)))*)&ka->ra.rp[b];
+#else
+    return rl_replay{};
+#endif
+}
+__device__ inline void capture_reserve(const KParams& p, Smem& s, RunParamsC* ka, int n1, int* slot)
+{
+    const int lane = lane_id();
+    int cnt = 0;
+    for (int base = 0; base < n1; base += 64) {
+        const int k = base + lane;
+        const int a = k < n1 ? s.order[k] : 0;
+        const int br = (k < n1 && s.age[a] > 1) ? s.brain[a] : -1;   // Agent.learn: `if self.age > 1` (entities.py:196)
+        for (int bb = 0; bb < p.n_brains; ++bb) { const int c = __popcll(__ballot(br == bb)); if (lane == bb) cnt += c; }
+    }
+    unsigned long long pos = 0, capacity = 1;
+    if (lane < p.n_brains) {
+        const rl_replay R = load_replay(ka, lane);
+        capacity = (unsigned long long)R.capacity;
+        if (cnt) pos = atomicAdd(R.count, (unsigned long long)cnt);
+    }
+    for (int base = 0; base < n1; base += 64) {
+        const int k = base + lane;
+        const int a = k < n1 ? s.order[k] : 0;
+        const int br = (k < n1 && s.age[a] > 1) ? s.brain[a] : -1;
+        int mine = -1;
+        for (int bb = 0; bb < p.n_brains; ++bb) {
+            const unsigned long long m = __ballot(br == bb);
+            const unsigned long long start = read_lane_u64(pos, bb), capb = read_lane_u64(capacity, bb);
+            if (br == bb) mine = (int)((start + (unsigned long long)__popcll(m & lowmask(lane))) % capb);
+            if (lane == bb) pos += (unsigned long long)__popcll(m);
+        }
+        if (k < n1) slot[k] = mine;
+    }
+}
+template <int T>
+__device__ __forceinline__ void capture_rows(const KParams& p, Smem& s, RunParamsC* ka, int w, int n1, const int* slot, const float* state_rows)
+{
+    const int t = rl_tidx();
+    constexpr int G = T / 49;
+    const int g0 = t / 49, idx = t - g0 * 49;
+    const int dr = idx / 7 - 3, dc = idx - (idx / 7) * 7 - 3;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)state_rows, 0, 0x7fffffff, 0x00027000);
+    auto ld = [&](int64_t float_index) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(float_index * 4), 0, 16 /* sc1 */)); };
+    const int64_t wbase = (int64_t)w * p.cap;
+    if (g0 < G)
+        for (int k = g0; k < n1; k += G) {
+            const int sl = slot[k];
+            if (sl < 0) continue;
+            const int a = s.order[k];
+            const rl_replay R = load_replay(ka, s.brain[a]);
+            const int pa = s.pos[a];
+            int ci = (pa & 255) + dr, cj = (pa >> 8) + dc;
+            ci += ci < 0 ? p.H : 0; ci -= ci >= p.H ? p.H : 0;
+            cj += cj < 0 ? p.W : 0; cj -= cj >= p.W ? p.W : 0;
+            const int c = ci * p.W + cj;
+            const int g = s.genev[c];
+            float* d1 = R.state_prime + (size_t)sl * RL_OBS_DIM + idx;
+            d1[0] = s.foodv[c]; d1[49] = s.healthv[c]; d1[98] = g == -2 ? 0.f : (g == s.gene[a] ? 1.f : -1.f);   // (write_observations' values)
+            const int64_t src = (wbase + a) * RL_OBS_DIM + idx;   // (slot a of the tick == index a of the pre-step list: the row the policy read)
+            float* d0 = R.state + (size_t)sl * RL_OBS_DIM + idx;
+            d0[0] = ld(src); d0[49] = ld(src + 49); d0[98] = ld(src + 98);
+        }
+    float* const pout = *(float* const __attribute__((address_space(4)))*)&ka->ra.policy_out;
+    for (int k = t; k < n1; k += T) {
+        const int sl = slot[k];
+        if (sl < 0) continue;
+        const int a = s.order[k];
+        const rl_replay R = load_replay(ka, s.brain[a]);
+        const int same = (int)(s.hcnt[s.hslot[a]] >> 16);
+        float* d1 = R.state_prime + (size_t)sl * RL_OBS_DIM + 147;
+        d1[0] = (float)((double)s.health[a] * 0.005);
+        d1[1] = (s.flags[a] & RL_F_REPRODUCED) ? 1.f : 0.f;
+        d1[2] = (float)((double)same / (double)n1);
+        d1[3] = (float)((double)n1 / (double)p.max_agents);
+        d1[4] = (s.flags[a] & RL_F_KILLED) ? 1.f : 0.f;
+        d1[5] = (s.flags[a] & RL_F_ATE_SUPER) ? 1.f : -1.f;
+        const int64_t src = (wbase + a) * RL_OBS_DIM + 147;
+        float* d0 = R.state + (size_t)sl * RL_OBS_DIM + 147;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) d0[e] = ld(src + e);
+        const int act = s.action[a];
+        R.action[sl] = (int8_t)act;
+        R.reward[sl] = (float)s.reward[a];
+        R.done[sl] = (s.flags[a] & RL_F_DEAD) ? 1 : 0;
+        R.age[sl] = s.age[a];
+        if (pout && R.prob && act >= 0 && act < 8) {
+            const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)pout, 0, 0x7fffffff, 0x00027000);
+            R.prob[sl] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rq, (int)(((wbase + a) * 8 + act) * 4), 0, 16));
+        }
+    }
+}
+
 // Second half: Environment.step + update_env (+ re-generation) out of LDS, then recycle_world.  Same sequence as
 // k_world<T, MODE_TICK, LEAN>; writes Agent.state into ra.obs[cur ^ 1] and advances the loop state in LDS.
 template <int T, bool FIXED, int KIND, bool TRAIN>
@@ -640,12 +747,17 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     // runs on wave 1 ALONE, next to wave 0's serial section (_reproduce) and the other waves' state_prime rows: as one more job of a
     // row-writing wave it made that wave the longest of the interval (+4 us per tick).  It reads only what _reproduce leaves alone.
     const bool trk = TRAIN && T >= 256 && p.so.trk_tick != nullptr;   // uniform
-    auto track = [&]() { track_world_wave0(p, s, w, n1, ps.trk_scr, &ps.trk, ticks_done >= *(const int __attribute__((address_space(4)))*)&ka->ra.trk_skip); };
+    const bool cap = TRAIN && T >= 256 && *(const int __attribute__((address_space(4)))*)&ka->ra.capture != 0;   // transition capture (uniform)
+    int* const cap_slot = (int*)ps.trk_scr;   // (free once the Tracker pass of the same wave is through with it)
+    auto track = [&]() {
+        if (trk) track_world_wave0(p, s, w, n1, ps.trk_scr, &ps.trk, ticks_done >= *(const int __attribute__((address_space(4)))*)&ka->ra.trk_skip);
+        if (cap) capture_reserve(p, s, ka, n1, cap_slot);
+    };
     if (overlapped) {
         if (tid < 64) {
             if (!p.static_families) best_agents_wave(s, n1);
             reproduce_wave0<T, true>(p, s, w, n1, nslots);
-        } else if (TRAIN && trk) {
+        } else if (TRAIN && (trk || cap)) {
             if (tid < 128) track();
             else {
                 write_observations<(T >= 256 ? T - 128 : 64)>(p, s, w, n1, p.so.obs, tid - 128);
@@ -655,7 +767,7 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
             write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n1, p.so.obs, tid - 64);
             step_outputs(tid - 64, T - 64);
         }
-    } else if (TRAIN && trk) {
+    } else if (TRAIN && (trk || cap)) {
         if (tid >= 64 && tid < 128) track();
         else {
             const int t = tid < 64 ? tid : tid - 64;
@@ -668,6 +780,10 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     }
     lds_barrier();
     RL_MARK(63);
+    if (TRAIN && cap) {   // the tick's transitions into the replay rings, while the planes still show the post-step grid
+        capture_rows<T>(p, s, ka, w, n1, cap_slot, ((float* const __attribute__((address_space(4)))*)ka->ra.obs)[cur]);
+        lds_barrier();
+    }
     for (int a = tid; a < nslots; a += T) s.src[a] = s.newidx[a];
     if (!overlapped) lds_barrier();
     else { const int first_new = nslots; nslots = s.scal[S_NSLOTS]; patch_planes_after_update<T>(p, s, n1, first_new, nslots); }
@@ -730,7 +846,8 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     RL_MARK(68);
     if (tid == 0) { ps.meta[1] = n2; ps.meta[2] = cur ^ 1; ps.meta[3] = ticks_done + 1; ps.meta[4] = ps.xmirror != nullptr; }
     // (rows the policy will read back from memory must have reached L2 first; with every row mirrored in LDS the stores just drain)
-    recycle_world<T, kSpec>(p, s, n2, tick_next, epoch_next, next_uid, max_gene, ps.xmirror == nullptr || n2 > ps.xrows, rr,
+    // (capture copies the rows the policy read back from memory a tick later: they must have arrived)
+    recycle_world<T, kSpec>(p, s, n2, tick_next, epoch_next, next_uid, max_gene, ps.xmirror == nullptr || n2 > ps.xrows || (TRAIN && cap), rr,
                             KIND == kKindAll ? &ps.meta[5] : nullptr);   // (tiles that take several rounds read their rows from memory)
     RL_MARK(69);
 }
@@ -961,7 +1078,7 @@ int rl_world_run_supported(const rl_world* h, const rl_brain* brains, int n_brai
 }
 int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n_ticks, int8_t* actions, const rl_step_out* so,
                         float* const obs[2], int first, int16_t* upd_src, int refill_threshold, int refill_n_agents,
-                        int32_t* refill_count, const float* eps_sched, int trk_skip, hipStream_t st)
+                        int32_t* refill_count, const float* eps_sched, int trk_skip, const rl_replay* replays, float* policy_out, hipStream_t st)
 {
     if (!rl_world_run_supported(h, brains, n_brains)) { rl_set_error("rl_run: unsupported configuration (brain kinds / slot_cap / LDS)"); return RL_E_UNSUPPORTED; }
     KParams p = make_params(h);
@@ -975,13 +1092,15 @@ int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n
     RunArgs& ra = rp.ra;
     for (int b = 0; b < n_brains; ++b) { ra.packed[b] = brains[b].packed; ra.eps[b] = brains[b].epsilon; ra.kind[b] = brains[b].kind; }
     ra.obs[0] = obs[0]; ra.obs[1] = obs[1]; ra.first = first; ra.n_ticks = n_ticks; ra.actions = actions; ra.eps_sched = eps_sched; ra.trk_skip = trk_skip;
+    ra.capture = replays != nullptr; ra.policy_out = policy_out;
+    if (replays) for (int b = 0; b < n_brains; ++b) ra.rp[b] = replays[b];
     ra.debug = g_run_debug;
     if (g_run_debug) rl_set_error("rl_run: measurement mask %d is set (rl_debug_set_run_mask): the results of this launch are not valid", g_run_debug);
     const int T = run_block(h);
     const int kind = run_kind_of(brains, n_brains);
     const size_t bytes = kind == kKindAll ? run_smem_bytes<kKindAll>(h, T) : run_smem_bytes<RL_PERD3QN>(h, T);
     const bool fixed = p.W == kFixW && p.H == kFixH && p.cap == kFixCap && p.hash_size == kFixHash && !getenv("RL_WORLD_GENERIC");
-    const bool train = eps_sched != nullptr || p.so.trk_tick != nullptr;
+    const bool train = eps_sched != nullptr || p.so.trk_tick != nullptr || replays != nullptr || policy_out != nullptr;
     const void* fn = nullptr;
 #define RL_RUN_PICK(TT, FX, KD, TR) if (T == TT && fixed == FX && kind == KD && train == TR) fn = (const void*)k_run<TT, FX, KD, TR>;
 #ifdef RL_RUN_DEV_BUILD   /* tuning builds: only the instantiations bench.py times (compile time) */

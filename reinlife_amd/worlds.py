@@ -84,6 +84,7 @@ class DeviceWorlds:
         self._tape_keep = None
         self._run_pair = None
         self._eps_keep = None
+        self._capture_prob = False
 
     def __del__(self):
         try:
@@ -181,7 +182,9 @@ class DeviceWorlds:
         self._build_step_out()
 
     def enable_capture(self, capacity, with_prob=False):
-        """Allocate one replay ring per brain (rl_replay) for capture_transitions()."""
+        """Allocate one replay ring per brain (rl_replay): filled by capture_transitions() after a stand-alone tick, or by run() inside
+        the multi-tick launch (every tick of it)."""
+        self._capture_prob = bool(with_prob)
         self.replays = []
         arr = (_lib.Replay * self.n_brains)()
         for b in range(self.n_brains):
@@ -283,21 +286,25 @@ class DeviceWorlds:
         # (with many worlds per GPU -- several per CU -- the two stand-alone launches are faster: 8.0e8 against 6.1e8 agent-steps/s
         # at 1024 worlds, the cross-world policy tiles waste fewer rows; RL_RUN_ALWAYS=1 forces the single launch)
         fused = self.run_supported() and (self.R <= 768 or bool(os.environ.get("RL_RUN_ALWAYS")))
-        if self.replays is not None or not fused:
+        if not fused:
             for t in range(n_ticks):
                 if eps_schedule is not None:
                     self._set_epsilons(eps_schedule[t].tolist())
-                self.act()
+                self.act(want_q=self.replays is not None and self._capture_prob)
                 if threshold >= 0:
                     self.tick_refill(threshold, n_agents)
                 else:
                     self.tick()
+                if self.replays is not None:
+                    self.capture_transitions(with_policy_out=self._capture_prob)
                 if self.tracking and t + 1 == trk_skip:
                     self.reset_tracking()
             return
         if self._run_pair is None:
             self._run_pair = (C.c_void_p * 2)(_ptr(self._obs2[0]), _ptr(self._obs2[1]))
-        opts = _lib.RunOpts(threshold, n_agents, _ptr(self.refill_count), _ptr(eps_schedule), trk_skip)
+        cap = self.replays is not None
+        opts = _lib.RunOpts(threshold, n_agents, _ptr(self.refill_count), _ptr(eps_schedule), trk_skip,
+                            C.cast(self._replay_arr, C.c_void_p) if cap else None, _ptr(self.out_q) if (cap and self._capture_prob) else None)
         _lib.check(self.lib.rl_run_ex(self.handle, self._brains, self.n_brains, n_ticks, _ptr(self.actions), C.byref(self._step_out),
                                       self._run_pair, self._cur, _ptr(self.src2), C.byref(opts), self._stream()), "rl_run_ex")
         self._eps_keep = eps_schedule   # the launch reads it asynchronously

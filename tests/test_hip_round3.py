@@ -435,3 +435,46 @@ def test_multi_tick_launch_many_tiles_take_several_rounds(monkeypatch):
             fused.check_error_flag(); loop.check_error_flag()
             _same_device_state(fused, loop, "8 brains, chunk %d" % chunk)
             _cmp_rows(fused.actions.cpu().numpy(), loop.actions.cpu().numpy(), fused.n_acted.cpu().numpy(), "actions")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# transition capture inside the multi-tick launch
+# ---------------------------------------------------------------------------------------------------------------------
+def _ring_rows(dw, b, lo, hi):
+    """Transitions lo..hi-1 of brain b's ring as comparable byte rows (state | state_prime | reward | prob | action | done | age)."""
+    r = dw.replays[b]
+    cap = r["state"].shape[0]
+    idx = np.arange(lo, hi) % cap
+    cols = [r["state"].cpu().numpy()[idx], r["state_prime"].cpu().numpy()[idx], r["reward"].cpu().numpy()[idx, None]]
+    if r["prob"] is not None:
+        cols.append(r["prob"].cpu().numpy()[idx, None])
+    cols += [r[k].cpu().numpy()[idx, None].astype(np.float32) for k in ("action", "done", "age")]
+    rows = np.ascontiguousarray(np.concatenate(cols, axis=1))
+    return rows[np.lexsort(rows.T[::-1])]
+
+
+@pytest.mark.parametrize("names,eps,static", [(("PERD3QN", "D3QN"), (0.0, 0.15), True), (("PPO", "PERD3QN"), (0.0, 0.05), False)],
+                         ids=["dueling", "PPO+PERD3QN"])
+def test_capture_inside_the_multi_tick_launch(names, eps, static, monkeypatch):
+    """DeviceWorlds.enable_capture + run(k): the launch appends every tick's transitions (state the policy read, action, reward,
+    state_prime, done, age, the taken action's policy output) to the brains' rings -- the same transitions rl_capture_transitions stores
+    after each stand-alone tick (trainer.py:95-96 / entities.py:194-208: agents of the post-step list with age > 1).  Within a tick the
+    worlds' transitions interleave by atomics in both paths, so a tick's transitions are compared as sets; counts and worlds exactly."""
+    monkeypatch.setenv("RL_POLICY_VARIANT", "pair")
+    (fused, loop), wts, cfg = _kind_pair(names, eps, 9, static, 31)
+    for dw in (fused, loop):
+        dw.enable_capture(capacity=40_000, with_prob=True)
+    assert fused.run_supported()
+    seen = [0] * len(names)
+    for chunk in (1, 1, 3, 12):
+        fused.run(chunk, 70, 100)
+        for _ in range(chunk):
+            loop.act(want_q=True); loop.tick_refill(70, 100); loop.capture_transitions(with_policy_out=True)
+        fused.check_error_flag(); loop.check_error_flag()
+        _same_device_state(fused, loop, "capture chunk %d" % chunk)
+        for b in range(len(names)):
+            tot_f, tot_l = int(fused.replays[b]["count"].item()), int(loop.replays[b]["count"].item())
+            assert tot_f == tot_l >= seen[b], (b, tot_f, tot_l)   # (nothing in the first tick: Agent.learn needs age > 1)
+            assert np.array_equal(_ring_rows(fused, b, seen[b], tot_f), _ring_rows(loop, b, seen[b], tot_l)), (names[b], chunk)
+            seen[b] = tot_f
+    assert sum(seen) > 5000
