@@ -140,7 +140,7 @@ template <int KIND> __device__ inline float (*pol_part(const PolSmem& ps, int g)
 // is 1 MB of memory traffic per tick.)
 struct RunParams;
 typedef const RunParams __attribute__((address_space(4))) RunParamsC;
-template <int T, int KIND, bool TRAIN>
+template <int T, int KIND, int TRAIN>
 __device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base);
 
 // Between two ticks of k_run: the post-update list becomes slots 0..n-1 (slot == list index, what load_world establishes),
@@ -205,7 +205,7 @@ struct RunParams {
 };
 // Exploration rate of brains-list entry b in this tick: TRAIN launches may carry a schedule (one row per tick of the launch: the
 // reference's brains decay epsilon from episode to episode, D3QN.py:84-89, DQN.py:67-69), else the brain's constant one.  Uniform: scalar loads.
-template <bool TRAIN>
+template <int TRAIN>
 __device__ inline float run_eps(RunParamsC* ka, int b, int n_brains, const PolSmem& ps)
 {
     typedef const float __attribute__((address_space(4))) cfloat;
@@ -247,7 +247,7 @@ __device__ inline void run_carve(const KParams& p, Smem& s, PolSmem& ps, char* s
     carve_policy<KIND>(ps, smem_raw, o0, p.cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, p.n_brains));
 }
 
-template <int T, int KIND, bool TRAIN>
+template <int T, int KIND, int TRAIN>
 __device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base)
 {
     constexpr int GROUPS = T / 256;
@@ -303,7 +303,7 @@ __device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& p
         io.row = (int64_t)w * p.cap + k;
         io.valid = valid;
         io.eps = run_eps<TRAIN>(ka, b, p.n_brains, ps);
-        io.out = TRAIN ? *(float* const __attribute__((address_space(4)))*)&ka->ra.policy_out : nullptr;
+        io.out = TRAIN == 2 ? *(float* const __attribute__((address_space(4)))*)&ka->ra.policy_out : nullptr;
         io.actions = *(int8_t* const __attribute__((address_space(4)))*)&ka->ra.actions;
         io.seed = p.seed;
         io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
@@ -404,7 +404,7 @@ __device__ inline void policy_schedule_wave0(const KParams& p, PolSmem& ps, RunP
 // tile on one SIMD (policy_tile1s<PAIR>); five to eight tiles: one hand-scheduled tile per wave (policy_tile1s); T = 256: one
 // policy_tile1 per wave (no LDS, no barrier inside a tile), wave i takes tiles i, i + 4, ...  Tile rows, validity and brain come from the
 // descriptors wave 0 wrote next to the row lists (policy_lists_wave0).
-template <int T, int KIND, bool TRAIN>
+template <int T, int KIND, int TRAIN>
 __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base, int wave)
 {
     // (`wave`: the wave's index in the workgroup, uniform -- computed once per launch and kept in an SGPR)
@@ -429,7 +429,7 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
         io.row = (int64_t)w * p.cap + k;
         io.valid = !(e & 0x8000);
         io.eps = run_eps<TRAIN>(ka, b, p.n_brains, ps);
-        io.out = TRAIN ? *(float* const __attribute__((address_space(4)))*)&ka->ra.policy_out : nullptr;
+        io.out = TRAIN == 2 ? *(float* const __attribute__((address_space(4)))*)&ka->ra.policy_out : nullptr;
         io.actions = *(int8_t* const __attribute__((address_space(4)))*)&ka->ra.actions;
         io.seed = p.seed;
         io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
@@ -477,7 +477,7 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
 }
 
 // The policy half of the kKindAll kernels (512-thread workgroups): per tile, the code of its brain's kind.
-template <int T, bool TRAIN>
+template <int T, int TRAIN>
 __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base, int wave)
 {
     static_assert(T == 512, "kKindAll: 512-thread workgroups");
@@ -497,7 +497,7 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
         io.row = (int64_t)w * p.cap + k;
         io.valid = !(e & 0x8000);
         io.eps = run_eps<TRAIN>(ka, b, p.n_brains, ps);
-        io.out = TRAIN ? *(float* const __attribute__((address_space(4)))*)&ka->ra.policy_out : nullptr;
+        io.out = TRAIN == 2 ? *(float* const __attribute__((address_space(4)))*)&ka->ra.policy_out : nullptr;
         io.actions = *(int8_t* const __attribute__((address_space(4)))*)&ka->ra.actions;
         io.seed = p.seed;
         io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
@@ -558,7 +558,7 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
 }
 
 // First half of a tick: the policy.  Reads the list length and the Agent.state parity from LDS.
-template <int T, bool FIXED, int KIND, bool TRAIN>
+template <int T, bool FIXED, int KIND, int TRAIN>
 __device__ __forceinline__ void run_policy_half(RunParamsC* ka, int wave)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -707,7 +707,7 @@ __device__ __forceinline__ void capture_rows(const KParams& p, Smem& s, RunParam
 
 // Second half: Environment.step + update_env (+ re-generation) out of LDS, then recycle_world.  Same sequence as
 // k_world<T, MODE_TICK, LEAN>; writes Agent.state into ra.obs[cur ^ 1] and advances the loop state in LDS.
-template <int T, bool FIXED, int KIND, bool TRAIN>
+template <int T, bool FIXED, int KIND, int TRAIN>
 __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -747,7 +747,7 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     // runs on wave 1 ALONE, next to wave 0's serial section (_reproduce) and the other waves' state_prime rows: as one more job of a
     // row-writing wave it made that wave the longest of the interval (+4 us per tick).  It reads only what _reproduce leaves alone.
     const bool trk = TRAIN && T >= 256 && p.so.trk_tick != nullptr;   // uniform
-    const bool cap = TRAIN && T >= 256 && *(const int __attribute__((address_space(4)))*)&ka->ra.capture != 0;   // transition capture (uniform)
+    const bool cap = TRAIN == 2 && T >= 256 && *(const int __attribute__((address_space(4)))*)&ka->ra.capture != 0;   // transition capture (uniform)
     int* const cap_slot = (int*)ps.trk_scr;   // (free once the Tracker pass of the same wave is through with it)
     auto track = [&]() {
         if (trk) track_world_wave0(p, s, w, n1, ps.trk_scr, &ps.trk, ticks_done >= *(const int __attribute__((address_space(4)))*)&ka->ra.trk_skip);
@@ -780,7 +780,7 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     }
     lds_barrier();
     RL_MARK(63);
-    if (TRAIN && cap) {   // the tick's transitions into the replay rings, while the planes still show the post-step grid
+    if (TRAIN == 2 && cap) {   // the tick's transitions into the replay rings, while the planes still show the post-step grid
         capture_rows<T>(p, s, ka, w, n1, cap_slot, ((float* const __attribute__((address_space(4)))*)ka->ra.obs)[cur]);
         lds_barrier();
     }
@@ -847,17 +847,17 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     if (tid == 0) { ps.meta[1] = n2; ps.meta[2] = cur ^ 1; ps.meta[3] = ticks_done + 1; ps.meta[4] = ps.xmirror != nullptr; }
     // (rows the policy will read back from memory must have reached L2 first; with every row mirrored in LDS the stores just drain)
     // (capture copies the rows the policy read back from memory a tick later: they must have arrived)
-    recycle_world<T, kSpec>(p, s, n2, tick_next, epoch_next, next_uid, max_gene, ps.xmirror == nullptr || n2 > ps.xrows || (TRAIN && cap), rr,
+    recycle_world<T, kSpec>(p, s, n2, tick_next, epoch_next, next_uid, max_gene, ps.xmirror == nullptr || n2 > ps.xrows || (TRAIN == 2 && cap), rr,
                             KIND == kKindAll ? &ps.meta[5] : nullptr);   // (tiles that take several rounds read their rows from memory)
     RL_MARK(69);
 }
 
-template <int T, int KIND, bool TRAIN>
+template <int T, int KIND, int TRAIN>
 __device__ __forceinline__ void run_tick_call_fixed(RunParamsC* ka) { run_tick_body<T, true, KIND, TRAIN>(ka); }
-template <int T, int KIND, bool TRAIN>
+template <int T, int KIND, int TRAIN>
 __device__ __forceinline__ void run_tick_call_generic(RunParamsC* ka) { run_tick_body<T, false, KIND, TRAIN>(ka); }
 
-template <int T, bool FIXED, int KIND, bool TRAIN>
+template <int T, bool FIXED, int KIND, int TRAIN>
 __device__ __forceinline__ void run_load_call(RunParamsC* ka)   // (inlined: load_world reads the kernel-argument segment through the intrinsic)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -955,7 +955,7 @@ __device__ __forceinline__ void run_load_call(RunParamsC* ka)   // (inlined: loa
     lds_barrier();
     RL_MARK(95);
 }
-template <int T, bool FIXED, int KIND, bool TRAIN>
+template <int T, bool FIXED, int KIND, int TRAIN>
 __device__ __forceinline__ void run_store_call(RunParamsC* ka)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -975,9 +975,10 @@ __device__ __forceinline__ void run_store_call(RunParamsC* ka)
 
 // Kernel body = the policy half (inlined: a kernel saves no registers, and the tile code gets the 128-VGPR budget of a
 // 1024-thread workgroup to itself); the tick half, the initial load and the final store are callees.
-// TRAIN: the launch also serves a training loop -- per-tick exploration rates and the Tracker's statistics (rl_run_ex); the plain
-// inference launch (what bench.py times) does not carry that code.
-template <int T, bool FIXED, int KIND, bool TRAIN>
+// TRAIN: the launch also serves a training loop (rl_run_ex) -- 1: per-tick exploration rates and the Tracker's statistics; 2: also the
+// policy's outputs and the transition capture into the replay rings.  The plain inference launch (0, what bench.py times) carries none of
+// that code, and a training loop that does not capture (trainer(): learn() is a no-op in this build) not the capture's.
+template <int T, bool FIXED, int KIND, int TRAIN>
 __global__ __launch_bounds__(T) void k_run(const RunParams rp)
 {
     RunParamsC* ka = (RunParamsC*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1100,24 +1101,23 @@ int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n
     const int kind = run_kind_of(brains, n_brains);
     const size_t bytes = kind == kKindAll ? run_smem_bytes<kKindAll>(h, T) : run_smem_bytes<RL_PERD3QN>(h, T);
     const bool fixed = p.W == kFixW && p.H == kFixH && p.cap == kFixCap && p.hash_size == kFixHash && !getenv("RL_WORLD_GENERIC");
-    const bool train = eps_sched != nullptr || p.so.trk_tick != nullptr || replays != nullptr || policy_out != nullptr;
+    const int train = (replays != nullptr || policy_out != nullptr) ? 2 : (eps_sched != nullptr || p.so.trk_tick != nullptr) ? 1 : 0;
     const void* fn = nullptr;
 #define RL_RUN_PICK(TT, FX, KD, TR) if (T == TT && fixed == FX && kind == KD && train == TR) fn = (const void*)k_run<TT, FX, KD, TR>;
 #ifdef RL_RUN_DEV_BUILD   /* tuning builds: only the instantiations bench.py times (compile time) */
-    RL_RUN_PICK(512, true, RL_PERD3QN, false)
+    RL_RUN_PICK(512, true, RL_PERD3QN, 0)
 #ifdef RL_RUN_DEV_ALL
-    RL_RUN_PICK(512, true, kKindAll, false)
+    RL_RUN_PICK(512, true, kKindAll, 0)
 #endif
 #else
-    RL_RUN_PICK(1024, true, RL_PERD3QN, false) RL_RUN_PICK(1024, false, RL_PERD3QN, false) RL_RUN_PICK(512, true, RL_PERD3QN, false)
-    RL_RUN_PICK(512, false, RL_PERD3QN, false) RL_RUN_PICK(256, true, RL_PERD3QN, false) RL_RUN_PICK(256, false, RL_PERD3QN, false)
-    RL_RUN_PICK(1024, true, RL_PERD3QN, true) RL_RUN_PICK(1024, false, RL_PERD3QN, true) RL_RUN_PICK(512, true, RL_PERD3QN, true)
-    RL_RUN_PICK(512, false, RL_PERD3QN, true) RL_RUN_PICK(256, true, RL_PERD3QN, true) RL_RUN_PICK(256, false, RL_PERD3QN, true)
-    RL_RUN_PICK(512, true, kKindAll, false) RL_RUN_PICK(512, false, kKindAll, false)
-    RL_RUN_PICK(512, true, kKindAll, true) RL_RUN_PICK(512, false, kKindAll, true)
+#define RL_RUN_PICK3(TT, FX, KD) RL_RUN_PICK(TT, FX, KD, 0) RL_RUN_PICK(TT, FX, KD, 1) RL_RUN_PICK(TT, FX, KD, 2)
+    RL_RUN_PICK3(1024, true, RL_PERD3QN) RL_RUN_PICK3(1024, false, RL_PERD3QN) RL_RUN_PICK3(512, true, RL_PERD3QN) RL_RUN_PICK3(512, false, RL_PERD3QN)
+    RL_RUN_PICK3(256, true, RL_PERD3QN) RL_RUN_PICK3(256, false, RL_PERD3QN)
+    RL_RUN_PICK3(512, true, kKindAll) RL_RUN_PICK3(512, false, kKindAll)
+#undef RL_RUN_PICK3
 #endif
 #undef RL_RUN_PICK
-    if (!fn) { rl_set_error("rl_run: no kernel instantiation for T=%d fixed=%d kind=%d train=%d in this build", T, (int)fixed, kind, (int)train); return RL_E_UNSUPPORTED; }
+    if (!fn) { rl_set_error("rl_run: no kernel instantiation for T=%d fixed=%d kind=%d train=%d in this build", T, (int)fixed, kind, train); return RL_E_UNSUPPORTED; }
     if (bytes > 64 * 1024) {   // opt in to the large dynamic-LDS window (per device copy of the kernel: cheap, done every launch)
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) { rl_set_error("hipFuncSetAttribute(%zu bytes of LDS) failed: %s", bytes, hipGetErrorString(e)); return RL_E_LAUNCH; }
