@@ -348,7 +348,7 @@ def _kind_pair(names, eps, R, static, seed, **extra):
     return out, wts, cfg
 
 
-KIND_SETS = [(("DQN", "DQN"), (0.0, 0.2), True), (("PPO", "PERD3QN"), (0.0, 0.05), False), (("PPO", "DQN", "D3QN"), (0.0, 0.1, 0.0), True),
+KIND_SETS = [(("DQN",), (0.0,), True), (("DQN", "DQN"), (0.0, 0.2), True), (("PPO", "PERD3QN"), (0.0, 0.05), False), (("PPO", "DQN", "D3QN"), (0.0, 0.1, 0.0), True),
              (("PPO", "PPO"), (0.0, 0.0), True), (("DQN", "PERD3QN", "PPO", "D3QN"), (0.3, 0.0, 0.0, 0.2), False)]
 
 
