@@ -724,7 +724,7 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     int nslots = n0;
     constexpr bool kPlanesEarly = T >= 256;
     RL_MARK(60);
-    phase_step<T, true, kPlanesEarly, kSpec>(p, s, w, n0);
+    phase_step<T, true, kPlanesEarly, kSpec, KIND == kKindAll>(p, s, w, n0);
     RL_MARK(61);
     assign_order<T>(p, s, nslots);
     if (kPlanesEarly) patch_placed_planes(s);
@@ -821,7 +821,7 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
             const int aa = a < nslots ? a : 0;
             const int ps_ = s.pos[aa], ge = s.gene[aa];
             const bool on = a < nslots && s.occ[(ps_ & 255) * p.W + (ps_ >> 8)] == a;
-            hash_insert_wave(s, p.hash_mask, on, a, on ? ge : 0, 1u << 16);
+            hash_insert_wave(s, p.hash_mask, on, a, on ? ge : 0, 1u << 16, KIND == kKindAll && !p.static_families);
         }
     }
     RL_MARK(66);
@@ -1118,9 +1118,16 @@ int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n
 #endif
 #undef RL_RUN_PICK
     if (!fn) { rl_set_error("rl_run: no kernel instantiation for T=%d fixed=%d kind=%d train=%d in this build", T, (int)fixed, kind, train); return RL_E_UNSUPPORTED; }
-    if (bytes > 64 * 1024) {   // opt in to the large dynamic-LDS window (per device copy of the kernel: cheap, done every launch)
-        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) { rl_set_error("hipFuncSetAttribute(%zu bytes of LDS) failed: %s", bytes, hipGetErrorString(e)); return RL_E_LAUNCH; }
+    if (bytes > 64 * 1024) {   // opt in to the large dynamic-LDS window: once per (kernel, device, size) -- the attribute belongs to the device's copy of the kernel
+        static const void* granted_fn[64];
+        static size_t granted_bytes[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (granted_fn[dev] != fn || granted_bytes[dev] < bytes) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e != hipSuccess) { rl_set_error("hipFuncSetAttribute(%zu bytes of LDS) failed: %s", bytes, hipGetErrorString(e)); return RL_E_LAUNCH; }
+            granted_fn[dev] = fn; granted_bytes[dev] = bytes;
+        }
     }
     void* kargs[] = {(void*)&rp};
     const hipError_t le = hipLaunchKernel(fn, dim3(h->cfg.n_worlds), dim3(T), kargs, bytes, st);

@@ -85,6 +85,7 @@ class DeviceWorlds:
         self._run_pair = None
         self._eps_keep = None
         self._capture_prob = False
+        self._fused_key = self._fused = None
 
     def __del__(self):
         try:
@@ -285,7 +286,10 @@ class DeviceWorlds:
             assert tuple(eps_schedule.shape) == (n_ticks, self.n_brains)
         # (with many worlds per GPU -- several per CU -- the two stand-alone launches are faster: 8.0e8 against 6.1e8 agent-steps/s
         # at 1024 worlds, the cross-world policy tiles waste fewer rows; RL_RUN_ALWAYS=1 forces the single launch)
-        fused = self.run_supported() and (self.R <= 768 or bool(os.environ.get("RL_RUN_ALWAYS")))
+        key = (id(self._brains), os.environ.get("RL_WORLD_BLOCK"), os.environ.get("RL_RUN_ALWAYS"))   # (what the decision depends on)
+        if self._fused_key != key:
+            self._fused_key, self._fused = key, self.run_supported() and (self.R <= 768 or bool(os.environ.get("RL_RUN_ALWAYS")))
+        fused = self._fused
         if not fused:
             for t in range(n_ticks):
                 if eps_schedule is not None:
