@@ -618,10 +618,12 @@ int rl_policy_act_impl(rl_world* h, const rl_brain* brains, int n_brains, const 
         s.kind = brains[b].kind;
         return s;
     };
+    // (D3QN and PERD3QN are ONE network -- D3QN.py:149-165, PERD3QN.py:186-202 -- and one kernel: a population of both is not "mixed")
+    auto canon = [](int k) { return k == RL_D3QN ? RL_PERD3QN : k; };
     unsigned kinds = 0;
     for (int b = 0; b < n_brains; ++b) {
         if (brains[b].kind < RL_DQN || brains[b].kind > RL_PPO) { rl_set_error("unknown brain kind %d", brains[b].kind); return RL_E_INVALID; }
-        kinds |= 1u << brains[b].kind;
+        kinds |= 1u << canon(brains[b].kind);
     }
     const char* variant = getenv("RL_POLICY_VARIANT");
     if (variant && !strcmp(variant, "pair") && n_brains <= kMaxBrainsPerLaunch) {   // one launch, the tile code picked per workgroup
@@ -643,9 +645,10 @@ int rl_policy_act_impl(rl_world* h, const rl_brain* brains, int n_brains, const 
         return RL_OK;
     }
     for (int kind = RL_DQN; kind <= RL_PPO; ++kind) {
+        if (kind == RL_D3QN) continue;   // (served by the PERD3QN pass)
         PolicyArgs a = base_args();
         for (int b = 0; b < n_brains; ++b) {
-            if (brains[b].kind != kind) continue;
+            if (canon(brains[b].kind) != kind) continue;
             a.b[a.nb++] = slot_of(b);
             if (a.nb == kMaxBrainsPerLaunch) {
                 if (int rc = launch_policy(kind, a, bound, expected, st)) return rc;

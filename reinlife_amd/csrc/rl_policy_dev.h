@@ -1404,15 +1404,22 @@ __device__ inline void policy_pair2(const TileIO& io, int lane, int role, const 
         if (c < kInChunks) split_slice<6>(slot % 6, [&](int e) { return xraw(c, e); }, sc0, B1[c][0], B1[c][1]);
     });
     ep.c = c1 + role * OWN1 * 64;
+    // (the hidden layer's first weight chunks are requested before the exposed part of the epilogue and the two exchanges, not after them)
+    WRingH<16, D, 32, 8> w2p;      // PPO: hidden layer, the role's four output tiles in two passes
+    WRing<2, 1, 1, D> w2d;         // DQN: hidden layer, output tile `role`
+    WRing<1, 1, 1, 2> whd;         // DQN: the head's two K-chunks of that tile
     if (KIND == RL_PPO) {
         k_pass<kInChunks, 1>(w1, B1, F[OWN1 - 2], F[OWN1 - 1], [&](int slot) {
             if (slot == 0) ep.fetch(0, 0);
             if (slot >= 2 && slot < 34) ep.step(0, slot - 2, F[0], F[1], un0, mrow);
         });
+        w2p.start(packed + L.l2a + role * (4 * kPlanes * 64 * 4), lane);
         ep.fetch(2, 0);
 #pragma unroll
         for (int e = 0; e < 32; ++e) ep.step(2, e, F[OWN1 - 2], F[OWN1 - 1], un0, mrow);
     } else {
+        w2d.start(packed + L.l2a, lane, role);
+        whd.start(packed + L.ha, lane, 2 * role);
         ep.fetch(0, 0);
 #pragma unroll
         for (int e = 0; e < 32; ++e) ep.step(0, e, F[0], F[1], un0, mrow);
@@ -1443,10 +1450,8 @@ __device__ inline void policy_pair2(const TileIO& io, int lane, int role, const 
         for (int c = 0; c < 8; ++c)
 #pragma unroll
             for (int pl = 0; pl < kPlanes; ++pl) B2[c][pl] = pair_lds->ex[(c * kPlanes + pl) * 64 + lane];
-        WRing<2, 1, 1, D> w2;
-        w2.start(packed + L.l2a, lane, role);
-        WRing<1, 1, 1, 2> wh;
-        wh.start(packed + L.ha, lane, 2 * role);
+        WRing<2, 1, 1, D>& w2 = w2d;
+        WRing<1, 1, 1, 2>& wh = whd;
         f32x16 acc, cross;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; cross[r] = 0.0f; }
@@ -1473,8 +1478,7 @@ __device__ inline void policy_pair2(const TileIO& io, int lane, int role, const 
         head_stream<2, 2>(wh, *(const f32x4*)(hconsts + 4 * h), araw, sc2, un2, head4);
     } else {
         // ---- hidden layer 256 -> 256: output tiles 4 role .. 4 role + 3 in two passes, B from LDS
-        WRingH<16, D, 32, 8> w2;
-        w2.start(packed + L.l2a + role * (4 * kPlanes * 64 * 4), lane);
+        WRingH<16, D, 32, 8>& w2 = w2p;
         f32x16 A[4];
         float m2 = 0.0f;
         k_pass_lds16<0>(w2, pair_lds->ex, lane, A[0], A[1], [&](int) {});

@@ -453,14 +453,17 @@ def _ring_rows(dw, b, lo, hi):
     return rows[np.lexsort(rows.T[::-1])]
 
 
-@pytest.mark.parametrize("names,eps,static", [(("PERD3QN", "D3QN"), (0.0, 0.15), True), (("PPO", "PERD3QN"), (0.0, 0.05), False)],
-                         ids=["dueling", "PPO+PERD3QN"])
-def test_capture_inside_the_multi_tick_launch(names, eps, static, monkeypatch):
+@pytest.mark.parametrize("names,eps,static,block", [(("PERD3QN", "D3QN"), (0.0, 0.15), True, None), (("PPO", "PERD3QN"), (0.0, 0.05), False, None),
+                                                    (("PERD3QN", "D3QN"), (0.0, 0.15), False, 256), (("D3QN", "PERD3QN"), (0.1, 0.0), True, 1024)],
+                         ids=["dueling", "PPO+PERD3QN", "dueling-T256", "dueling-T1024"])
+def test_capture_inside_the_multi_tick_launch(names, eps, static, block, monkeypatch):
     """DeviceWorlds.enable_capture + run(k): the launch appends every tick's transitions (state the policy read, action, reward,
     state_prime, done, age, the taken action's policy output) to the brains' rings -- the same transitions rl_capture_transitions stores
     after each stand-alone tick (trainer.py:95-96 / entities.py:194-208: agents of the post-step list with age > 1).  Within a tick the
     worlds' transitions interleave by atomics in both paths, so a tick's transitions are compared as sets; counts and worlds exactly."""
-    monkeypatch.setenv("RL_POLICY_VARIANT", "pair")
+    if block:
+        monkeypatch.setenv("RL_WORLD_BLOCK", str(block))
+    monkeypatch.setenv("RL_POLICY_VARIANT", "pair" if block is None else ("wave" if block == 256 else "nsplit"))
     (fused, loop), wts, cfg = _kind_pair(names, eps, 9, static, 31)
     for dw in (fused, loop):
         dw.enable_capture(capacity=40_000, with_prob=True)
