@@ -18,9 +18,11 @@ the Philox generator, a world is re-generated when its population drops below 70
 with NO data-path collective (weak scaling); RCCL is used once, for the final counter reduction.
 An agent-step = one live agent receiving an action and being advanced by one step().
 
-Before the warm-up the worlds are brought to their steady regime in untimed set-up (`--burnin`, 300 ticks: every world
-starts with one cohort of 100 agents, so without it the first refills come in synchronized waves), so any --steps window
-measures the same thing.
+Before the warm-up the worlds are brought to their steady regime in untimed set-up (`--burnin`, 2000 ticks: every world
+starts with one cohort of 100 agents, so without it the first refills come in synchronized waves; and the chip needs tens of
+milliseconds of sustained load to reach its working clocks -- behind 300 ticks = 7 ms of load a 20-step window reads 7.6e8,
+behind 600 ... 5000 ticks 8.0e8, `tools/window_probe.py`), so any --steps window measures the state a
+training loop runs in.
 
 Prints ONE JSON line (rank 0).  `value` counts the full tick (update_env included: more work than the metric's
 literal "env.step + policy fwd", never less); `variant_policy_plus_step` is the literal variant (i) of BASELINE.md 3
@@ -239,7 +241,7 @@ def main():
     ap.add_argument("--groups", type=int, default=1, help="split the GPU's worlds into this many stream groups (overlap)")
     ap.add_argument("--path", default="auto", choices=["auto", "fused", "two-launch"],
                     help="fused = one multi-tick launch (rl_run); two-launch = rl_policy_act + rl_tick_refill per tick")
-    ap.add_argument("--burnin", type=int, default=300, help="untimed set-up ticks that de-synchronise the worlds' cohorts")
+    ap.add_argument("--burnin", type=int, default=2000, help="untimed set-up ticks: de-synchronise the worlds' cohorts, bring the chip to its working clocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api-trainer", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
