@@ -338,12 +338,15 @@ def main():
         # the multi-tick launch, HIP events around launches of N ticks; then its two halves alone (rl_debug_set_run_mask: the library
         # skips one half of every tick -- results are then wrong, the work of the remaining half is the same)
         def timed_run(n, debug=None):
+            # launches back to back in stream order, the last one between the events: the ones before it bring the chip to its
+            # working clocks (a launch that follows a host round trip starts on a chip that has begun to clock down, and behind a
+            # 0.5 ms launch it still is at its idle clocks: tools/launch_cost.py, tools/window_probe.py), and nothing but the
+            # kernel lies between the events
+            if n < 1000:
+                dw.run(1000, 70, 100)
             if debug:
                 _lib.lib().rl_debug_set_run_mask(int(debug))   # explicit measurement switch of THIS process (never an environment variable)
             try:
-                # two launches back to back in stream order, the second one between the events: the first keeps the chip at its
-                # working clocks (a launch that follows a host round trip starts on a chip that has begun to clock down:
-                # tools/launch_cost.py, "after a 2 ms sleep"), and nothing but the kernel lies between the events
                 dw.run(n, 70, 100)
                 before = dw.acted_total.clone()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
