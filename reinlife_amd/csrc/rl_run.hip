@@ -228,7 +228,7 @@ __device__ inline KParams run_params(RunParamsC* ka)
     KParams p{};
 #endif
     if (FIXED) {
-        p.W = kFixW; p.H = kFixH; p.C = kFixC; p.Cp = kFixCp; p.nW = kFixCp / 64;
+        p.W = kFixW; p.H = kFixH; p.C = kFixC; p.Cp = kFixCp; p.nW = kFixCp / 64; p.PS = kFixPS; p.invW = kFixInvW;
         p.cap = kFixCap; p.hash_size = kFixHash; p.hash_mask = kFixHash - 1;
     }
     return p;
@@ -243,7 +243,7 @@ __host__ __device__ constexpr int run_cbrains(int T, int n_brains) { return T ==
 template <bool FIXED, int KIND>
 __device__ inline void run_carve(const KParams& p, Smem& s, PolSmem& ps, char* smem_raw, int T)
 {
-    const size_t o0 = FIXED ? carve(s, smem_raw, kFixCp, kFixCap, kFixHash) : carve(s, smem_raw, p.Cp, p.cap, p.hash_size);
+    const size_t o0 = FIXED ? carve(s, smem_raw, kFixCp, kFixCap, kFixHash, kFixPp) : carve(s, smem_raw, p.Cp, p.cap, p.hash_size, plane_words(p.PS, p.H, p.Cp));
     carve_policy<KIND>(ps, smem_raw, o0, p.cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, p.n_brains));
 }
 
@@ -588,13 +588,13 @@ __device__ inline void patch_planes_after_update(const KParams& p, Smem& s, int 
         const int a = s.order[k];
         const int fl = s.flags[a], ps = s.pos[a];  // one batch
         if (fl & RL_F_DEAD) {
-            const int c = (ps & 255) * p.W + (ps >> 8);
+            const int c = (ps & 255) * p.PS + (ps >> 8);   // (plane word; cell (0,0) is word 0)
             s.foodv[c] = 0.5f; s.healthv[c] = -1.f; s.genev[c] = -2;
             cell0 |= c == 0;
         }
     }
     for (int i = first_new + tid; i < end_new; i += T) {
-        const int c = s.tgt[i];
+        const int c = cell_to_plane(p, s.tgt[i]);
         s.foodv[c] = 0.f; s.healthv[c] = 1.f; s.genev[c] = -2;
         cell0 |= c == 0;
     }
@@ -667,7 +667,7 @@ __device__ __forceinline__ void capture_rows(const KParams& p, Smem& s, RunParam
             int ci = (pa & 255) + dr, cj = (pa >> 8) + dc;
             ci += ci < 0 ? p.H : 0; ci -= ci >= p.H ? p.H : 0;
             cj += cj < 0 ? p.W : 0; cj -= cj >= p.W ? p.W : 0;
-            const int c = ci * p.W + cj;
+            const int c = ci * p.PS + cj;
             const int g = s.genev[c];
             float* d1 = R.state_prime + (size_t)sl * RL_OBS_DIM + idx;
             d1[0] = s.foodv[c]; d1[49] = s.healthv[c]; d1[98] = g == -2 ? 0.f : (g == s.gene[a] ? 1.f : -1.f);   // (write_observations' values)
@@ -727,7 +727,7 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     phase_step<T, true, kPlanesEarly, kSpec, KIND == kKindAll>(p, s, w, n0);
     RL_MARK(61);
     assign_order<T>(p, s, nslots);
-    if (kPlanesEarly) patch_placed_planes(s);
+    if (kPlanesEarly) patch_placed_planes(p, s);
     const int n1 = s.scal[S_N1];
     lds_barrier();
     RL_MARK(62);
@@ -1100,7 +1100,7 @@ int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n
     const int T = run_block(h);
     const int kind = run_kind_of(brains, n_brains);
     const size_t bytes = kind == kKindAll ? run_smem_bytes<kKindAll>(h, T) : run_smem_bytes<RL_PERD3QN>(h, T);
-    const bool fixed = p.W == kFixW && p.H == kFixH && p.cap == kFixCap && p.hash_size == kFixHash && !getenv("RL_WORLD_GENERIC");
+    const bool fixed = p.W == kFixW && p.H == kFixH && p.PS == kFixPS && p.cap == kFixCap && p.hash_size == kFixHash && !getenv("RL_WORLD_GENERIC");
     const int train = (replays != nullptr || policy_out != nullptr) ? 2 : (eps_sched != nullptr || p.so.trk_tick != nullptr) ? 1 : 0;
     const void* fn = nullptr;
 #define RL_RUN_PICK(TT, FX, KD, TR) if (T == TT && fixed == FX && kind == KD && train == TR) fn = (const void*)k_run<TT, FX, KD, TR>;

@@ -13,7 +13,7 @@ __global__ __launch_bounds__(T) void k_world(const KParams p_in)
 {
     KParams p = p_in;
     if (FIXED) {
-        p.W = kFixW; p.H = kFixH; p.C = kFixC; p.Cp = kFixCp; p.nW = kFixCp / 64;
+        p.W = kFixW; p.H = kFixH; p.C = kFixC; p.Cp = kFixCp; p.nW = kFixCp / 64; p.PS = kFixPS; p.invW = kFixInvW;
         p.cap = kFixCap; p.hash_size = kFixHash; p.hash_mask = kFixHash - 1;
     }
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -25,17 +25,17 @@ __global__ __launch_bounds__(T) void k_world(const KParams p_in)
         // arguments lazily, a few at a time, and each first touch of a line is a scalar-cache miss (~0.2 us) on the
         // critical path of load_world; afterwards they are hits.
         auto ka = __builtin_amdgcn_kernarg_segment_ptr();
-        int t0, t1, t2, t3, t4, t5, t6, t7;
-        asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x40\n\ts_load_dword %2, %8, 0x80\n\t"
-                     "s_load_dword %3, %8, 0xc0\n\ts_load_dword %4, %8, 0x100\n\ts_load_dword %5, %8, 0x140\n\t"
-                     "s_load_dword %6, %8, 0x180\n\ts_load_dword %7, %8, 0x1c0\n\ts_waitcnt lgkmcnt(0)"
-                     : "=s"(t0), "=s"(t1), "=s"(t2), "=s"(t3), "=s"(t4), "=s"(t5), "=s"(t6), "=s"(t7)
+        int t0, t1, t2, t3, t4, t5, t6, t7, t8;
+        asm volatile("s_load_dword %0, %9, 0x0\n\ts_load_dword %1, %9, 0x40\n\ts_load_dword %2, %9, 0x80\n\t"
+                     "s_load_dword %3, %9, 0xc0\n\ts_load_dword %4, %9, 0x100\n\ts_load_dword %5, %9, 0x140\n\t"
+                     "s_load_dword %6, %9, 0x180\n\ts_load_dword %7, %9, 0x1c0\n\ts_load_dword %8, %9, 0x200\n\ts_waitcnt lgkmcnt(0)"
+                     : "=s"(t0), "=s"(t1), "=s"(t2), "=s"(t3), "=s"(t4), "=s"(t5), "=s"(t6), "=s"(t7), "=s"(t8)
                      : "s"(ka) : "memory");
-        static_assert(sizeof(KParams) >= 0x1c0 + 4 && sizeof(KParams) <= 0x200, "the warm-up loads must cover the argument block");
+        static_assert(sizeof(KParams) >= 0x200 + 4 && sizeof(KParams) <= 0x240, "the warm-up loads must cover the argument block");
     }
     Smem s;
-    if (FIXED) carve(s, smem_raw, kFixCp, kFixCap, kFixHash);
-    else carve(s, smem_raw, p.Cp, p.cap, p.hash_size);
+    if (FIXED) carve(s, smem_raw, kFixCp, kFixCap, kFixHash, kFixPp);
+    else carve(s, smem_raw, p.Cp, p.cap, p.hash_size, plane_words(p.PS, p.H, p.Cp));
     const int w = blockIdx.x;
     const int tid = rl_tidx();
     int n0;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(T) void k_world(const KParams p_in)
             phase_step<T, LEAN, kPlanesEarly, kSpec>(p, s, w, n0);
             RL_MARK(8);
             assign_order<T>(p, s, nslots);     // same barrier interval as the planes: they do not read the ordering
-            if (kPlanesEarly) patch_placed_planes(s);
+            if (kPlanesEarly) patch_placed_planes(p, s);
         } else build_order<T>(p, s, nslots, S_N1);
         RL_MARK(9);
         const int n1 = s.scal[S_N1];
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(T) void k_reset(const KParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem s;
-    carve(s, smem_raw, p.Cp, p.cap, p.hash_size);
+    carve(s, smem_raw, p.Cp, p.cap, p.hash_size, plane_words(p.PS, p.H, p.Cp));
     const int w = blockIdx.x;
     if (p.refill_threshold >= 0 && p.st.n_agents[w] >= p.refill_threshold) {  // uniform per workgroup: nothing to re-generate
         if (p.lists && rl_tidx() < 64) {
@@ -258,8 +258,8 @@ template <int MODE, bool LEAN>
 int launch_world_v(const rl_world* h, const KParams& p, hipStream_t stream)
 {
     const int blk = pick_block(h);
-    static const size_t fixed_bytes = rl_world_smem_bytes(kFixCp, kFixCap, kFixHash);  // inside the default 64 KB window
-    const bool fixed = LEAN && MODE == MODE_TICK && p.W == kFixW && p.H == kFixH && p.cap == kFixCap && p.hash_size == kFixHash &&
+    static const size_t fixed_bytes = rl_world_smem_bytes(kFixCp, kFixCap, kFixHash, kFixPS, kFixH);  // inside the default 64 KB window
+    const bool fixed = LEAN && MODE == MODE_TICK && p.W == kFixW && p.H == kFixH && p.PS == kFixPS && p.cap == kFixCap && p.hash_size == kFixHash &&
                        fixed_bytes <= 64 * 1024 && !getenv("RL_WORLD_GENERIC");  // (env: run the generic code -- tests, A/B)
     const dim3 grid(h->cfg.n_worlds);
     if (fixed) {
@@ -352,11 +352,12 @@ __global__ __launch_bounds__(256) void k_capture(const CaptureArgs A)
 // ---------------------------------------------------------------------------------------------------------------
 // host entry points used by rl_capi.hip
 // ---------------------------------------------------------------------------------------------------------------
-size_t rl_world_smem_bytes(int cpad, int cap, int hash)
+size_t rl_world_smem_bytes(int cpad, int cap, int hash, int plane_stride, int height)
 {
     Smem s;
-    return carve(s, nullptr, cpad, cap, hash);
+    return carve(s, nullptr, cpad, cap, hash, plane_words(plane_stride, height, cpad));
 }
+int rl_world_plane_stride(int width, int height) { return plane_stride(width, height); }
 int rl_world_block() { return 1024; }
 
 int rl_world_prepare_bytes(size_t bytes)

@@ -47,7 +47,7 @@ __device__ inline int rl_lane_fresh()
 }
 
 int rl_world_prepare_bytes(size_t bytes);
-size_t rl_world_smem_bytes(int cpad, int cap, int hash);
+size_t rl_world_smem_bytes(int cpad, int cap, int hash, int plane_stride, int height);
 extern int g_rl_ablate;   // tuning only (rl_debug_set_ablate, rl_world.hip)
 
 namespace {
@@ -61,6 +61,8 @@ enum { S_ALIVE = 0, S_NFOOD, S_NPOISON, S_NSUPER, S_NSLOTS, S_N1, S_N2, S_NPAREN
 
 struct KParams {
     int W, H, C, Cp, nW;
+    int PS;           // row stride of the observation planes in LDS (rl_world::plane_stride)
+    unsigned invW;    // 2^32 / W rounded up: cell / W == umulhi(cell, invW) for every cell < 2^16 (cell_to_plane)
     int cap, max_agents, n_brains, hash_size, hash_mask, world_base;
     int static_families, limit_reproduction, incentivize_killing;
     uint64_t seed;
@@ -98,9 +100,9 @@ struct Smem {
     int* present;                 // [RL_MAX_BRAINS]
     int* hkey;                    // [hash]
     unsigned* hcnt;               // [hash] low 16: alive, high 16: on grid
-    float* foodv;                 // [Cp]  (aliased: unsigned target counts during movement)
-    float* healthv;               // [Cp]
-    int* genev;                   // [Cp]
+    float* foodv;                 // [plane_words]: cell (i, j) at i * PS + j  (aliased: unsigned target counts per cell during movement)
+    float* healthv;               // [plane_words]
+    int* genev;                   // [plane_words]
     short* occ;                   // [Cp]
     uint8_t* type;                // [Cp]
     int *health, *age, *max_age, *gene, *brain, *uid;  // [cap]
@@ -130,7 +132,26 @@ enum { AUX_VANISH = 1, AUX_PARENT = 2 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-__host__ __device__ inline size_t carve(Smem& s, char* base, int Cp, int cap, int hash)
+// Row stride (32-bit words) of the three observation planes in LDS.  write_observations gathers the 7x7 window of ONE agent with 49
+// consecutive lanes, cell (i + dr, j + dc) = word (i + dr) * S + j + dc, by ds_read_b32: two groups of 32 lanes, bank = word mod 32
+// (MI355X_MICROARCH.md, LDS).  Lanes 0-31 are window rows 0-3 and four cells of row 4: with S = 7 (mod 32) the rows start at banks 0, 7,
+// 14, 21, 28 and the 32 lanes hit the 32 banks once each; lanes 32-48 (rest of row 4, rows 5, 6) then take banks 0-16.  With S = W = 30
+// the rows start at 0, 30, 28, 26, 24: every row collides with its neighbours (SQ_LDS_BANK_CONFLICT 29.5 % of the LDS-active cycles of
+// k_run).  The padding is taken when it costs at most 16 KB over the three planes (30x30: 39 words, +3.2 KB), and rl_create
+// falls back to S = W when the world would not fit the 160 KB otherwise: the stride is a property of the handle (rl_world::plane_stride ->
+// KParams::PS).
+__host__ __device__ constexpr int plane_stride(int W, int H)
+{
+    int S = W;
+    while ((S & 31) != 7) ++S;
+    return (S - W) * H * 12 <= 16 * 1024 ? S : W;
+}
+__host__ __device__ constexpr int plane_words(int PS, int H, int Cp)   // (>= Cp: the planes double as per-cell scratch of other phases)
+{
+    const int n = (PS * H + 63) & ~63;
+    return n > Cp ? n : Cp;
+}
+__host__ __device__ inline size_t carve(Smem& s, char* base, int Cp, int cap, int hash, int Pp)
 {
     size_t o = 0;
 #define CARVE(field, type, count) s.field = (type*)(base + o); o = align16(o + sizeof(type) * (size_t)(count));
@@ -151,9 +172,9 @@ __host__ __device__ inline size_t carve(Smem& s, char* base, int Cp, int cap, in
     CARVE(present, int, RL_MAX_BRAINS)
     CARVE(hkey, int, hash)
     CARVE(hcnt, unsigned, hash)
-    CARVE(foodv, float, Cp)
-    CARVE(healthv, float, Cp)
-    CARVE(genev, int, Cp)
+    CARVE(foodv, float, Pp)
+    CARVE(healthv, float, Pp)
+    CARVE(genev, int, Pp)
     CARVE(health, int, cap)
     CARVE(age, int, cap)
     CARVE(max_age, int, cap)
@@ -639,6 +660,9 @@ __device__ inline void scan_order_wave(const KParams& p, Smem& s, int lane, int 
     if (lane == 63) s.scal[out_slot] = incl;
 }
 
+// plane word of row-major cell c
+__device__ __forceinline__ int cell_to_plane(const KParams& p, int c) { return c + (int)__umulhi((unsigned)c, p.invW) * (p.PS - p.W); }
+
 // _prepare_observations (environment.py:377-404) into LDS planes
 template <int T>
 __device__ __forceinline__ void build_planes(const KParams& p, Smem& s, int t0 = rl_tidx(), int nt = T)
@@ -662,7 +686,8 @@ __device__ __forceinline__ void build_planes(const KParams& p, Smem& s, int t0 =
             h = float_mode ? (float)v : (float)(double)(long long)v;  // astype(int64) truncates toward zero
             if (s.flags[a] & RL_F_DEAD) g = s.gene[a];             // _get_genes, environment.py:448-456
         }
-        s.foodv[c] = f; s.healthv[c] = h; s.genev[c] = g;
+        const int pc = cell_to_plane(p, c);
+        s.foodv[pc] = f; s.healthv[pc] = h; s.genev[pc] = g;
     }
 }
 
@@ -694,7 +719,7 @@ __device__ __forceinline__ void write_observations(const KParams& p, Smem& s, in
                 int ci = (pa & 255) + dr, cj = (pa >> 8) + dc;
                 ci += ci < 0 ? p.H : 0; ci -= ci >= p.H ? p.H : 0;
                 cj += cj < 0 ? p.W : 0; cj -= cj >= p.W ? p.W : 0;
-                const int c = ci * p.W + cj;
+                const int c = ci * p.PS + cj;
                 const int g = s.genev[c];
                 const float vf = s.foodv[c], vh = s.healthv[c], vg = g == -2 ? 0.f : (g == s.gene[a] ? 1.f : -1.f);  // _extract_gene_observation, environment.py:424-428
                 o[0] = vf;
@@ -716,7 +741,7 @@ __device__ __forceinline__ void write_observations(const KParams& p, Smem& s, in
                 int ci = (pa[u] & 255) + dr, cj = (pa[u] >> 8) + dc;
                 ci += ci < 0 ? p.H : 0; ci -= ci >= p.H ? p.H : 0;
                 cj += cj < 0 ? p.W : 0; cj -= cj >= p.W ? p.W : 0;
-                c[u] = ci * p.W + cj;
+                c[u] = ci * p.PS + cj;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) { g[u] = s.genev[c[u]]; f[u] = s.foodv[c[u]]; h[u] = s.healthv[c[u]]; }
@@ -1037,13 +1062,13 @@ __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int
 }
 
 // the planes of the cells _add_food just filled (they were built as empty cells next to the placement)
-__device__ inline void patch_placed_planes(Smem& s)
+__device__ inline void patch_placed_planes(const KParams& p, Smem& s)
 {
     const int tid = rl_tidx();
     if (tid < s.scal[S_NPLACED]) {
         const int c = s.plist[tid];
         const int t = s.type[c];
-        s.foodv[c] = t == RL_FOOD ? 0.5f : (t == kSuper ? 1.f : -1.f);
+        s.foodv[cell_to_plane(p, c)] = t == RL_FOOD ? 0.5f : (t == kSuper ? 1.f : -1.f);
     }
 }
 
@@ -1547,6 +1572,8 @@ enum { MODE_STEP = 0, MODE_UPDATE = 1, MODE_TICK = 2, MODE_OBSERVE = 3, MODE_FOO
 //    the width, single-trip cell loops, constant window wrap): another ~1,100 instructions and 28 VGPRs less.
 constexpr int kFixW = 30, kFixH = 30, kFixMaxAgents = 100;
 constexpr int kFixC = kFixW * kFixH, kFixCp = (kFixC + 63) & ~63;
+constexpr int kFixPS = plane_stride(kFixW, kFixH), kFixPp = plane_words(kFixPS, kFixH, kFixCp);
+constexpr unsigned kFixInvW = (unsigned)(((1ull << 32) + kFixW - 1) / kFixW);
 constexpr int kFixCap = ((2 * kFixMaxAgents + 2 + 63) / 64) * 64;   // 256: births can overshoot max_agents up to 2n+1
 constexpr int kFixHash = 512;                                       // rl_create: the power of two >= 2 * slot_cap
 static_assert(kFixHash >= 2 * kFixCap && kFixHash / 2 < 2 * kFixCap, "hash size rule of rl_create");
@@ -1676,6 +1703,7 @@ inline KParams make_params(const rl_world* h)
 {
     KParams p{};
     p.W = h->cfg.width; p.H = h->cfg.height; p.C = h->cells; p.Cp = h->cpad; p.nW = h->cpad / 64;
+    p.PS = h->plane_stride; p.invW = (unsigned)(((1ull << 32) + p.W - 1) / p.W);
     p.cap = h->cfg.slot_cap; p.max_agents = h->cfg.max_agents; p.n_brains = h->cfg.n_brains;
     p.hash_size = h->hash_size; p.hash_mask = h->hash_size - 1; p.world_base = h->cfg.world_base;
     p.static_families = h->cfg.static_families; p.limit_reproduction = h->cfg.limit_reproduction;

@@ -18,6 +18,11 @@ dw = bench.make_worlds(args, 0, "cuda:0")
 fused = os.environ.get("RL_PMC_PATH", "fused") == "fused" and dw.run_supported() and args.worlds <= 768
 TICKS, LAUNCHES = 40, 5
 if fused:   # the multi-tick launch: LAUNCHES dispatches of TICKS ticks each
+    mask = int(os.environ.get("RL_PMC_RUN_MASK", "0"))   # tuning: 1 = skip the policy half, 2 = skip the tick half (counters of one half alone)
+    if mask:
+        from reinlife_amd import _lib
+        dw.run(300, 70, 100)
+        _lib.lib().rl_debug_set_run_mask(mask)
     for _ in range(LAUNCHES):
         dw.run(TICKS, 70, 100)
     print("ticks_per_launch", TICKS)
