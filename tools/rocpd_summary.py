@@ -28,6 +28,10 @@ def main():
         print("%-72s %7d %12.1f %10.2f %10.2f %10.2f %6.1f %5s %5s %5s %7s %9s" % (
             short, len(d), sum(d) / 1e3, sum(d) / len(d) / 1e3, min(d) / 1e3, max(d) / 1e3, 100.0 * sum(d) / total,
             s["vg"], s["ag"], s["sg"], s["lds"], "%d/%d" % (s["gx"] // max(1, s["wx"]), s["wx"])))
+    for name, s in sorted(stats.items(), key=lambda kv: -sum(kv[1]["d"]))[:3]:   # the few calls of the big kernels, one by one (start order)
+        d = s["d"][skip:] or s["d"]
+        if 1 < len(d) <= 12:
+            print("calls of %s in start order (us): %s" % (name if len(name) <= 72 else name[:69] + "...", "  ".join("%.2f" % (x / 1e3) for x in d)))
     try:
         pmc = cur.execute("select k.name, p.counter_name, avg(p.counter_value), count(*) from pmc_events p join kernels k "
                           "on p.dispatch_id = k.dispatch_id group by k.name, p.counter_name").fetchall()
