@@ -41,6 +41,18 @@ def test_create_validates_like_the_reference():
         assert lib.rl_last_error()
 
 
+def test_create_accepts_the_world_shapes_the_lds_budget_allows():
+    """rl_create sizes the world's LDS (160 KB per workgroup).  The observation planes are padded to a conflict-free row stride only where
+    that fits (rl_world_dev.h plane_stride; rl_create falls back to plain rows otherwise): every shape that fitted before still does."""
+    lib = _lib.lib()
+    h = C.c_void_p()
+    for w, hgt, agents, cap in ((3, 3, 2, 64), (30, 30, 100, 256), (64, 64, 100, 256), (64, 64, 500, 1024), (10, 255, 100, 256), (255, 10, 100, 256),
+                                (28, 146, 200, 448), (40, 100, 300, 640), (63, 65, 60, 128), (30, 30, 400, 832)):
+        cfg = _lib.Config(w, hgt, agents, 2, cap, 4, 1, 0, 1, 0, 0)
+        assert lib.rl_create(C.byref(cfg), C.byref(h)) == 0, (w, hgt, agents, cap, lib.rl_last_error())
+        lib.rl_destroy(h)
+
+
 def test_philox_matches_oracle_and_known_answers():
     from oracle import oracle as orc
     lib = _lib.lib()
