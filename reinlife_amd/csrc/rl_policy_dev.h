@@ -828,7 +828,6 @@ __device__ inline void policy_tile1(const TileIO& io, int lane)
             for (int q = 0; q < 2; ++q) {
                 const int k0 = (c == kInChunks - 1 && h == 1) ? 149 : 16 * c + 8 * h + 4 * q;
                 if (COHERENT) {
-                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)io.obs, 0, 0x7fffffff, 0x00027000);
                     B1[c][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((rbase + k0) * 4), 0, 16 /* sc1 */));
                 } else
@@ -970,7 +969,7 @@ __device__ inline void split_hi(float x0, float x1, float sc, float& hi)
 __device__ inline void split_lo(float x0, float x1, float sc, float hi, float& lo)
 {
     unsigned l = 0;
-    const unsigned h = __builtin_bit_cast(unsigned, hi);
+    [[maybe_unused]] const unsigned h = __builtin_bit_cast(unsigned, hi);   // (the host pass has no use for it)
 #if defined(__HIP_DEVICE_COMPILE__)
     asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(sc), "v"(h));
     asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(sc), "v"(h));
@@ -1349,6 +1348,7 @@ __device__ inline void policy_pair2(const TileIO& io, int lane, int role, const 
     const float* const c2 = cbase + T1 * 64 + 32 * h;                         // hidden layer
     const float* const hconsts = cbase + T1 * 64 + (KIND == RL_PPO ? 512 : 128);   // head: [unscale 8 | bias 8]
     // ---- input layer: the role's OWN1 output tiles
+    RL_PMARK1(1);
     WRingH<kInChunks, D, (OWN1 / 2) * kInChunks, T1> w1;
     w1.start(packed + L.l1 + role * (OWN1 * kPlanes * 64 * 4), lane);
     f32x4 X[kInChunks][2];
@@ -1399,10 +1399,12 @@ __device__ inline void policy_pair2(const TileIO& io, int lane, int role, const 
     f32x16 F[OWN1];
     EpiStream ep;
     float mrow = 0.0f;
+    RL_PMARK1(2);
     k_pass<kInChunks, 0>(w1, B1, F[0], F[1], [&](int slot) {
         const int c = slot / 6 + 1;
         if (c < kInChunks) split_slice<6>(slot % 6, [&](int e) { return xraw(c, e); }, sc0, B1[c][0], B1[c][1]);
     });
+    RL_PMARK1(3);
     ep.c = c1 + role * OWN1 * 64;
     // (the hidden layer's first weight chunks are requested before the exposed part of the epilogue and the two exchanges, not after them)
     WRingH<16, D, 32, 8> w2p;      // PPO: hidden layer, the role's four output tiles in two passes
@@ -1413,6 +1415,7 @@ __device__ inline void policy_pair2(const TileIO& io, int lane, int role, const 
             if (slot == 0) ep.fetch(0, 0);
             if (slot >= 2 && slot < 34) ep.step(0, slot - 2, F[0], F[1], un0, mrow);
         });
+        RL_PMARK1(4);
         w2p.start(packed + L.l2a + role * (4 * kPlanes * 64 * 4), lane);
         ep.fetch(2, 0);
 #pragma unroll
@@ -1427,7 +1430,9 @@ __device__ inline void policy_pair2(const TileIO& io, int lane, int role, const 
     // ---- the row's scale over ALL features of the layer, then the split activations of both roles through LDS
     mrow = fmaxf(mrow, __shfl_xor(mrow, 32));
     pair_lds->pmax[role * 64 + lane] = mrow;
+    RL_PMARK1(5);
     lds_barrier();
+    RL_PMARK1(6);
     mrow = fmaxf(mrow, pair_lds->pmax[(role ^ 1) * 64 + lane]);
     float sc1, un1;
     row_scale(mrow, sc1, un1);
@@ -1440,7 +1445,9 @@ __device__ inline void policy_pair2(const TileIO& io, int lane, int role, const 
         pair_lds->ex[((2 * OWN1 * role + c) * kPlanes + 0) * 64 + lane] = hi;
         pair_lds->ex[((2 * OWN1 * role + c) * kPlanes + 1) * 64 + lane] = lo;
     }
+    RL_PMARK1(7);
     lds_barrier();
+    RL_PMARK1(8);
     float head4[4];
     float sc2, un2;
     if (KIND == RL_DQN) {
@@ -1482,11 +1489,13 @@ __device__ inline void policy_pair2(const TileIO& io, int lane, int role, const 
         f32x16 A[4];
         float m2 = 0.0f;
         k_pass_lds16<0>(w2, pair_lds->ex, lane, A[0], A[1], [&](int) {});
+        RL_PMARK1(9);
         ep.c = c2 + role * 4 * 64;
         k_pass_lds16<1>(w2, pair_lds->ex, lane, A[2], A[3], [&](int slot) {
             if (slot == 0) ep.fetch(0, 0);
             if (slot >= 2 && slot < 34) ep.step(0, slot - 2, A[0], A[1], un1, m2);
         });
+        RL_PMARK1(13);
         WRing<1, 1, 1, D> wh;
         wh.start(packed + L.ha, lane, 8 * role);
         ep.fetch(2, 0);
@@ -1494,8 +1503,10 @@ __device__ inline void policy_pair2(const TileIO& io, int lane, int role, const 
         for (int e = 0; e < 32; ++e) ep.step(2, e, A[2], A[3], un1, m2);
         m2 = fmaxf(m2, __shfl_xor(m2, 32));
         row_scale(m2, sc2, un2);
+        RL_PMARK1(14);
         auto araw = [&](int c, int e) { return A[c >> 1][8 * (c & 1) + e]; };
         head_stream<D>(wh, *(const f32x4*)(hconsts + 4 * h), araw, sc2, un2, head4);
+        RL_PMARK1(15);
     }
     if (role) {
         *(f32x4*)(pair_lds->val + 4 * lane) = f32x4{head4[0], head4[1], head4[2], head4[3]};
@@ -1523,13 +1534,17 @@ __device__ inline void pair_finish(const TileIO& io, int lane, const Tile1Part& 
     if (h == 0) {
         float q[8] = {a4[0], a4[1], a4[2], a4[3], o4[0], o4[1], o4[2], o4[3]};
         if (KIND == RL_PPO) {
+            // softmax (PPO.py:105).  This runs on ONE wave per tile while every other wave of the workgroup waits at the barrier behind
+            // the tiles: exp as v_exp_f32(x log2 e) (the arguments are <= 0: no range handling; ~1e-6 relative) and ONE division, not
+            // eight calls of expf and eight divisions -- ~100 instructions instead of ~350 (2.8k -> 0.9k counts of the stamped build).
             float mx = q[0], sm = 0.0f;
 #pragma unroll
             for (int i = 1; i < 8; ++i) mx = fmaxf(mx, q[i]);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { q[i] = expf(q[i] - mx); sm += q[i]; }
+            for (int i = 0; i < 8; ++i) { q[i] = __builtin_amdgcn_exp2f((q[i] - mx) * 1.44269504088896340736f); sm += q[i]; }
+            const float inv = 1.0f / sm;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) q[i] = q[i] / sm;
+            for (int i = 0; i < 8; ++i) q[i] *= inv;
         }
         if (io.valid) {
             if (io.out) {

@@ -71,7 +71,7 @@ struct PolSmem {
     TrkLds trk;         // the Tracker's running sums for the length of the launch
     // kKindAll kernels: the policy half's schedule, written by wave 0 next to the row lists (policy_schedule_wave0).  meta[5]: 0 = every
     // tile gets a wave pair in ONE round (<= 4 tiles whose exchange buffers fit into the mirror), 1 = rounds of meta[6] tiles
-    short* wtask;       // [8]  per wave: tile | role << 8, or -1
+    int* wtask;         // [8]  per wave: tile | role << 8 | brains-list index << 12 | kind << 20, or -1
     int* texoff;        // [4]  per tile: byte offset of its exchange buffer inside the mirror
     int* bkind;         // [8]  the brains' kinds (filled once per launch)
 };
@@ -114,7 +114,7 @@ __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o
     if (n_cbrains > 0) { ps.cconst = (float*)(base + o); o = align16(o + sizeof(float) * run_const_floats<KIND>() * (size_t)n_cbrains); }
     ps.pairv = nullptr;
     if (n_cbrains > 0) { ps.pairv = (float*)(base + o); o = align16(o + sizeof(float) * 4 * run_pair_floats<KIND>()); }
-    ps.wtask = (short*)(base + o); o = align16(o + sizeof(short) * 8);
+    ps.wtask = (int*)(base + o); o = align16(o + sizeof(int) * 8);
     ps.texoff = (int*)(base + o); o = align16(o + sizeof(int) * 4);
     ps.bkind = (int*)(base + o); o = align16(o + sizeof(int) * kRunMaxBrains);
     ps.trk_scr = (double*)(base + o); o = align16(o + sizeof(double) * (size_t)cap);
@@ -373,7 +373,8 @@ __device__ inline void policy_schedule_wave0(const KParams& p, PolSmem& ps, RunP
     // only needs the tile of the cost RANK its slot stands for.
     const int nt = __builtin_amdgcn_readfirstlane(ps.meta[0]);
     const int t = lane & 3;
-    const int kind = ps.bkind[ps.tbrain[t] & (kRunMaxBrains - 1)];
+    const int brain = ps.tbrain[t] & (kRunMaxBrains - 1);
+    const int kind = ps.bkind[brain];
     const int cost = t < nt ? (kind == RL_PPO ? 672 : kind == RL_DQN ? 180 : 360) : 0;   // MFMAs per tile
     const int ex = t < nt ? pair_ex_bytes(kind) : 0;
     int rank = 0, off = 0, total_ex = 0;
@@ -389,11 +390,14 @@ __device__ inline void policy_schedule_wave0(const KParams& p, PolSmem& ps, RunP
     const int fit = (int)(mirror_bytes / (size_t)pair_ex_bytes(RL_PPO));
     // wave v = slot (v >> 2) of SIMD v & 3: ranks 0 0 1 1 / 3 3 2 2 (heaviest with lightest, second with third), role = v & 1
     const int want = (0x22331100 >> (4 * (lane & 7))) & 15;
-    int tile = -1;
+    int tile = -1, tb = 0, tk = 0;   // (brain and kind ride along: the tile wave then needs neither tbrain[] nor the kind table)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) if (u < nt && __builtin_amdgcn_readlane(rank, u) == want) tile = u;
+    for (int u = 0; u < 4; ++u) {
+        const int bu = __builtin_amdgcn_readlane(brain, u), ku = __builtin_amdgcn_readlane(kind, u);
+        if (u < nt && __builtin_amdgcn_readlane(rank, u) == want) { tile = u; tb = bu; tk = ku; }
+    }
     if (lane < 4) ps.texoff[lane] = off;
-    if (lane < 8) ps.wtask[lane] = (short)((pair_ok && tile >= 0) ? (tile | ((lane & 1) << 8)) : -1);
+    if (lane < 8) ps.wtask[lane] = (pair_ok && tile >= 0) ? (tile | ((lane & 1) << 8) | (tb << 12) | (tk << 20)) : -1;
     if (lane == 0) {
         ps.meta[5] = pair_ok ? 0 : 1;
         ps.meta[6] = fit < 1 ? 1 : (fit > 4 ? 4 : fit);   // tiles per round when the tiles take several rounds
@@ -408,7 +412,8 @@ template <int T, int KIND, int TRAIN>
 __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base, int wave)
 {
     // (`wave`: the wave's index in the workgroup, uniform -- computed once per launch and kept in an SGPR)
-    const int lane = rl_lane_fresh(), tid = wave * 64 + lane, j = lane & 31;
+    const int lane = rl_lane_fresh(), j = lane & 31;
+    [[maybe_unused]] const int tid = wave * 64 + lane;   // (the stamped build)
 #ifdef RL_PHASE_PROFILE
     const long long t_entry = (long long)clock64();
 #endif
@@ -489,8 +494,8 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
     const int ntiles = __builtin_amdgcn_readfirstlane(ps.meta[0]);
     const bool mirrored = ps.xmirror != nullptr && __builtin_amdgcn_readfirstlane(ps.meta[4]) != 0;
     const bool fallback = __builtin_amdgcn_readfirstlane(ps.meta[5]) != 0;
-    auto tile_io = [&](int ti, TileIO& io, bool from_mirror) {
-        const int b = __builtin_amdgcn_readfirstlane(ps.tbrain[ti]);
+    auto tile_io = [&](int ti, TileIO& io, bool from_mirror, int task) {   // task >= 0: the wave's descriptor names brain and kind
+        const int b = task >= 0 ? ((task >> 12) & 255) : __builtin_amdgcn_readfirstlane(ps.tbrain[ti]);
         const int e = (unsigned short)ps.trow[ti * 32 + j], k = e & 0x7fff;
         io.packed = (gfloat*)((const float* const __attribute__((address_space(4)))*)ka->ra.packed)[b];
         io.obs = obs_rows;
@@ -506,18 +511,18 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
         io.x_lds_off = (from_mirror && mirrored && k < ps.xrows) ? (int)((char*)(ps.xmirror + k * kXStride) - smem_base) : -1;
         io.c_lds_off = (int)((char*)(ps.cconst + kTileConstMax * b) - smem_base);
 #ifdef RL_PHASE_PROFILE
-        io.prof = nullptr;
+        io.prof = (p.prof && (int)blockIdx.x == p.prof_world && wave == ((p.ablate >> 20) & 7)) ? p.prof : nullptr;   // (tuning: the stamped wave = bits 20-22 of the ablate mask)
 #endif
-        return ((cint*)ka->ra.kind)[b];
+        return task >= 0 ? ((task >> 20) & 7) : ((cint*)ka->ra.kind)[b];
     };
     // One tile on a pair of waves: policy_tile1s<PAIR> (dueling kinds) / policy_pair2 (DQN, PPO); every wave meets the same barriers.
-    auto pair_round = [&](bool have, int ti, int role, int slot, int ex_off, bool from_mirror) {
+    auto pair_round = [&](bool have, int ti, int role, int slot, int ex_off, bool from_mirror, int task) {
         TileIO io;
         Tile1Part part;
         PairLds pl;
         int kind = -1;
         if (have) {
-            kind = __builtin_amdgcn_readfirstlane(tile_io(ti, io, from_mirror));
+            kind = __builtin_amdgcn_readfirstlane(tile_io(ti, io, from_mirror, task));
             pl.val = ps.pairv + kPairFloatsAll * slot; pl.pmax = pl.val + kPairValFloats;
             pl.ex = (f32x4*)((char*)ps.xmirror + ex_off);
             if (kind == RL_DQN) policy_pair2<RL_DQN, RL_RUN_COHERENT>(io, lane, role, &pl, &part);
@@ -536,7 +541,7 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
     // per slot; round 1's buffers overwrite the mirror, so every tile reads its rows from memory (recycle_world drained the stores).
     // The same tiles, hence the same bits, either way.  (ONE call site: the tile code exists once in the kernel.)
     const int pr = __builtin_amdgcn_readfirstlane(ps.meta[6]);
-    const int task = __builtin_amdgcn_readfirstlane((int)ps.wtask[wave]);
+    const int task = __builtin_amdgcn_readfirstlane(ps.wtask[wave]);
     const int n_rounds = fallback ? (ntiles + pr - 1) / pr : 1;
     for (int r = 0; r < n_rounds; ++r) {
         const int slot = fallback ? (wave & 3) : (task & 255);
@@ -544,7 +549,7 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
         const bool have = fallback ? (slot < pr && ti < ntiles) : task >= 0;
         const int role = __builtin_amdgcn_readfirstlane(fallback ? (wave >> 2) : ((task >> 8) & 1));
         const int ex_off = fallback ? slot * pair_ex_bytes(RL_PPO) : (have ? ps.texoff[slot] : 0);
-        pair_round(have, ti, role, slot, ex_off, !fallback);
+        pair_round(have, ti, role, slot, ex_off, !fallback, fallback ? -1 : task);
         if (fallback) lds_barrier();   // (the finish read this round's partials; the next round overwrites them)
     }
 #ifdef RL_PHASE_PROFILE
