@@ -9,7 +9,6 @@
 
 // implemented in rl_world.hip / rl_policy.hip
 size_t rl_world_smem_bytes(int cpad, int cap, int hash, int plane_stride, int height);
-int rl_world_plane_stride(int width, int height);
 int rl_world_block();
 int rl_world_launch_step(rl_world*, const int8_t*, const rl_tape*, const rl_step_out*, hipStream_t);
 int rl_world_launch_step_split(rl_world*, const int8_t*, const rl_step_out*, int32_t*, hipStream_t);
@@ -87,12 +86,7 @@ int rl_create(const rl_config* cfg, rl_world** out)
     int hs = 64;
     while (hs < 2 * cfg->slot_cap) hs <<= 1;
     h->hash_size = hs;
-    h->plane_stride = rl_world_plane_stride(cfg->width, cfg->height);   // (conflict-free window gather: rl_world_dev.h plane_stride)
-    h->smem_bytes = rl_world_smem_bytes(h->cpad, cfg->slot_cap, hs, h->plane_stride, cfg->height);
-    if (h->smem_bytes > 160 * 1024 && h->plane_stride != cfg->width) {   // the padded planes do not fit: plain row-major planes
-        h->plane_stride = cfg->width;
-        h->smem_bytes = rl_world_smem_bytes(h->cpad, cfg->slot_cap, hs, h->plane_stride, cfg->height);
-    }
+    h->smem_bytes = rl_world_smem_bytes(h->cpad, cfg->slot_cap, hs, cfg->width, cfg->height);
     h->block = rl_world_block();
     if (h->smem_bytes > 160 * 1024) {
         rl_set_error("rl_create: world needs %zu bytes of LDS (> 160 KB)", h->smem_bytes);

@@ -15,7 +15,6 @@ struct rl_world {
     int cpad;            // cells rounded up to 64
     int hash_size;       // power of two >= 2*slot_cap
     size_t smem_bytes;   // dynamic LDS of the world kernels
-    int plane_stride;    // row stride (words) of the observation planes in LDS: padded for a conflict-free 7x7 gather when it fits (rl_create)
     int block;           // threads per world workgroup
     void* work;          // bound policy work buffer (device) or null
     int lists_valid;     // the row lists in `work` describe the current world state

@@ -216,7 +216,10 @@ __device__ inline float run_eps(RunParamsC* ka, int b, int n_brains, const PolSm
     return ((cfloat*)ka->ra.eps)[b];
 }
 
-template <bool FIXED>
+// Row stride of the observation planes in this kernel: padded (plane_stride: the window gather hits every LDS bank once) with ONE world
+// per CU, i.e. workgroups of >= 512 threads; row-major for 256-thread workgroups, which share a CU's LDS (rl_world_dev.h plane_stride).
+__host__ __device__ constexpr int run_plane_stride(int T, int W, int H) { return T >= 512 ? plane_stride(W, H) : W; }
+template <bool FIXED, int T>
 __device__ inline KParams run_params(RunParamsC* ka)
 {
     // A struct copy out of the CONSTANT address space: every field that is used becomes a scalar load of the kernel-argument
@@ -228,7 +231,7 @@ __device__ inline KParams run_params(RunParamsC* ka)
     KParams p{};
 #endif
     if (FIXED) {
-        p.W = kFixW; p.H = kFixH; p.C = kFixC; p.Cp = kFixCp; p.nW = kFixCp / 64; p.PS = kFixPS; p.invW = kFixInvW;
+        p.W = kFixW; p.H = kFixH; p.C = kFixC; p.Cp = kFixCp; p.nW = kFixCp / 64; p.PS = run_plane_stride(T, kFixW, kFixH); p.invW = kFixInvW;
         p.cap = kFixCap; p.hash_size = kFixHash; p.hash_mask = kFixHash - 1;
     }
     return p;
@@ -243,7 +246,8 @@ __host__ __device__ constexpr int run_cbrains(int T, int n_brains) { return T ==
 template <bool FIXED, int KIND>
 __device__ inline void run_carve(const KParams& p, Smem& s, PolSmem& ps, char* smem_raw, int T)
 {
-    const size_t o0 = FIXED ? carve(s, smem_raw, kFixCp, kFixCap, kFixHash, kFixPp) : carve(s, smem_raw, p.Cp, p.cap, p.hash_size, plane_words(p.PS, p.H, p.Cp));
+    const size_t o0 = FIXED ? carve(s, smem_raw, kFixCp, kFixCap, kFixHash, plane_words(run_plane_stride(T, kFixW, kFixH), kFixH, kFixCp))
+                            : carve(s, smem_raw, p.Cp, p.cap, p.hash_size, plane_words(p.PS, p.H, p.Cp));
     carve_policy<KIND>(ps, smem_raw, o0, p.cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, p.n_brains));
 }
 
@@ -567,7 +571,7 @@ template <int T, bool FIXED, int KIND, int TRAIN>
 __device__ __forceinline__ void run_policy_half(RunParamsC* ka, int wave)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const KParams p = run_params<FIXED>(ka);
+    const KParams p = run_params<FIXED, T>(ka);
     Smem s;
     PolSmem ps;
     run_carve<FIXED, KIND>(p, s, ps, smem_raw, T);
@@ -716,7 +720,7 @@ template <int T, bool FIXED, int KIND, int TRAIN>
 __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const KParams p = run_params<FIXED>(ka);
+    const KParams p = run_params<FIXED, T>(ka);
     Smem s;
     PolSmem ps;
     run_carve<FIXED, KIND>(p, s, ps, smem_raw, T);
@@ -867,7 +871,7 @@ __device__ __forceinline__ void run_load_call(RunParamsC* ka)   // (inlined: loa
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     typedef const int __attribute__((address_space(4))) cint;
-    const KParams p = run_params<FIXED>(ka);
+    const KParams p = run_params<FIXED, T>(ka);
     Smem s;
     PolSmem ps;
     run_carve<FIXED, KIND>(p, s, ps, smem_raw, T);
@@ -964,7 +968,7 @@ template <int T, bool FIXED, int KIND, int TRAIN>
 __device__ __forceinline__ void run_store_call(RunParamsC* ka)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const KParams p = run_params<FIXED>(ka);
+    const KParams p = run_params<FIXED, T>(ka);
     Smem s;
     PolSmem ps;
     run_carve<FIXED, KIND>(p, s, ps, smem_raw, T);
@@ -1049,13 +1053,21 @@ static int run_kind_of(const rl_brain* brains, int n_brains)
     }
     return duel ? RL_PERD3QN : kKindAll;   // (D3QN and PERD3QN are the same network: PERD3QN.py:186-202, D3QN.py:149-165)
 }
+// LDS of a launch with planes of row stride `stride`; host_plane_stride picks the stride: padded where it fits, else row-major
 template <int KIND>
-static size_t run_smem_bytes(const rl_world* h, int T, int* xrows = nullptr)
+static size_t run_smem_bytes(const rl_world* h, int T, int stride, int* xrows = nullptr)
 {
     PolSmem ps;
-    const size_t b = carve_policy<KIND>(ps, nullptr, h->smem_bytes, h->cfg.slot_cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, h->cfg.n_brains));
+    const size_t world = rl_world_smem_bytes(h->cpad, h->cfg.slot_cap, h->hash_size, stride, h->cfg.height);
+    const size_t b = carve_policy<KIND>(ps, nullptr, world, h->cfg.slot_cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, h->cfg.n_brains));
     if (xrows) *xrows = ps.xrows;
     return b;
+}
+template <int KIND>
+static int host_plane_stride(const rl_world* h, int T)
+{
+    const int padded = run_plane_stride(T, h->cfg.width, h->cfg.height);
+    return (padded != h->cfg.width && run_smem_bytes<KIND>(h, T, padded) > 160 * 1024) ? h->cfg.width : padded;
 }
 // Workgroup size of the multi-tick kernel: 512 threads for few worlds (the one-wave policy tile needs the 256-VGPR budget; the
 // tick half alone would prefer 1024: 10.6 vs 13.1 us at 256 worlds), 256 when there are many worlds (several per CU).
@@ -1077,10 +1089,10 @@ int rl_world_run_supported(const rl_world* h, const rl_brain* brains, int n_brai
         // the mixed-kind kernel exists for 512-thread workgroups; the tiles' exchange buffers (32 KB for a PPO tile) lie in the mirror
         if (T != 512) return 0;
         int xrows = 0;
-        if (run_smem_bytes<kKindAll>(h, T, &xrows) > 160 * 1024) return 0;
+        if (run_smem_bytes<kKindAll>(h, T, host_plane_stride<kKindAll>(h, T), &xrows) > 160 * 1024) return 0;
         return (size_t)xrows * kXStride * sizeof(float) >= (size_t)pair_ex_bytes(RL_PPO);   // (at least one tile per round)
     }
-    return run_smem_bytes<RL_PERD3QN>(h, T) <= 160 * 1024;
+    return run_smem_bytes<RL_PERD3QN>(h, T, host_plane_stride<RL_PERD3QN>(h, T)) <= 160 * 1024;
 }
 int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n_ticks, int8_t* actions, const rl_step_out* so,
                         float* const obs[2], int first, int16_t* upd_src, int refill_threshold, int refill_n_agents,
@@ -1104,8 +1116,9 @@ int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n
     if (g_run_debug) rl_set_error("rl_run: measurement mask %d is set (rl_debug_set_run_mask): the results of this launch are not valid", g_run_debug);
     const int T = run_block(h);
     const int kind = run_kind_of(brains, n_brains);
-    const size_t bytes = kind == kKindAll ? run_smem_bytes<kKindAll>(h, T) : run_smem_bytes<RL_PERD3QN>(h, T);
-    const bool fixed = p.W == kFixW && p.H == kFixH && p.PS == kFixPS && p.cap == kFixCap && p.hash_size == kFixHash && !getenv("RL_WORLD_GENERIC");
+    rp.p.PS = kind == kKindAll ? host_plane_stride<kKindAll>(h, T) : host_plane_stride<RL_PERD3QN>(h, T);
+    const size_t bytes = kind == kKindAll ? run_smem_bytes<kKindAll>(h, T, rp.p.PS) : run_smem_bytes<RL_PERD3QN>(h, T, rp.p.PS);
+    const bool fixed = p.W == kFixW && p.H == kFixH && rp.p.PS == run_plane_stride(T, kFixW, kFixH) && p.cap == kFixCap && p.hash_size == kFixHash && !getenv("RL_WORLD_GENERIC");
     const int train = (replays != nullptr || policy_out != nullptr) ? 2 : (eps_sched != nullptr || p.so.trk_tick != nullptr) ? 1 : 0;
     const void* fn = nullptr;
 #define RL_RUN_PICK(TT, FX, KD, TR) if (T == TT && fixed == FX && kind == KD && train == TR) fn = (const void*)k_run<TT, FX, KD, TR>;

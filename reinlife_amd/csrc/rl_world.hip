@@ -13,7 +13,7 @@ __global__ __launch_bounds__(T) void k_world(const KParams p_in)
 {
     KParams p = p_in;
     if (FIXED) {
-        p.W = kFixW; p.H = kFixH; p.C = kFixC; p.Cp = kFixCp; p.nW = kFixCp / 64; p.PS = kFixPS; p.invW = kFixInvW;
+        p.W = kFixW; p.H = kFixH; p.C = kFixC; p.Cp = kFixCp; p.nW = kFixCp / 64; p.PS = kFixW; p.invW = kFixInvW;
         p.cap = kFixCap; p.hash_size = kFixHash; p.hash_mask = kFixHash - 1;
     }
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -258,8 +258,8 @@ template <int MODE, bool LEAN>
 int launch_world_v(const rl_world* h, const KParams& p, hipStream_t stream)
 {
     const int blk = pick_block(h);
-    static const size_t fixed_bytes = rl_world_smem_bytes(kFixCp, kFixCap, kFixHash, kFixPS, kFixH);  // inside the default 64 KB window
-    const bool fixed = LEAN && MODE == MODE_TICK && p.W == kFixW && p.H == kFixH && p.PS == kFixPS && p.cap == kFixCap && p.hash_size == kFixHash &&
+    static const size_t fixed_bytes = rl_world_smem_bytes(kFixCp, kFixCap, kFixHash, kFixW, kFixH);  // inside the default 64 KB window
+    const bool fixed = LEAN && MODE == MODE_TICK && p.W == kFixW && p.H == kFixH && p.cap == kFixCap && p.hash_size == kFixHash &&
                        fixed_bytes <= 64 * 1024 && !getenv("RL_WORLD_GENERIC");  // (env: run the generic code -- tests, A/B)
     const dim3 grid(h->cfg.n_worlds);
     if (fixed) {
@@ -357,7 +357,6 @@ size_t rl_world_smem_bytes(int cpad, int cap, int hash, int plane_stride, int he
     Smem s;
     return carve(s, nullptr, cpad, cap, hash, plane_words(plane_stride, height, cpad));
 }
-int rl_world_plane_stride(int width, int height) { return plane_stride(width, height); }
 int rl_world_block() { return 1024; }
 
 int rl_world_prepare_bytes(size_t bytes)

@@ -61,7 +61,7 @@ enum { S_ALIVE = 0, S_NFOOD, S_NPOISON, S_NSUPER, S_NSLOTS, S_N1, S_N2, S_NPAREN
 
 struct KParams {
     int W, H, C, Cp, nW;
-    int PS;           // row stride of the observation planes in LDS (rl_world::plane_stride)
+    int PS;           // row stride of the observation planes in LDS: W, or plane_stride(W, H) in the multi-tick kernel
     unsigned invW;    // 2^32 / W rounded up: cell / W == umulhi(cell, invW) for every cell < 2^16 (cell_to_plane)
     int cap, max_agents, n_brains, hash_size, hash_mask, world_base;
     int static_families, limit_reproduction, incentivize_killing;
@@ -137,9 +137,10 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t
 // (MI355X_MICROARCH.md, LDS).  Lanes 0-31 are window rows 0-3 and four cells of row 4: with S = 7 (mod 32) the rows start at banks 0, 7,
 // 14, 21, 28 and the 32 lanes hit the 32 banks once each; lanes 32-48 (rest of row 4, rows 5, 6) then take banks 0-16.  With S = W = 30
 // the rows start at 0, 30, 28, 26, 24: every row collides with its neighbours (SQ_LDS_BANK_CONFLICT 29.5 % of the LDS-active cycles of
-// k_run).  The padding is taken when it costs at most 16 KB over the three planes (30x30: 39 words, +3.2 KB), and rl_create
-// falls back to S = W when the world would not fit the 160 KB otherwise: the stride is a property of the handle (rl_world::plane_stride ->
-// KParams::PS).
+// k_run).  The padding is taken when it costs at most 16 KB over the three planes (30x30: 39 words, +3.2 KB) and only by
+// the multi-tick kernel with ONE world per CU (workgroups of >= 512 threads: rl_run.hip run_plane_stride) -- the stand-alone world
+// kernels keep S = W: with 256-thread workgroups four 30x30 worlds share a CU's 160 KB (39.9 KB each), and 3 KB more per world would
+// make that three (1,024 worlds: 47.9 -> 62.9 us per tick launch).  KParams::PS carries the stride of the launch.
 __host__ __device__ constexpr int plane_stride(int W, int H)
 {
     int S = W;
@@ -1572,7 +1573,7 @@ enum { MODE_STEP = 0, MODE_UPDATE = 1, MODE_TICK = 2, MODE_OBSERVE = 3, MODE_FOO
 //    the width, single-trip cell loops, constant window wrap): another ~1,100 instructions and 28 VGPRs less.
 constexpr int kFixW = 30, kFixH = 30, kFixMaxAgents = 100;
 constexpr int kFixC = kFixW * kFixH, kFixCp = (kFixC + 63) & ~63;
-constexpr int kFixPS = plane_stride(kFixW, kFixH), kFixPp = plane_words(kFixPS, kFixH, kFixCp);
+constexpr int kFixPp = plane_words(kFixW, kFixH, kFixCp);   // (the stand-alone kernels: row-major planes)
 constexpr unsigned kFixInvW = (unsigned)(((1ull << 32) + kFixW - 1) / kFixW);
 constexpr int kFixCap = ((2 * kFixMaxAgents + 2 + 63) / 64) * 64;   // 256: births can overshoot max_agents up to 2n+1
 constexpr int kFixHash = 512;                                       // rl_create: the power of two >= 2 * slot_cap
@@ -1703,7 +1704,7 @@ inline KParams make_params(const rl_world* h)
 {
     KParams p{};
     p.W = h->cfg.width; p.H = h->cfg.height; p.C = h->cells; p.Cp = h->cpad; p.nW = h->cpad / 64;
-    p.PS = h->plane_stride; p.invW = (unsigned)(((1ull << 32) + p.W - 1) / p.W);
+    p.PS = p.W; p.invW = (unsigned)(((1ull << 32) + p.W - 1) / p.W);
     p.cap = h->cfg.slot_cap; p.max_agents = h->cfg.max_agents; p.n_brains = h->cfg.n_brains;
     p.hash_size = h->hash_size; p.hash_mask = h->hash_size - 1; p.world_base = h->cfg.world_base;
     p.static_families = h->cfg.static_families; p.limit_reproduction = h->cfg.limit_reproduction;

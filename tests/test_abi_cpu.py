@@ -42,8 +42,8 @@ def test_create_validates_like_the_reference():
 
 
 def test_create_accepts_the_world_shapes_the_lds_budget_allows():
-    """rl_create sizes the world's LDS (160 KB per workgroup).  The observation planes are padded to a conflict-free row stride only where
-    that fits (rl_world_dev.h plane_stride; rl_create falls back to plain rows otherwise): every shape that fitted before still does."""
+    """rl_create sizes the world's LDS (160 KB per workgroup; the stand-alone kernels' row-major observation planes -- the multi-tick
+    launch pads them where that fits, rl_run.hip host_plane_stride): every shape the budget allows creates."""
     lib = _lib.lib()
     h = C.c_void_p()
     for w, hgt, agents, cap in ((3, 3, 2, 64), (30, 30, 100, 256), (64, 64, 100, 256), (64, 64, 500, 1024), (10, 255, 100, 256), (255, 10, 100, 256),
