@@ -1402,7 +1402,35 @@ __device__ __forceinline__ void track_world_wave0(const KParams& p, Smem& s, int
     const int lane = lane_id();
     const int G = p.static_families ? p.n_brains : 1;
     int m = 0, sum_age = 0, best = 0, attacks = 0, kills = 0;  // lane g: statistics of group g
-    // pass 1: per-group integer statistics, one ballot-aggregated step per distinct group of every 64-agent chunk
+    // pass 1: per-group integer statistics.  With LDS atomics on four words per group (count | attacks << 16, sum of the ages, oldest,
+    // kills; integer sums and maxima do not depend on the order): the lanes of a group serialise on its words, ~100 cycles per
+    // instruction -- the ballot-aggregated loop below (two wave scans per distinct group of every 64-agent chunk) took 1.4 us of a wave
+    // that is the longest of its interval (tools/trk_parts.py).  The words live at the head of scr, which pass 2 overwrites afterwards.
+    const bool by_atomics = 16 * G <= 8 * p.cap && n1 <= 4096;
+    if (by_atomics) {
+        unsigned* const acc4 = (unsigned*)scr;
+        if (lane < G) { acc4[4 * lane] = 0u; acc4[4 * lane + 1] = 0u; acc4[4 * lane + 2] = 0u; acc4[4 * lane + 3] = 0u; }
+        for (int base = 0; base < n1; base += 64) {
+            const int k = base + lane;
+            if (k < n1) {
+                const int a = s.order[k];
+                const int g = p.static_families ? s.gene[a] : 0;
+                if (g >= 0 && g < G) {
+                    const int age = s.age[a];
+                    const unsigned fl = s.flags[a];
+                    __hip_atomic_fetch_add(&acc4[4 * g], 1u + (s.action[a] >= 4 ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&acc4[4 * g + 1], (unsigned)age, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_max(&acc4[4 * g + 2], (unsigned)max(age, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (fl & RL_F_KILLED) __hip_atomic_fetch_add(&acc4[4 * g + 3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        if (lane < G) {
+            const unsigned ca = acc4[4 * lane];
+            m = (int)(ca & 0xffffu); attacks = (int)(ca >> 16); sum_age = (int)acc4[4 * lane + 1]; best = (int)acc4[4 * lane + 2]; kills = (int)acc4[4 * lane + 3];
+        }
+        asm volatile("" ::: "memory");   // (pass 2 stores doubles into the same bytes: keep it behind these reads)
+    } else
     for (int base = 0; base < n1; base += 64) {
         const int k = base + lane;
         const bool act = k < n1;

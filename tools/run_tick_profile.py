@@ -17,6 +17,8 @@ args = __import__("argparse").Namespace(worlds=R, workload=os.environ.get("RL_AB
 dw = bench.make_worlds(args, 0, "cuda:0")
 stamps = torch.zeros(128, dtype=torch.int64, device="cuda:0")
 lib = _lib.lib()
+if os.environ.get("RL_PROF_TRACK"):
+    dw.enable_tracking(True)   # the TRAIN instantiation with the Tracker pass on wave 1
 dw.run(50, 70, 100)
 acc = []
 iv = []
