@@ -55,11 +55,11 @@ struct RunArgs {
 struct PolSmem {
     char* group0;       // per-group block: lds_h | lds_aux | lds_part, group g at group0 + g * group_bytes
     int group_bytes;
-    short* prow;        // [cap] list indices grouped by brain
+    short* prow;        // [cap] T = 1024: list indices grouped by brain; T <= 512: per list entry, brain << 10 | position in the brain's list
     int* bstart;        // [64] first entry of brain b in prow
     int* bcnt;          // [64]
     int* tstart;        // [64] first tile of brain b
-    short* trow;        // [kMaxTiles][32] list index of tile row j (| 0x8000: padding, repeats the brain's last row)
+    short* trow;        // [kMaxTiles][32] list index of tile row j (0x8000: padding -- reads list entry 0, not valid)
     int* tbrain;        // [kMaxTiles] brain of tile t
     int* meta;          // [8]  [0] number of tiles; loop state of k_run: [1] list length, [2] Agent.state parity, [3] ticks done,
                         //      [4] the LDS mirror holds the current Agent.state rows
@@ -322,45 +322,44 @@ __device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& p
     }
 }
 
-// Rows of a world grouped by brain, 32-row tiles per brain, by ONE wave (ballots; lane b keeps brain b's count): prow / bstart / bcnt /
-// tstart / meta[0].  `brain_of(k)`: brains-list index of list entry k.
+// Rows of a world grouped by brain, 32-row tiles per brain, by ONE wave: trow / tbrain / tstart / bcnt / meta[0].  `brain_of(k)`:
+// brains-list index of list entry k.  Every entry takes a position in its brain's list with a RETURNING LDS atomic -- any order will do:
+// the rows of a tile are independent of each other (per-row scales, per-row outputs addressed by list index, Philox keyed by it), so the
+// results do not depend on which tile row an agent sits in -- and parks brain | position in prow; once the brains' tile ranges are known
+// it writes its list index straight into its tile row.  Padding rows read list entry 0 and are marked invalid.  (The ballot version --
+// per chunk and brain a ballot / popcount step, twice, then a gather for the descriptors -- was ~200 instructions of a lone wave.)
 template <typename F>
 __device__ inline void policy_lists_wave0(const KParams& p, PolSmem& ps, int n, int lane, F brain_of)
 {
-    int cnt = 0;
+    if (lane < p.n_brains) ps.bcnt[lane] = 0;
     for (int base = 0; base < n; base += 64) {
         const int k = base + lane;
-        const int b = k < n ? brain_of(k) : -1;
-        for (int bb = 0; bb < p.n_brains; ++bb) { const int c = __popcll(__ballot(b == bb)); if (lane == bb) cnt += c; }
-    }
-    const int mine = lane < p.n_brains ? cnt : 0;
-    const int incl = wave_incl_scan(mine);
-    const int tiles = (mine + 31) >> 5;
-    const int tincl = wave_incl_scan(tiles);
-    if (lane < p.n_brains) { ps.bstart[lane] = incl - mine; ps.bcnt[lane] = mine; ps.tstart[lane] = tincl - tiles; }
-    if (lane == 63) ps.meta[0] = tincl;
-    int pos = incl - mine;
-    for (int base = 0; base < n; base += 64) {
-        const int k = base + lane;
-        const int b = k < n ? brain_of(k) : -1;
-        for (int bb = 0; bb < p.n_brains; ++bb) {
-            const unsigned long long m = __ballot(b == bb);
-            const int start = read_lane(pos, bb);
-            if (b == bb) ps.prow[start + __popcll(m & lowmask(lane))] = (short)k;
-            if (lane == bb) pos += __popcll(m);
+        if (k < n) {
+            const int b = brain_of(k);
+            const int pos = __hip_atomic_fetch_add(&ps.bcnt[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ps.prow[k] = (short)(unsigned short)(pos | (b << 10));   // (pos < 1024 entries per world, b < 64)
         }
     }
-    // tile descriptors: one LDS read per lane instead of a dependent chain of four at the start of every policy half
+    const int mine = lane < p.n_brains ? ps.bcnt[lane] : 0;
+    const int tiles = (mine + 31) >> 5;
+    const int tincl = wave_incl_scan(tiles);
+    const int first_tile = tincl - tiles;
+    if (lane < p.n_brains) ps.tstart[lane] = first_tile;
+    if (lane == 63) ps.meta[0] = tincl;
     const int tt = min(read_lane(tincl, 63), kMaxTiles);
-    const int first_tile = tincl - tiles, first_row = incl - mine;
-    for (int e = lane; e < tt * 32; e += 64) {
-        const int t = e >> 5, j = e & 31;
+    for (int e = lane; e < tt * 32; e += 64) ps.trow[e] = (short)0x8000;
+    if (lane < tt) {
         int b = 0;
-        for (int bb = 1; bb < p.n_brains; ++bb) if (read_lane(first_tile, bb) <= t && read_lane(mine, bb) > 0) b = bb;
-        const int cntb = __shfl(mine, b), li = (t - __shfl(first_tile, b)) * 32 + j;
-        const int k = ps.prow[__shfl(first_row, b) + min(li, cntb - 1)];
-        ps.trow[e] = (short)(k | (li < cntb ? 0 : 0x8000));
-        if (j == 0) ps.tbrain[t] = b;
+        for (int bb = 1; bb < p.n_brains; ++bb) if (read_lane(first_tile, bb) <= lane && read_lane(mine, bb) > 0) b = bb;
+        ps.tbrain[lane] = b;
+    }
+    for (int base = 0; base < n; base += 64) {
+        const int k = base + lane;
+        if (k < n) {
+            const int e = (unsigned short)ps.prow[k], pos = e & 1023, b = e >> 10;
+            const int t = ps.tstart[b] + (pos >> 5);
+            if (t < kMaxTiles) ps.trow[t * 32 + (pos & 31)] = (short)k;
+        }
     }
 }
 
