@@ -4,7 +4,7 @@ T=$1
 H=$(python -c "from reinlife_amd import build; print(build.source_hash())")
 cp gpurun_out/$T/pmc_traffic.txt profiles/r03_pmc_hbm_traffic.txt
 cp gpurun_out/pmc_${T}_256/report.txt profiles/r03_run_sq_counters.txt
-DB=$(ls gpurun_out/$T/prof/*/*_results.db | head -1)
+DB=$(ls -t gpurun_out/$T/prof/*/*_results.db | head -1)
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-kernel-timing --no-api-trainer  (round 3, final kernel sources $H)"
   echo "# k_run is launched three times: burn-in (2000 ticks, with the start-up transient of the synthetic worlds), warm-up (300 ticks), TIMED REGION (2000 ticks): see the per-call line below"
   python tools/rocpd_summary.py $DB; } > profiles/r03_kernel_stats.txt

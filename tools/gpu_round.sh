@@ -9,7 +9,7 @@ fi
 timeout 600 python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err; echo "bench rc=$?"; tail -c 1500 gpurun_out/$TAG/bench.json
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/$TAG/bench_driver_window.json 2>> gpurun_out/$TAG/bench.err; echo
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-timing --no-api-trainer > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof.log 2>&1)
-DB=$(ls gpurun_out/$TAG/prof/*/*_results.db 2>/dev/null | head -1)
+DB=$(ls -t gpurun_out/$TAG/prof/*/*_results.db 2>/dev/null | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py $DB > gpurun_out/$TAG/kernel_stats.txt && head -8 gpurun_out/$TAG/kernel_stats.txt
 timeout 300 python bench.py --path two-launch --no-cpu-baseline > gpurun_out/$TAG/bench_two_launch.json 2>> gpurun_out/$TAG/bench.err
 timeout 300 python bench.py --workload c5 --no-cpu-baseline > gpurun_out/$TAG/bench_c5.json 2>> gpurun_out/$TAG/bench.err
