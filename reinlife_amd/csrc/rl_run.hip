@@ -732,7 +732,7 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     int nslots = n0;
     constexpr bool kPlanesEarly = T >= 256;
     RL_MARK(60);
-    phase_step<T, true, kPlanesEarly, kSpec, KIND == kKindAll>(p, s, w, n0);
+    phase_step<T, true, kPlanesEarly, kSpec>(p, s, w, n0);
     RL_MARK(61);
     assign_order<T>(p, s, nslots);
     if (kPlanesEarly) patch_placed_planes(p, s);
@@ -829,7 +829,7 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
             const int aa = a < nslots ? a : 0;
             const int ps_ = s.pos[aa], ge = s.gene[aa];
             const bool on = a < nslots && s.occ[(ps_ & 255) * p.W + (ps_ >> 8)] == a;
-            hash_insert_wave(s, p.hash_mask, on, a, on ? ge : 0, 1u << 16, KIND == kKindAll && !p.static_families);
+            hash_insert_wave(s, p.hash_mask, on, a, on ? ge : 0, 1u << 16);
         }
     }
     RL_MARK(66);

@@ -555,53 +555,25 @@ __device__ __forceinline__ void load_world(const KParams& p, Smem& s, int w, int
     lds_barrier();
 }
 
-// gene -> (alive count, on-grid count) open-addressing table; every agent remembers its slot.  Lanes of a wave that
-// share a gene are aggregated first (one CAS + one add per distinct gene per wave instead of per agent): with a
-// handful of families every agent would otherwise hammer the same two LDS words.
-// Must be called by all 64 lanes of the wave; `active` lanes contribute.
-// `many` (uniform): genes multiply without bound when families are not static (_produce gives every newcomer a gene of its own,
-// environment.py:543), and the aggregation below takes one trip through its loop -- a CAS and an add, two LDS round trips -- per DISTINCT
-// gene of the wave.  Then every lane inserts its own agent: the atomics of different genes run side by side, those of a shared gene
-// serialise (a handful per gene).  The table ends up with the same counts either way (the slot a gene lands in may differ: it is only
-// ever used as an index).  Only the mixed-kind instantiation of k_run passes it (configs[4]: -0.4 us per tick); in the dueling-only kernel
-// the extra branch cost configs[3] 0.15 us.
-__device__ inline void hash_insert_wave(Smem& s, int mask, bool active, int a, int gene, unsigned add, bool many = false)
+// gene -> (alive count, on-grid count) open-addressing table; every agent remembers its slot (only ever used as an index).
+// `active` lanes contribute.  (Rounds 1-3 aggregated the lanes of a wave that share a gene first -- one CAS + one add per distinct gene
+// per wave -- on the assumption that two families' agents would otherwise hammer the same two LDS words; measured at the end of round 3,
+// the hammering is the cheaper of the two.)
+__device__ inline void hash_insert_wave(Smem& s, int mask, bool active, int a, int gene, unsigned add)
 {
-    if (many) {
-        if (active) {
-            unsigned hh = ((unsigned)gene * 2654435761u) & (unsigned)mask;
-            for (;;) {
-                const int old = atomicCAS(&s.hkey[hh], -1, gene);
-                if (old == -1 || old == gene) break;
-                hh = (hh + 1) & (unsigned)mask;
-            }
-            if (add) atomicAdd(&s.hcnt[hh], add);
-            s.hslot[a] = (unsigned short)hh;
+    // One CAS probe + one add per LANE.  The lanes of a gene serialise on its slot (~100 cycles per instruction for a full wave), which
+    // is still cheaper than aggregating them first: the ballot version (per distinct gene of the wave a leader lane probes and adds the
+    // popcounts, the others wait for its slot) cost 0.5 us per tick at configs[3] -- 23.57 -> 23.08 us -- although it issues two atomics
+    // per gene instead of two per agent.
+    if (active) {
+        unsigned hh = ((unsigned)gene * 2654435761u) & (unsigned)mask;
+        for (;;) {
+            const int old = atomicCAS(&s.hkey[hh], -1, gene);
+            if (old == -1 || old == gene) break;
+            hh = (hh + 1) & (unsigned)mask;
         }
-        return;
-    }
-    unsigned long long pending = __ballot(active);
-    while (pending) {
-        const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)pending) - 1);
-        const int g = __builtin_amdgcn_readlane(gene, leader);
-        const bool mine = active && gene == g;
-        const unsigned long long m = __ballot(mine);
-        const unsigned lo = (unsigned)__popcll(__ballot(mine && (add & 1u)));
-        const unsigned hi = (unsigned)__popcll(__ballot(mine && (add >> 16)));
-        int h = 0;
-        if (lane_id() == leader) {
-            unsigned hh = ((unsigned)g * 2654435761u) & (unsigned)mask;
-            for (;;) {
-                const int old = atomicCAS(&s.hkey[hh], -1, g);
-                if (old == -1 || old == g) break;
-                hh = (hh + 1) & (unsigned)mask;
-            }
-            if (lo | hi) atomicAdd(&s.hcnt[hh], lo | (hi << 16));
-            h = (int)hh;
-        }
-        h = __builtin_amdgcn_readlane(h, leader);
-        if (mine) s.hslot[a] = (unsigned short)h;
-        pending &= ~m;
+        if (add) atomicAdd(&s.hcnt[hh], add);
+        s.hslot[a] = (unsigned short)hh;
     }
 }
 
@@ -820,7 +792,7 @@ __device__ inline void precompute_draws(const KParams& p, Smem& s, int w, int n0
 }
 
 // Environment.step up to (not including) the observation pass
-template <int T, bool LEAN, bool PLANES_EARLY, bool SPEC = false, bool MANY_GENES = false>
+template <int T, bool LEAN, bool PLANES_EARLY, bool SPEC = false>
 __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int n0)
 {
     const int tid = rl_tidx();
@@ -958,7 +930,7 @@ __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int
             gene = s.gene[a];
         }
         alive_wave += __popcll(__ballot(alive != 0u));
-        hash_insert_wave(s, p.hash_mask, valid, a, gene, alive | (ongrid << 16), MANY_GENES && !p.static_families);
+        hash_insert_wave(s, p.hash_mask, valid, a, gene, alive | (ongrid << 16));
     }
     RL_MARK(37);
     if (alive_wave && lane_id() == 0) atomicAdd(&s.scal[S_ALIVE], alive_wave);
