@@ -637,11 +637,36 @@ __device__ inline void scan_order_wave(const KParams& p, Smem& s, int lane, int 
 __device__ __forceinline__ int cell_to_plane(const KParams& p, int c) { return c + (int)__umulhi((unsigned)c, p.invW) * (p.PS - p.W); }
 
 // _prepare_observations (environment.py:377-404) into LDS planes
+// `nslots` >= 0: the agents are slots 0 .. nslots-1 (on the grid iff occ[cell] names them) -- then in two disjoint parts: every
+// NON-agent cell from its type alone (one LDS trip, no divergent chain), and every agent writes its own cell (position, health, flags,
+// gene in one trip, the cell's occupant in a second).  The cell-driven version below pays type -> occupant -> (health, flags) -> gene,
+// four dependent trips, in every wave that sees an agent cell, i.e. all of them, three times over for a 30x30 grid: it was the longest
+// job of its interval in the multi-tick kernel (3.9k of the interval's 3.9k counts; without it 2.6k).
 template <int T>
-__device__ __forceinline__ void build_planes(const KParams& p, Smem& s, int t0 = rl_tidx(), int nt = T)
+__device__ __forceinline__ void build_planes(const KParams& p, Smem& s, int t0 = rl_tidx(), int nt = T, int nslots = -1)
 {
     if (RL_ABL(2)) return;
     const bool float_mode = s.type[0] == RL_AGENT;  // np.vectorize dtype inference from cell (0,0)
+    if (nslots >= 0) {
+        for (int c = t0; c < p.C; c += nt) {
+            const int t = s.type[c];
+            if (t == RL_AGENT) continue;
+            const float f = t == RL_FOOD ? 0.5f : (t == kSuper ? 1.f : (t == RL_POISON ? -1.f : 0.f));
+            const int pc = cell_to_plane(p, c);
+            s.foodv[pc] = f; s.healthv[pc] = -1.f; s.genev[pc] = -2;
+        }
+        for (int a = t0; a < nslots; a += nt) {
+            const int ps = s.pos[a], hp = s.health[a], fl = s.flags[a], ge = s.gene[a];  // one batch
+            const int i = ps & 255, j = ps >> 8, c = i * p.W + j;
+            if (s.type[c] != RL_AGENT || s.occ[c] != a) continue;   // (vanished: not on the grid)
+            const double v = (double)hp * 0.005;                      // see below
+            const int pc = i * p.PS + j;
+            s.foodv[pc] = hp < 0 ? 1.f : 0.f;
+            s.healthv[pc] = float_mode ? (float)v : (float)(double)(long long)v;
+            s.genev[pc] = (fl & RL_F_DEAD) ? ge : -2;
+        }
+        return;
+    }
     for (int c = t0; c < p.C; c += nt) {
         const int t = s.type[c];
         float f = 0.f, h = -1.f;
@@ -1029,7 +1054,7 @@ __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int
     } else if (PLANES_EARLY && tid >= 128) {
         // waves 2.. build the observation planes of the post-step grid meanwhile, as if nothing were placed; the (at most
         // seven) placed cells are patched in the next interval (patch_placed_planes)
-        build_planes<T>(p, s, tid - 128, T - 128);
+        build_planes<T>(p, s, tid - 128, T - 128, n0);   // (the list of the step: slots 0 .. n0-1)
     }
     lds_barrier();
 }

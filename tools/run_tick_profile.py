@@ -20,6 +20,9 @@ lib = _lib.lib()
 if os.environ.get("RL_PROF_TRACK"):
     dw.enable_tracking(True)   # the TRAIN instantiation with the Tracker pass on wave 1
 dw.run(50, 70, 100)
+if os.environ.get("RL_PROF_ABLATE"):   # tuning: skip sections of the tick in the stamped launches (results wrong; rl_world_dev.h RL_ABL bits)
+    lib.rl_debug_set_ablate.argtypes = [C.c_int]
+    lib.rl_debug_set_ablate(int(os.environ["RL_PROF_ABLATE"]))
 acc = []
 iv = []
 sub = []
