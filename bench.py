@@ -42,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from reinlife_amd import _lib  # noqa: E402
+from reinlife_amd import distributed as rl_dist  # noqa: E402
 from reinlife_amd.distributed import reduce_counters  # noqa: E402
 from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights  # noqa: E402
 
@@ -166,13 +167,15 @@ def cpu_baseline(args):
                          cores=max(1, min(os.cpu_count() or 1, 64)))
 
 
-def api_trainer(args, device):
+def api_trainer(args, device, dist=None, rank=0):
     """The same loop through the reference's API surface (Helpers/trainer.py:7-107): trainer(brains, n_episodes=K, n_worlds=...,
     save=False, print_results=False) with the reference's default training=True -- the brains' epsilon decays per episode and the
     Tracker closes an interval every 500 episodes -- on the benchmark's synthetic worlds (100 agents per world, re-generated below
     70: the keyword-only extras synthetic_agents / refill_below).  Wall-clocked around the loop inside trainer() (env.loop_seconds:
     construction of the Environment and the reset launch are set-up, like the untimed set-up of the main line); agent-steps from the
-    device counter."""
+    device counter.  With several ranks (--gpus N) EVERY rank makes the same call: Environment takes rank -> world_base = rank *
+    n_worlds and cuda:LOCAL_RANK from the process group and the Tracker pools every closed interval over all ranks with one RCCL
+    collective (Helpers/tracker.py); the figures below are then whole-job sums over the slowest rank's time."""
     import warnings
     from reinlife_amd import Models
     from reinlife_amd.Helpers.trainer import trainer
@@ -191,25 +194,70 @@ def api_trainer(args, device):
             out.append(b)
         return out
 
+    tracker_collectives = [0]
+
     def one(k, **kw):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             env = trainer(brains(), n_episodes=k, n_worlds=args.worlds, save=False, print_results=False, static_families=wl["static_families"],
-                          device=device, seed=args.seed, synthetic_agents=100, refill_below=70, **kw)
+                          device=device, seed=args.seed, synthetic_agents=100, refill_below=70, dist=dist, **kw)
         steps = int(env.worlds.acted_total.item())
         env.worlds.check_error_flag()
+        tracker_collectives[0] += env.tracker.collectives_executed
+        if dist is not None:   # whole job: the ranks' agent-steps over the slowest rank's loop time (one more small all-gather)
+            tot, tmax, _ = reduce_counters(torch.tensor([float(steps)], dtype=torch.float64, device=device), env.loop_seconds, dist)
+            return int(tot[0].item()), tmax, env
         return steps, env.loop_seconds, env
     one(40, update_interval=10)                # warm-up: the TRAIN kernel's first launch, the Tracker's torch reductions (first use loads their code objects: ~15 ms)
     k_long = max(2000, args.steps)
     s_long, t_long, env = one(k_long)
-    s_win, t_win, _ = one(args.steps)          # the same window as the main line's --steps
+    s_win, t_win, env_win = one(args.steps)    # the same window as the main line's --steps
     return {"value": round(s_long / t_long, 1), "unit": "agent-steps/s", "episodes": k_long + 1, "us_per_tick": round(t_long / (k_long + 1) * 1e6, 2),
-            "launches": 1 + k_long // 500, "tracker_intervals_closed": len(env.tracker.results["Avg Number of Populations"]),
+            "launches": env.worlds.launches, "tracker_intervals_closed": len(env.tracker.results["Avg Number of Populations"]),
             "final_epsilon": [round(float(getattr(b, "epsilon", 0.0)), 4) for b in env.brains],
+            "tracker_last_interval": {"Avg Population Size": [v[-1] for v in env.tracker.results["Avg Population Size"].values()],
+                                      "Avg Number of Populations": env.tracker.results["Avg Number of Populations"][-1]},
             "value_at_steps": round(s_win / t_win, 1), "steps_window": args.steps + 1, "window_ms": round(t_win * 1e3, 4),
+            "ranks": 1 if dist is None else dist.get_world_size(), "world_base": env.world_base,
+            "tracker_rccl_collectives": tracker_collectives[0] if dist is not None else 0,
             "call": "trainer(brains, n_episodes=K, n_worlds=%d, save=False, print_results=False, synthetic_agents=100, refill_below=70) "
-                    "[training=True, update_interval=500: the reference's defaults]" % args.worlds,
+                    "[training=True, update_interval=500: the reference's defaults]%s" % (args.worlds, "" if dist is None else " on every rank, torch.distributed initialised"),
             "timed": "the loop inside trainer() (env.loop_seconds), device idle before and after; agent-steps from the device counter"}
+
+
+def c5_leg(args, rank, device):
+    """BASELINE configs[4]'s per-GPU workload next to the main line: PPO + PERD3QN mixed brains, static_families=False (the mixed-kind
+    multi-tick kernel, k_run<512, fixed, kKindAll>; PPO.py:101-106,164-169, PERD3QN.py:198-210, environment.py:521-547,728-739), the
+    same synthetic worlds and refill rule, 256 worlds per GPU.  ~60 ms of GPU time: 1000 untimed ticks, then one 1000-tick launch
+    between HIP events and a wall clock."""
+    import argparse
+    a5 = argparse.Namespace(**dict(vars(args), workload="c5"))
+    dw = make_worlds(a5, rank, device)
+    if not dw.run_supported():
+        return {"error": "rl_run does not cover this configuration"}
+    n = 1000
+    dw.run(n, 70, 100)
+    torch.cuda.synchronize()
+    dw.acted_total.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(); dw.run(n, 70, 100); e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dw.check_error_flag()
+    steps = int(dw.acted_total.item())
+    t_k = e0.elapsed_time(e1) * 1e-3
+    wl = WORKLOADS["c5"]
+    flop = float(np.mean([POLICY_FLOP_PER_AGENT[k] for k in wl["brains"]]))
+    by = TICK_BYTES_PER_AGENT_STEP + POLICY_BYTES_PER_AGENT
+    return {"workload": wl["name"], "value": round(steps / wall, 1), "unit": "agent-steps/s", "ticks": n, "us_per_tick": round(wall / n * 1e6, 2),
+            "kernel_us_per_tick": round(t_k / n * 1e6, 2), "agent_steps_per_tick": round(steps / n, 1),
+            "roofline": {"kernel": "k_run<512, fixed, kKindAll> (rl_run, mixed brain kinds)", "bound": "hbm", "achieved": round(steps * by / t_k / 1e9, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(steps * by / t_k / 1e9 / HBM_PEAK_GBS, 5), "bytes_per_agent_step": by,
+                         "flop_per_agent": flop, "mfma_tflops": round(steps * flop / t_k / 1e12, 2),
+                         "mfma_frac": round(steps * flop / t_k / 1e12 / MFMA_F32_EQUIV_PEAK_TFLOPS, 5),
+                         "how": "HIP events on the launch stream around ONE launch of %d ticks, queued behind %d untimed ticks" % (n, n)},
+            "timed": "wall clock around the launch + synchronize (value); inputs resident in HBM"}
 
 
 def respawn_under_torchrun(args):
@@ -244,6 +292,7 @@ def main():
     ap.add_argument("--burnin", type=int, default=2000, help="untimed set-up ticks: de-synchronise the worlds' cohorts, bring the chip to its working clocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api-trainer", action="store_true")
+    ap.add_argument("--no-c5", action="store_true", help="skip the configs[4] per-GPU leg of the default (c4) line")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
@@ -480,9 +529,14 @@ def main():
                 "what": "rl_policy_act + rl_step (Environment.step, un-fused kernel) between HIP events; update_env + refill run untimed "
                         "between the pairs; 1 GPU (rank 0)"}
 
+    main_collectives = rl_dist.collectives_executed   # (the metric's own reduction: exactly one when a process group exists)
     api = None
-    if rank == 0 and args.gpus == 1 and not args.no_api_trainer and args.groups == 1:
-        api = api_trainer(args, device)
+    if not args.no_api_trainer and args.groups == 1:   # every rank: trainer() shards by rank and reduces its Tracker over RCCL
+        api = api_trainer(args, device, dist, rank)
+
+    c5 = None
+    if rank == 0 and args.workload == "c4" and args.groups == 1 and not args.no_c5:
+        c5 = c5_leg(args, rank, device)
 
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
@@ -496,7 +550,7 @@ def main():
             "unit": "agent-steps/s",
             "n_gpus": args.gpus,
             "rccl_ranks": rccl_ranks,
-            "rccl_collectives_executed": 1 if dist is not None else 0,
+            "rccl_collectives_executed": main_collectives,
             "per_rank": {"value_min": round(min(rank_rates), 1), "value_max": round(max(rank_rates), 1),
                          "elapsed_ms": [round(float(x) * 1e3, 3) for x in rank_table[:, 2].tolist()]},
             "steps": args.steps,
@@ -515,6 +569,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "api_trainer": api,
+            "c5": c5,
         }
         out.update(extra)
         sys.stdout.flush()

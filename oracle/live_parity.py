@@ -34,11 +34,6 @@ def compare_world(tag, got, want, check_best):
                 raise AssertionError("%s: %s differs\n got  %s\n want %s" % (tag, key, got[key], want[key]))
 
 
-def compare_tick(tag, ow, w, rec, static):
-    ps, pu = rec["post_step"], rec["post_update"]
-    return ps, pu
-
-
 def run_case(name, seed, ticks, n_brains=2, width=30, height=30, max_agents=100, static=True, limit=False,
              incentive=True, fill=0, p_attack=None, verbose=True):
     rh.seed_all(seed)

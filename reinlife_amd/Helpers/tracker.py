@@ -5,7 +5,8 @@ episodes, tracker.py:107-121,166-176,279-282) on top of the accumulators the HIP
 "Avg Number of Populations".  With several replicas (and several GPUs) the valid per-tick values of ALL worlds are pooled:
 aggregate = sum over worlds of trk_sum / sum over worlds of trk_cnt -- for one world this is exactly the reference's
 np.mean over the interval (values <= -1 are dropped, as Tracker._aggregate does); across GPUs the same two arrays are
-summed with one RCCL all-reduce per interval.  Plots and the colab widgets are out of scope."""
+pooled with ONE RCCL collective per interval (an all-gather of the ranks' per-world rows, summed in global replica order on every rank:
+the aggregates do not depend on the number of ranks).  Plots and the colab widgets are out of scope."""
 import numpy as np
 import torch
 
@@ -25,6 +26,7 @@ class Tracker:
         self.results["Avg Number of Populations"] = []
         self.worlds = worlds
         self.dist = dist
+        self.collectives_executed = 0   # collectives issued so far: exactly one per closed interval when a process group exists
         self.fig = None
         if worlds is not None:
             worlds.enable_tracking(True)
@@ -35,23 +37,30 @@ class Tracker:
         (tracker.py:279-282 keeps the last `update_interval` entries of update_interval+1), so its contribution is dropped."""
         if n_epi == 0:
             self.worlds.reset_tracking()
-            return
+            return False
         if n_epi % self.update_interval == 0:
             self._average_results()
-            if self.print_results:
+            if self.print_results and (self.dist is None or not self.dist.is_initialized() or self.dist.get_rank() == 0):
                 self._print_results()
+            return True   # an interval was closed (and the device synchronised)
+        return False
 
     def _average_results(self):
         w = self.worlds
-        s = w.trk_sum.sum(0)
-        c = w.trk_cnt.sum(0).to(torch.float64)
-        pop = w.trk_pop[:, 1:].sum(0)
+        rows = torch.cat([w.trk_sum.reshape(w.trk_sum.shape[0], -1), w.trk_cnt.reshape(w.trk_cnt.shape[0], -1).to(torch.float64),
+                          w.trk_pop[:, 1:]], dim=1)   # one row per world of this rank: [sums | counts | population sums]
         if self.dist is not None and self.dist.is_initialized():   # (also at world size 1: the collective is the same code path)
-            buf = torch.cat([s.reshape(-1), c.reshape(-1), pop])
-            self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM)  # one small fused buffer per interval
-            n = s.numel()
-            s, c, pop = buf[:n].view_as(s), buf[n:2 * n].view_as(c), buf[2 * n:]
-        s, c, pop = s.cpu().numpy(), c.cpu().numpy(), pop.cpu().numpy()
+            # ONE collective per closed interval.  The ranks' PER-WORLD rows are gathered (a few hundred bytes per world and interval)
+            # and every rank then sums the job's worlds in global replica order with the same reduction a single-rank job uses: the
+            # aggregates are bit-identical whatever the number of ranks (a sum of per-rank partial sums -- an all-reduce(SUM) -- would
+            # re-associate the float64 additions: equal to 1e-16 relative, not exactly)
+            flat = torch.empty(self.dist.get_world_size() * rows.numel(), dtype=torch.float64, device=rows.device)
+            self.dist.all_gather_into_tensor(flat, rows.reshape(-1).contiguous())
+            self.collectives_executed += 1
+            rows = flat.view(-1, rows.shape[1])
+        tot = rows.sum(0).cpu().numpy()
+        n = w.trk_sum[0].numel()
+        s, c, pop = tot[:n].reshape(tuple(w.trk_sum.shape[1:])), tot[n:2 * n].reshape(tuple(w.trk_sum.shape[1:])), tot[2 * n:]
         with np.errstate(invalid="ignore", divide="ignore"):
             agg = s / c  # nan when a variable had no valid tick, like np.mean([])
             pagg = pop[0] / pop[1]

@@ -14,18 +14,24 @@ from ..World.environment import Environment
 
 def trainer(brains, n_episodes=10_000, width=30, height=30, visualize_results=False, google_colab=False, update_interval=500,
             print_results=True, max_agents=100, render=False, static_families=True, training=True, save=True,
-            limit_reproduction=False, incentivize_killing=True, *, n_worlds=1, device="cuda:0", seed=0, rng=None, per_agent_api=False,
-            fused=None, synthetic_agents=None, refill_below=None):
+            limit_reproduction=False, incentivize_killing=True, *, n_worlds=1, device=None, seed=0, rng=None, per_agent_api=False,
+            fused=None, synthetic_agents=None, refill_below=None, dist=None, world_base=None):
     """Extra keyword-only arguments: n_worlds / device / seed / rng / synthetic_agents / refill_below (Environment); per_agent_api=True makes the reference's literal
     per-agent get_action / learn calls; fused (default: True for rng="philox" without per_agent_api) runs the loop through
     Environment.run -- whole chunks of ticks per launch, ending where the Tracker closes an interval -- instead of three launches
     and a host round trip per tick; fused=False keeps the tick-by-tick loop (same results, tests/test_hip_round3.py).
-    The wall time of the loop itself is left in env.loop_seconds."""
+    The wall time of the loop itself is left in env.loop_seconds.
+    Several GPUs: start one process per GPU (torchrun) and initialise torch.distributed (backend "nccl" = RCCL) before the
+    call -- or pass the process-group module as `dist`.  Every rank then owns `n_worlds` replicas (global ids rank * n_worlds ...: the
+    worlds are the same whatever the number of ranks), runs on cuda:LOCAL_RANK unless `device` says otherwise, and the Tracker's
+    per-interval statistics (tracker.py:107-121) are pooled over ALL ranks' worlds by one all-reduce per closed interval -- the only
+    collective of the job; every rank returns the same `env.tracker.results`."""
     env = Environment(width=width, height=height, max_agents=max_agents, brains=brains, grid_size=24,
                       static_families=static_families, update_interval=update_interval, print_results=print_results,
                       interactive_results=visualize_results, google_colab=google_colab, training=training,
                       limit_reproduction=limit_reproduction, incentivize_killing=incentivize_killing, n_worlds=n_worlds,
-                      device=device, seed=seed, rng=rng, synthetic_agents=synthetic_agents, refill_below=refill_below)
+                      device=device, seed=seed, rng=rng, synthetic_agents=synthetic_agents, refill_below=refill_below, dist=dist,
+                      world_base=world_base)
     env.reset()
     if fused is None:
         fused = env.rng == "philox" and not per_agent_api

@@ -108,6 +108,18 @@ class DQNAgent(_HipBrain):
         if self.training and n_epi % 30 == 0:
             self.epsilon = max(0.01, 0.20 - 0.20 * (n_epi / self.max_epi))
 
+    def epsilon_schedule(self, n_epi, k):
+        """update_epsilon for episodes n_epi .. n_epi + k - 1 in one go: the rate in force in each of them (float64, the same
+        arithmetic), the brain left as after the last."""
+        out = np.empty(k, np.float64)
+        t = 0
+        while t < k:
+            self.update_epsilon(n_epi + t)           # (acts on multiples of 30 only)
+            nxt = min(k, t + 30 - (n_epi + t) % 30)  # the rate holds until the next multiple
+            out[t:nxt] = self.epsilon
+            t = nxt
+        return out
+
     def get_action(self, state, n_epi, out=None):
         """`out`: this state's Q values when the caller already ran the forward pass in a batch (Environment.act)."""
         self.update_epsilon(n_epi)
@@ -145,6 +157,21 @@ class _DuelingAgent(_HipBrain):
             if self.epsilon > self.epsilon_min:
                 self.epsilon = self.epsilon * self.decay
             self.n_epi = n_epi
+
+    def epsilon_schedule(self, n_epi, k):
+        """update_epsilon for episodes n_epi .. n_epi + k - 1 in one go (the same float64 products in the same order); once the
+        rate has reached its floor -- after ~290 episodes -- the rest of the range is one fill."""
+        out = np.empty(k, np.float64)
+        t = 0
+        while t < k and self.training and self.epsilon > self.epsilon_min:
+            self.update_epsilon(n_epi + t)
+            out[t] = self.epsilon
+            t += 1
+        if t < k:
+            out[t:] = self.epsilon
+            if self.training:
+                self.n_epi = max(self.n_epi, n_epi + k - 1)
+        return out
 
     def get_action(self, state, n_epi, out=None):
         self.update_epsilon(n_epi)
@@ -194,6 +221,9 @@ class PPOAgent(_HipBrain):
 
     def update_epsilon(self, n_epi):
         pass
+
+    def epsilon_schedule(self, n_epi, k):
+        return np.zeros(k, np.float64)
 
     def get_action(self, s, out=None):
         prob = (self.forward_batch(np.asarray(s)[None])[0] if out is None else out).cpu()

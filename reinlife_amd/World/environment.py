@@ -14,6 +14,8 @@ replays the golden traces from their seeds alone).  The draws of _add_food depen
 is two launches (rl_step_split -> host draws -> rl_step_food).  `rng="philox"` (the default and only choice for
 n_worlds > 1) draws inside the kernels from counter-based Philox streams keyed by `seed`.  The Tracker's statistics are accumulated in the step kernel (Helpers/tracker.py); Saver and a headless painter (Helpers/render.py) mirror the reference's; pygame windows are out of scope.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -122,8 +124,8 @@ class AgentView:
 class Environment:
     def __init__(self, width=30, height=30, brains=None, grid_size=16, max_agents=50, update_interval=500, print_results=True,
                  static_families=True, interactive_results=False, google_colab=False, training=True, save=False,
-                 pastel_colors=False, limit_reproduction=False, incentivize_killing=True, *, n_worlds=1, device="cuda:0",
-                 seed=0, rng=None, synthetic_agents=None, refill_below=None):
+                 pastel_colors=False, limit_reproduction=False, incentivize_killing=True, *, n_worlds=1, device=None,
+                 seed=0, rng=None, synthetic_agents=None, refill_below=None, dist=None, world_base=None):
         if not brains:
             raise ValueError("Environment needs a non-empty list of brains")
         self.width, self.height = width, height
@@ -140,6 +142,14 @@ class Environment:
         self.action_space = 8
         self.observation_space = 153
         self.n_worlds = n_worlds
+        # Replica sharding: under an initialised torch.distributed process group (passed as `dist`, or found) this
+        # process is ONE rank of a job whose replicas are `n_worlds` per rank -- global replica ids rank * n_worlds .. + n_worlds - 1
+        # key the Philox streams (results do not depend on the number of ranks), the device defaults to cuda:LOCAL_RANK, and the
+        # Tracker sums its per-interval statistics over all ranks with ONE all-reduce per closed interval.  No other collective.
+        self.dist, self.rank, self.world_size = resolve_dist(dist)
+        self.world_base = int(world_base) if world_base is not None else self.rank * n_worlds
+        if device is None:
+            device = "cuda:%d" % (int(os.environ.get("LOCAL_RANK", "0")) if self.dist is not None else 0)
         self.device = device
         self.rng = rng or ("reference" if n_worlds == 1 else "philox")
         if self.rng not in ("reference", "philox") or (self.rng == "reference" and n_worlds != 1):
@@ -161,17 +171,19 @@ class Environment:
         self.worlds = DeviceWorlds(n_worlds=n_worlds, width=width, height=height, max_agents=max_agents,
                                    n_brains=len(brains), static_families=static_families,
                                    limit_reproduction=limit_reproduction, incentivize_killing=incentivize_killing, seed=seed,
-                                   device=device)
+                                   device=device, world_base=self.world_base)
         # results tracker (environment.py:125-131); numeric part only, fed by the step kernel
         from ..Helpers.tracker import Tracker
         self.tracker = Tracker(update_interval=update_interval, interactive=False, print_results=print_results, nr_genes=len(brains),
-                               static_families=static_families, brains=brains, worlds=self.worlds if training else None)
+                               static_families=static_families, brains=brains, worlds=self.worlds if training else None,
+                               dist=self.dist)
         self._mirrors = {}          # world -> _WorldMirror, built on demand (_mat): env.agents is world 0's
         self._grid = self._max_gene = None
         self._phase = "update"
         self._acted = False         # act() ran since the last step() / update_env(): worlds.actions holds the policy's choice
         self._empty = True          # no world has been built yet (before reset())
-        self._brains_bound = False
+        self._brains_bound, self._bound_key = False, None
+        self._ticks_since_check = 0
         self.loop_seconds = None    # wall time of the last trainer() / tester() loop on this environment (set by them)
         if training:
             warn_inference_only()
@@ -208,8 +220,30 @@ class Environment:
 
     # -- brains -------------------------------------------------------------------------------------------------
     def _bind_brains(self):
-        self.worlds.set_brains([(b.kind, float(getattr(b, "epsilon", 0.0)), b.packed_weights(self.device)) for b in self.brains])
-        self._brains_bound = True
+        """The brains' packed weights and current exploration rates on the device.  Weights are packed and uploaded when they have
+        changed (packed_weights() keys its cache on the parameters' storage and version counters); otherwise only the rates move."""
+        packed = [b.packed_weights(self.device) for b in self.brains]
+        key = tuple((b.kind, id(p)) for b, p in zip(self.brains, packed))   # (a repack makes a new tensor object)
+        eps = [float(getattr(b, "epsilon", 0.0)) for b in self.brains]
+        if self._brains_bound and key == self._bound_key:
+            self.worlds._set_epsilons(eps)
+            return
+        self.worlds.set_brains([(b.kind, e, p) for b, e, p in zip(self.brains, eps, packed)])
+        self._brains_bound, self._bound_key = True, key
+
+    def _epsilon_schedule(self, n_epi, k):
+        """[k, n_brains] float32: the brains' exploration rates in episodes n_epi .. n_epi + k - 1 (their own update rules:
+        DQN.py:67-69, D3QN.py:84-89); leaves every brain in the state it has after episode n_epi + k - 1."""
+        eps = np.empty((k, len(self.brains)), np.float32)
+        for b, brain in enumerate(self.brains):
+            sched = getattr(brain, "epsilon_schedule", None)
+            if sched is not None:
+                eps[:, b] = sched(n_epi, k)
+            else:   # a brain class of the caller's: its own update rule, episode by episode
+                for t in range(k):
+                    brain.update_epsilon(n_epi + t)
+                    eps[t, b] = getattr(brain, "epsilon", 0.0)
+        return eps
 
     # -- reference protocol ---------------------------------------------------------------------------------------
     def reset(self):
@@ -222,12 +256,14 @@ class Environment:
             return
         # replicas: the same construction (one agent per brain, gene = its index; environment.py:147-149) on the device, from the
         # Philox streams keyed by (seed, global replica id): ONE launch for any number of worlds ...
-        if self.n_worlds > 1:
+        if self.n_worlds > 1 or self.world_base != 0:
             self.worlds.reset_families()
-        # ... and world 0 alone consumes the process-global np.random, in the reference's order
-        snap = host_reset(self.width, self.height, len(self.brains))
-        self.worlds.load_world(0, snap)
-        self.worlds.observe()
+        # ... and the job's replica 0 alone (world 0 of the rank with world_base 0) consumes the process-global np.random, in the
+        # reference's order: a sharded job builds the same replicas whatever the number of ranks
+        if self.world_base == 0:
+            snap = host_reset(self.width, self.height, len(self.brains))
+            self.worlds.load_world(0, snap)
+            self.worlds.observe()
         self._empty = False
         self._refresh(after="update")
 
@@ -277,7 +313,13 @@ class Environment:
     def update_env(self, n_epi=0):
         """environment.py:188-215"""
         if self.training:
-            self.tracker.update_results(None, n_epi)   # (the per-tick statistics were accumulated inside the step launch)
+            if self.tracker.update_results(None, n_epi):   # (the per-tick statistics were accumulated inside the step launch)
+                self.worlds.check_error_flag()             # an interval closed: the Tracker has just synchronised
+                self._ticks_since_check = 0
+        self._ticks_since_check += 1
+        if self._ticks_since_check >= 256:   # a loop that never reads env.agents / env.grid still learns of a device error
+            self._sync()
+            self._ticks_since_check = 0
         if self.rng == "reference":
             tape, produced = self._draw_update()
             self.worlds.update(self.worlds.make_tape([tape]))
@@ -391,19 +433,19 @@ class Environment:
             k = min(n_ticks, max_chunk)
             if self.training and n_epi + k - 1 >= interval:   # up to and including the next episode that closes a Tracker interval
                 k = min(k, (max(n_epi, 1) + interval - 1) // interval * interval - n_epi + 1)
-            eps = np.empty((k, len(self.brains)), np.float32)
-            for t in range(k):
-                for b, brain in enumerate(self.brains):
-                    brain.update_epsilon(n_epi + t)
-                    eps[t, b] = getattr(brain, "epsilon", 0.0)
-            self._bind_brains()   # (the brains' current epsilon = the last row)
-            # episode 0 writes its statistics but stays out of the running sums (Tracker.update_results(n_epi=0) zeroes them)
+            eps = self._epsilon_schedule(n_epi, k)
+            self._bind_brains()   # (the brains' current epsilon = the last row; weights are uploaded only when they changed)
+            if self.training and n_epi == 0:
+                # Tracker.update_results(n_epi=0) zeroes the running sums (tracker.py:279-282): whatever an earlier loop on this
+                # environment left in them goes, and episode 0 itself stays out of them inside the launch (trk_skip)
+                self.worlds.reset_tracking()
             self.worlds.run(k, thr, self.synthetic_agents or 0, eps_schedule=None if (eps == eps[-1]).all() else eps,
                             trk_skip=1 if (self.training and n_epi == 0) else 0)
             self._refresh(after="update")
             last = n_epi + k - 1
             if self.training and last > 0 and last % interval == 0:
                 self.tracker.update_results(None, last)
+                self.worlds.check_error_flag()   # (the Tracker has just synchronised: a corrupted world stops the loop at the interval)
             n_epi += k
             n_ticks -= k
 
@@ -450,6 +492,18 @@ class Environment:
         self._acted = False
         self._mirrors = {}
         self._grid = self._max_gene = None
+
+
+def resolve_dist(dist=None):
+    """(process-group module or None, rank, world size): `dist` as given (torch.distributed or a stand-in with the same calls), else
+    torch.distributed when a default process group is initialised, else a single-process job."""
+    if dist is None:
+        import torch.distributed as td
+        if td.is_available() and td.is_initialized():
+            dist = td
+    if dist is not None and dist.is_initialized():
+        return dist, int(dist.get_rank()), int(dist.get_world_size())
+    return None, 0, 1
 
 
 def warn_inference_only():

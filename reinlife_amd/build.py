@@ -28,35 +28,66 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(paths, extra=""):
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for f in paths:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def _stamp_ok(target, want):
+    """A built file is current when it exists and the stamp beside it (<file>.srchash) names the digest of what it was built from.
+    Content, not mtimes: prebuilt objects travel to the GPU box next to freshly copied sources, and a stale object with a newer
+    mtime must not survive there."""
+    try:
+        with open(target + ".srchash") as fh:
+            return os.path.exists(target) and fh.read().strip() == want
+    except OSError:
+        return False
+
+
+def _write_stamp(target, digest):
+    with open(target + ".srchash", "w") as fh:
+        fh.write(digest + "\n")
 
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(LIB_DIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
-    objs, jobs = [], []
+    flags = FLAGS + (["-DRL_PHASE_PROFILE"] if PROFILE else [])
+    objs, digests, jobs = [], [], []
     for src in SOURCES:   # the translation units compile side by side (rl_world.hip alone takes over a minute)
         sp = os.path.join(CSRC, src)
         obj = os.path.join(LIB_DIR, src.replace(".hip", TAG + ".o"))
-        objs.append(obj)
-        if force or _stale(obj, [sp] + hdrs):
-            cmd = [hipcc] + FLAGS + (["-DRL_PHASE_PROFILE"] if PROFILE else []) + ["-c", sp, "-o", obj]
+        want = _digest([sp] + hdrs, " ".join(flags))   # (every unit includes every header)
+        objs.append(obj); digests.append(want)
+        if force or not _stamp_ok(obj, want):
+            cmd = [hipcc] + flags + ["-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
-            jobs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, job in jobs:
+            if os.path.exists(obj + ".srchash"):
+                os.remove(obj + ".srchash")
+            jobs.append((cmd, subprocess.Popen(cmd), obj, want))
+    failed = None
+    for cmd, job, obj, want in jobs:   # wait for EVERY compiler before reporting the first failure (no orphaned hipcc behind an exception)
         if job.wait() != 0:
-            raise subprocess.CalledProcessError(job.returncode, cmd)
-    if force or _stale(LIB_PATH, objs):
+            failed = failed or subprocess.CalledProcessError(job.returncode, cmd)
+        else:
+            _write_stamp(obj, want)
+    if failed is not None:
+        raise failed
+    lib_want = _digest([], " ".join(digests))
+    if force or jobs or not _stamp_ok(LIB_PATH, lib_want):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
         if verbose:
             print(" ".join(cmd))
+        if os.path.exists(LIB_PATH + ".srchash"):
+            os.remove(LIB_PATH + ".srchash")
         subprocess.check_call(cmd)
+        _write_stamp(LIB_PATH, lib_want)
     return LIB_PATH
 
 

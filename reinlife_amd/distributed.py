@@ -2,6 +2,8 @@
 block of global replica ids and the only collective of a job is ONE all-gather of the metric counters (a row per rank)."""
 import torch
 
+collectives_executed = 0   # collectives this module has issued in this process (bench.py reports it; tests assert it)
+
 
 def shard(n_worlds_total, rank, world_size):
     """(first global replica id, number of replicas) of this rank: contiguous blocks, remainder to the low ranks."""
@@ -20,6 +22,8 @@ def reduce_counters(counters, elapsed_s, dist=None):
     where RCCL executes the same call."""
     row = torch.cat([counters.to(torch.float64), torch.tensor([elapsed_s], dtype=torch.float64, device=counters.device)])
     if dist is not None and dist.is_initialized():
+        global collectives_executed
+        collectives_executed += 1
         flat = torch.empty(dist.get_world_size() * row.numel(), dtype=torch.float64, device=row.device)
         dist.all_gather_into_tensor(flat, row)   # (flat output: the shape every backend accepts)
         table = flat.view(dist.get_world_size(), row.numel())

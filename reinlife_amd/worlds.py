@@ -86,6 +86,8 @@ class DeviceWorlds:
         self._eps_keep = None
         self._capture_prob = False
         self._fused_key = self._fused = None
+        self._eps_ring, self._eps_slot = [], 0   # pinned staging of run()'s epsilon schedules (slot: host buffer, device buffer, copy-done event)
+        self.launches = 0                        # kernel-launching C-ABI calls made by run() so far (bench.py reports it)
 
     def __del__(self):
         try:
@@ -278,32 +280,43 @@ class DeviceWorlds:
             raise _lib.ReinLifeHipError("set_brains() was not called")
         if n_ticks <= 0:
             return
+        eps_host = None
         if eps_schedule is not None:
-            if not torch.is_tensor(eps_schedule) or not eps_schedule.is_cuda:   # host array: pinned staging + asynchronous upload
-                host = torch.as_tensor(np.ascontiguousarray(eps_schedule, dtype=np.float32)) if not torch.is_tensor(eps_schedule) else eps_schedule.float()
-                eps_schedule = host.pin_memory().to(self.device, non_blocking=True)
-            eps_schedule = eps_schedule.to(torch.float32).contiguous()
-            assert tuple(eps_schedule.shape) == (n_ticks, self.n_brains)
+            if not torch.is_tensor(eps_schedule) or not eps_schedule.is_cuda:
+                eps_host = np.ascontiguousarray(eps_schedule.cpu().numpy() if torch.is_tensor(eps_schedule) else eps_schedule, dtype=np.float32)
+                assert eps_host.shape == (n_ticks, self.n_brains)
+            else:
+                eps_schedule = eps_schedule.to(torch.float32).contiguous()
+                assert tuple(eps_schedule.shape) == (n_ticks, self.n_brains)
         # (with many worlds per GPU -- several per CU -- the two stand-alone launches are faster: 8.0e8 against 6.1e8 agent-steps/s
         # at 1024 worlds, the cross-world policy tiles waste fewer rows; RL_RUN_ALWAYS=1 forces the single launch)
-        key = (id(self._brains), os.environ.get("RL_WORLD_BLOCK"), os.environ.get("RL_RUN_ALWAYS"))   # (what the decision depends on)
+        # (what the decision depends on: the brains' kinds -- set_brains() drops the cached answer -- and the two switches)
+        key = (os.environ.get("RL_WORLD_BLOCK"), os.environ.get("RL_RUN_ALWAYS"))
         if self._fused_key != key:
             self._fused_key, self._fused = key, self.run_supported() and (self.R <= 768 or bool(os.environ.get("RL_RUN_ALWAYS")))
         fused = self._fused
         if not fused:
+            if eps_schedule is not None and eps_host is None:
+                eps_host = eps_schedule.cpu().numpy()   # ONE read-back, not one per tick
+            keep = None
+            if self.tracking and trk_skip > 0:   # like the kernel: the first trk_skip ticks stay out of the running sums, earlier sums stay
+                keep = (self.trk_sum.clone(), self.trk_cnt.clone(), self.trk_pop[:, 1:].clone())
             for t in range(n_ticks):
-                if eps_schedule is not None:
-                    self._set_epsilons(eps_schedule[t].tolist())
+                if eps_host is not None:
+                    self._set_epsilons(eps_host[t].tolist())
                 self.act(want_q=self.replays is not None and self._capture_prob)
                 if threshold >= 0:
                     self.tick_refill(threshold, n_agents)
                 else:
                     self.tick()
+                self.launches += 2
                 if self.replays is not None:
                     self.capture_transitions(with_policy_out=self._capture_prob)
-                if self.tracking and t + 1 == trk_skip:
-                    self.reset_tracking()
+                if keep is not None and t + 1 == trk_skip:
+                    self.trk_sum.copy_(keep[0]); self.trk_cnt.copy_(keep[1]); self.trk_pop[:, 1:].copy_(keep[2])
             return
+        if eps_host is not None:
+            eps_schedule = self._stage_schedule(eps_host)
         if self._run_pair is None:
             self._run_pair = (C.c_void_p * 2)(_ptr(self._obs2[0]), _ptr(self._obs2[1]))
         cap = self.replays is not None
@@ -312,8 +325,34 @@ class DeviceWorlds:
         _lib.check(self.lib.rl_run_ex(self.handle, self._brains, self.n_brains, n_ticks, _ptr(self.actions), C.byref(self._step_out),
                                       self._run_pair, self._cur, _ptr(self.src2), C.byref(opts), self._stream()), "rl_run_ex")
         self._eps_keep = eps_schedule   # the launch reads it asynchronously
+        self.launches += 1
         self._cur = (self._cur + n_ticks) & 1
         self._ticked = True
+
+    def _stage_schedule(self, host):
+        """A host [n_ticks, n_brains] float32 schedule -> device, through a small ring of persistent pinned buffers (allocating and
+        pinning a fresh buffer per launch cost more than a short launch's kernel).  A slot is reused only once its previous
+        upload has executed (its event), and its device buffer only once the launch that read it has finished (stream order: the
+        next upload into it is queued behind that launch)."""
+        n = host.size
+        if len(self._eps_ring) < 4:
+            cap = max(4096, 1 << int(n - 1).bit_length())
+            slot = [torch.empty(cap, dtype=torch.float32).pin_memory(), torch.empty(cap, dtype=torch.float32, device=self.device),
+                    torch.cuda.Event()]
+            self._eps_ring.append(slot)
+        else:
+            slot = self._eps_ring[self._eps_slot % 4]
+            self._eps_slot += 1
+            if slot[0].numel() < n:
+                cap = 1 << int(n - 1).bit_length()
+                slot[2].synchronize()
+                slot[0], slot[1] = torch.empty(cap, dtype=torch.float32).pin_memory(), torch.empty(cap, dtype=torch.float32, device=self.device)
+            slot[2].synchronize()
+        slot[0][:n].copy_(torch.from_numpy(host.reshape(-1)))
+        dev = slot[1][:n]
+        dev.copy_(slot[0][:n], non_blocking=True)
+        slot[2].record(torch.cuda.current_stream(self.device))
+        return dev.view(host.shape)
 
     def _set_epsilons(self, eps):
         for b, e in enumerate(eps):
@@ -346,6 +385,7 @@ class DeviceWorlds:
             assert packed.numel() == self.lib.rl_policy_packed_floats(kind)
             arr[k] = _lib.Brain(kind, float(eps), packed.data_ptr())
         self._brains = arr
+        self._fused_key = None   # (the fused / two-launch decision depends on the brains' kinds)
         if self._work is None:
             nbytes = self.lib.rl_policy_work_bytes(self.handle)
             self._work = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=self.device)

@@ -317,6 +317,14 @@ def test_bench_rccl_path_at_world_size_one_reduces_the_same_counters():
     plain = _bench({})
     dist = _bench({"RL_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     assert plain["rccl_ranks"] == 1 and dist["rccl_ranks"] == 1 and dist["n_gpus"] == 1
+    # the metric's reduction really ran over RCCL, once -- and never without a process group
+    assert dist["rccl_collectives_executed"] == 1 and plain["rccl_collectives_executed"] == 0
+    # trainer() under the process group: rank -> world_base, ONE collective per closed Tracker interval (4 in the warm-up call with
+    # update_interval=10, 4 in the 2000-episode call, none in the 30-episode window), and the pooled statistics are the plain run's
+    ta, tb = plain["api_trainer"], dist["api_trainer"]
+    assert tb["ranks"] == 1 and tb["world_base"] == 0 and ta["tracker_rccl_collectives"] == 0
+    assert tb["tracker_rccl_collectives"] == 8 and tb["tracker_intervals_closed"] == 4
+    assert ta["tracker_last_interval"] == tb["tracker_last_interval"] and ta["launches"] == tb["launches"] == 4
     for key in ("agent_steps", "mean_agents_per_world", "world_refills", "worlds_total"):
         assert plain["config"][key] == dist["config"][key], key
     assert plain["config"]["agent_steps"] > 30 * 64 * 60

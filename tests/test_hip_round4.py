@@ -1,0 +1,183 @@
+"""GPU, round 4: parity AT THE BENCHED SIZE (256 worlds = 256 staggered workgroups) for the two instantiations of the multi-tick
+kernel that round 3 only covered at 6-14 worlds -- k_run<512, fixed, kKindAll> (BASELINE configs[4] per GPU: PPO + PERD3QN,
+static_families=False; PPO.py:101-106,164-169, PERD3QN.py:198-210, environment.py:521-547,728-739) and k_run<512, fixed, dueling,
+TRAIN 1> (what trainer() / bench.py's api_trainer launch: per-tick epsilon schedule + Tracker, tracker.py:107-282) -- each against the
+oracle fed the launch's actions and as ONE launch of 200 ticks against 200 launches of one; replica sharding through the API on the
+GPU (the Tracker's collective over RCCL at world size 1)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from test_hip_round2 import _cmp_rows, _cmp_state, _same_device_state  # noqa: E402
+from test_hip_round3 import _same_tracker  # noqa: E402
+
+SEED, TICKS = 20260928, 200
+
+
+def _worlds(workload, tracking=False):
+    sys.path.insert(0, ROOT)
+    import bench
+    dw = bench.make_worlds(argparse.Namespace(worlds=256, workload=workload, seed=SEED), 0, "cuda:0")
+    if tracking:
+        dw.enable_tracking(True)
+    assert dw.run_supported()
+    return dw, bench.WORKLOADS[workload]
+
+
+def _schedule(n_brains, t0, n):
+    """A per-tick exploration schedule that changes every tick and differs between the brains (float32, as Environment.run uploads it)."""
+    t = np.arange(t0, t0 + n, dtype=np.float64)[:, None]
+    return (0.35 * 0.99 ** t * (1.0 + 0.5 * np.arange(n_brains)[None, :])).astype(np.float32)
+
+
+def _against_the_oracle(workload, train):
+    from oracle import oracle as orc
+    dw, wl = _worlds(workload, tracking=train)
+    nb = len(wl["brains"])
+    ow = orc.OracleWorlds(n_worlds=256, seed=SEED, width=30, height=30, max_agents=100, n_brains=nb, static_families=wl["static_families"])
+    ow.reset_synthetic(100)
+    steps = 0
+    for t in range(TICKS):
+        n0 = ow.s["n_agents"].copy()
+        if train:
+            dw.run(1, 70, 100, eps_schedule=_schedule(nb, t, 1), trk_skip=1 if t == 0 else 0)
+        else:
+            dw.run(1, 70, 100)
+        acts = dw.actions.cpu().numpy()
+        if train and t == 0:
+            keep = (ow.trk_sum.copy(), ow.trk_cnt.copy(), ow.trk_pop.copy())
+        ow.step(acts)
+        if train:
+            if t == 0:   # (episode 0 stays out of the running sums)
+                ow.trk_sum[:] = keep[0]; ow.trk_cnt[:] = keep[1]; ow.trk_pop[:, 1:] = keep[2][:, 1:]
+            assert np.array_equal(dw.trk_tick.cpu().numpy(), ow.trk_tick, equal_nan=True), ("trk_tick", t)
+        full = t % 10 == 9
+        if full:
+            n1 = ow.s["n_agents"].copy()
+            _cmp_rows(dw.obs_state_prime().cpu().numpy(), ow.obs1, n1, "tick %d obs1" % t)
+            _cmp_rows(dw.reward.cpu().numpy(), ow.reward, n1, "tick %d reward" % t)
+            _cmp_rows(dw.done.cpu().numpy(), ow.done, n1, "tick %d done" % t)
+            _cmp_rows(dw.src1.cpu().numpy(), ow.src1, n1, "tick %d src1" % t)
+        ow.update(); ow.refill(70, 100)
+        assert np.array_equal(dw.n_acted.cpu().numpy(), n0)
+        steps += int(n0.sum())
+        for key in ("cell_type", "n_agents", "tick", "epoch", "next_uid", "max_gene"):
+            assert np.array_equal(dw.s[key].cpu().numpy().reshape(ow.s[key].shape), ow.s[key]), (t, key)
+        if full:
+            dw.check_error_flag()
+            _cmp_state(dw, ow, "tick %d" % t)
+            _cmp_rows(dw.obs_state().cpu().numpy(), ow.obs2, ow.s["n_agents"], "tick %d obs2" % t)
+            if train:
+                for name in ("trk_sum", "trk_cnt"):
+                    assert np.array_equal(getattr(dw, name).cpu().numpy(), getattr(ow, name), equal_nan=True), (name, t)
+                assert np.array_equal(dw.trk_pop.cpu().numpy()[:, 1:], ow.trk_pop[:, 1:]), ("trk_pop", t)
+    assert steps > 4_000_000 and int(dw.acted_total.item()) == steps and int(dw.refill_count.item()) > 300
+    return dw, ow
+
+
+def _one_launch_against_many(workload, train):
+    a, wl = _worlds(workload, tracking=train)
+    b, _ = _worlds(workload, tracking=train)
+    nb = len(wl["brains"])
+    if train:
+        a.run(TICKS, 70, 100, eps_schedule=_schedule(nb, 0, TICKS), trk_skip=1)
+        for t in range(TICKS):
+            b.run(1, 70, 100, eps_schedule=_schedule(nb, t, 1), trk_skip=1 if t == 0 else 0)
+    else:
+        a.run(TICKS, 70, 100)
+        for _ in range(TICKS):
+            b.run(1, 70, 100)
+    a.check_error_flag(); b.check_error_flag()
+    _same_device_state(a, b, "%d ticks" % TICKS)
+    assert int(a.acted_total.item()) == int(b.acted_total.item()) and int(a.refill_count.item()) == int(b.refill_count.item()) > 300
+    _cmp_rows(a.actions.cpu().numpy(), b.actions.cpu().numpy(), a.n_acted.cpu().numpy(), "actions")
+    for name in ("reward", "done", "src1", "src2"):
+        assert np.array_equal(getattr(a, name).cpu().numpy(), getattr(b, name).cpu().numpy()), name
+    assert np.array_equal(a.obs_state_prime().cpu().numpy(), b.obs_state_prime().cpu().numpy())
+    if train:
+        _same_tracker(a, b, "%d ticks" % TICKS)
+
+
+def test_c5_size_mixed_kind_launch_tracks_the_oracle_for_200_ticks():
+    """k_run<512, fixed, kKindAll, TRAIN 0> on 256 workgroups (bench.py's `c5` leg): integer state every tick, both observation passes
+    and every per-agent output every 10 ticks, non-static families (max_gene, best agents)."""
+    _against_the_oracle("c5", train=False)
+
+
+def test_c5_size_one_launch_of_200_ticks_equals_200_launches_of_one():
+    _one_launch_against_many("c5", train=False)
+
+
+def test_trainer_instantiation_at_the_benched_size_tracks_the_oracle_for_200_ticks():
+    """k_run<512, fixed, dueling, TRAIN 1> on 256 workgroups (what bench.py's api_trainer / trainer() launch): exploring brains on a
+    per-tick schedule, the Tracker's per-tick values every tick and its running sums every 10."""
+    _against_the_oracle("c4", train=True)
+
+
+def test_trainer_instantiation_one_launch_of_200_ticks_equals_200_launches_of_one():
+    _one_launch_against_many("c4", train=True)
+
+
+def test_c5_trainer_instantiation_one_launch_equals_many():
+    """... and the mixed-kind TRAIN instantiation (k_run<512, fixed, kKindAll, TRAIN 1>: trainer() with configs[4]'s brains)."""
+    _one_launch_against_many("c5", train=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# replica sharding through the API on the GPU: the Tracker's collective over RCCL (world size 1), world_base from the rank
+# ---------------------------------------------------------------------------------------------------------------------
+def test_trainer_under_a_process_group_shards_by_rank_and_reduces_its_tracker_over_rccl():
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    code = r'''
+import json, os, sys, warnings
+sys.path.insert(0, %r)
+import torch
+import torch.distributed as dist
+from reinlife_amd import Models
+from reinlife_amd.Helpers.trainer import trainer
+use_dist = sys.argv[1] == "dist"
+if use_dist:
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+torch.manual_seed(3)
+brains = [Models.PERD3QN(), Models.D3QN()]
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    env = trainer(brains, n_episodes=120, update_interval=40, n_worlds=24, save=False, print_results=False, seed=77,
+                  synthetic_agents=100, refill_below=70)
+print(json.dumps({"results": env.tracker.results, "collectives": env.tracker.collectives_executed, "rank": env.rank, "base": env.world_base,
+                  "device": str(env.device), "has_dist": env.dist is not None, "acted": int(env.worlds.acted_total.item())}))
+if use_dist:
+    dist.barrier(); dist.destroy_process_group()
+''' % ROOT
+    import json
+    outs = {}
+    for mode in ("plain", "dist"):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        out = subprocess.run([sys.executable, "-c", code, mode], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs[mode] = json.loads(out.stdout.strip().splitlines()[-1])
+    p, d = outs["plain"], outs["dist"]
+    assert not p["has_dist"] and p["collectives"] == 0
+    assert d["has_dist"] and d["collectives"] == 3 and d["rank"] == 0 and d["base"] == 0 and d["device"] == "cuda:0"
+    assert p["acted"] == d["acted"] > 100_000
+    assert json.dumps(p["results"], sort_keys=True) == json.dumps(d["results"], sort_keys=True)
+    assert len(p["results"]["Avg Number of Populations"]) == 3
+
+
+def test_random_configurations_through_the_launch_64_cases():
+    """tools/fuzz_parity.py, 64 cases (round 3: 16): random world shapes, capacities, brain lists of any kinds, family modes and launch
+    modes (plain / Tracker + schedule / capture) against the oracle and against tick-by-tick launches."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "64", "11"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "fuzz ok: 64 cases" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

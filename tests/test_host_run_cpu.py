@@ -36,6 +36,10 @@ class _FakeWorlds:
 
     def set_brains(self, brains):
         self.brains = [(k, e) for k, e, _ in brains]
+        self.calls.append(("set_brains",))
+
+    def _set_epsilons(self, eps):
+        self.brains = [(k, e) for (k, _), e in zip(self.brains, eps)]
 
     def run(self, n_ticks, threshold=-1, n_agents=0, eps_schedule=None, trk_skip=0):
         self.calls.append(("run", n_ticks, threshold, n_agents, None if eps_schedule is None else np.array(eps_schedule), trk_skip,
@@ -102,7 +106,10 @@ def test_run_cuts_chunks_at_tracker_boundaries_and_builds_the_brains_own_schedul
     # five closed intervals; the stand-in counted one valid value per counted tick and world, so every aggregate is exactly 1
     res = env.tracker.results
     assert len(res["Avg Number of Populations"]) == 5 and res["Avg Population Size"][0] == [1.0] * 5
-    assert sum(1 for c in env.worlds.calls if c[0] == "reset_tracking") == 5
+    # ... each closing zeroes the sums, and so does episode 0 (Tracker.update_results(n_epi=0), tracker.py:279-282) before its launch
+    assert sum(1 for c in env.worlds.calls if c[0] == "reset_tracking") == 6 and env.worlds.calls.index(("reset_tracking",)) < env.worlds.calls.index(runs[0])
+    # the weights go to the device ONCE; later chunks only move the exploration rates
+    assert sum(1 for c in env.worlds.calls if c[0] == "set_brains") == 1
 
 
 def test_run_in_arbitrary_pieces_and_constant_epsilon(fake_env):
