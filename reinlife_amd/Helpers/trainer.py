@@ -9,6 +9,8 @@ of this build do not learn -- Environment warns about it, and save=True writes t
 (settings.json says so).  Training is outside this build's scope (BASELINE.json north_star)."""
 import time
 
+import torch
+
 from ..World.environment import Environment
 
 
@@ -61,8 +63,9 @@ def trainer(brains, n_episodes=10_000, width=30, height=30, visualize_results=Fa
                 env.update_env(n_epi)
             if render:  # trainer.py:101-102
                 env.render(fps=120)
-    env._sync()
+    torch.cuda.synchronize(env.worlds.device)      # the loop is over when the device is
     env.loop_seconds = time.perf_counter() - t0
+    env.worlds.check_error_flag()                  # (a read-back of its own: after the clock)
     if save:
         env.save_results()
     return env

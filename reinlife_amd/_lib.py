@@ -93,6 +93,8 @@ ABI = [
     ("rl_policy_work_bytes", C.c_size_t, [_P]),
     ("rl_bind_policy_work", C.c_int, [_P, _P]),
     ("rl_policy_act", C.c_int, [_P, C.POINTER(Brain), C.c_int, _P, _P, _P, _P, _P]),
+    ("rl_set_option", C.c_int, [C.c_char_p, C.c_char_p]),
+    ("rl_get_option", C.c_int, [_P, C.c_char_p]),
     ("rl_philox", None, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                          C.POINTER(C.c_uint32 * 4)]),
 ]
@@ -121,6 +123,12 @@ def lib():
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+def set_option(name, value=None):
+    """rl_set_option: a process-level tuning / test switch (include/reinlife_hip.h "options"); handles created afterwards use it.
+    value None restores what the environment said when the library was loaded."""
+    check(lib().rl_set_option(name.encode(), None if value is None else str(value).encode()), "rl_set_option(%s)" % name)
 
 
 def check(rc, what):

@@ -29,6 +29,41 @@ int rl_policy_act_impl(rl_world*, const rl_brain*, int, const float*, int8_t*, f
 
 static thread_local char g_err[512] = "";
 
+// ---- options: environment read once, rl_set_option afterwards -------------------------------------------------------------------
+#include <stdlib.h>
+static int parse_variant(const char* v)
+{
+    if (!v || !*v || !strcmp(v, "auto")) return RL_PV_AUTO;
+    if (!strcmp(v, "nsplit")) return RL_PV_NSPLIT;
+    if (!strcmp(v, "wave")) return RL_PV_WAVE;
+    if (!strcmp(v, "dense")) return RL_PV_DENSE;
+    if (!strcmp(v, "pair")) return RL_PV_PAIR;
+    return -1;
+}
+static int parse_block(const char* v)
+{
+    const int b = (v && *v) ? atoi(v) : 0;
+    return (b == 0 || b == 256 || b == 512 || b == 1024) ? b : -1;
+}
+static rl_options options_from_env()
+{
+    rl_options o{};
+    const int b = parse_block(getenv("RL_WORLD_BLOCK"));
+    o.world_block = b < 0 ? 0 : b;
+    o.world_generic = getenv("RL_WORLD_GENERIC") ? 1 : 0;
+    const int v = parse_variant(getenv("RL_POLICY_VARIANT"));
+    o.policy_variant = v < 0 ? RL_PV_AUTO : v;
+    o.policy_per_kind = getenv("RL_POLICY_PER_KIND") ? 1 : 0;
+    o.run_always = getenv("RL_RUN_ALWAYS") ? 1 : 0;
+    return o;
+}
+static rl_options& options_mut()
+{
+    static rl_options o = options_from_env();   // (thread-safe one-time initialisation)
+    return o;
+}
+const rl_options& rl_options_current() { return options_mut(); }
+
 // The device a handle's buffers live on (taken from the state pointers in rl_bind_state).  Every launching entry point
 // makes it current for the duration of the call, so a caller whose current device is another GPU (several handles on
 // several GPUs in one process) still launches in the right context.
@@ -58,6 +93,38 @@ void rl_set_error(const char* fmt, ...)
 
 extern "C" {
 
+int rl_set_option(const char* name, const char* value)
+{
+    if (!name) { rl_set_error("rl_set_option: null name"); return RL_E_INVALID; }
+    rl_options& o = options_mut();
+    const rl_options env = options_from_env();   // value == NULL: back to what the environment says
+    if (!strcmp(name, "world_block")) {
+        const int b = value ? parse_block(value) : env.world_block;
+        if (b < 0) { rl_set_error("rl_set_option: world_block must be 0 (auto), 256, 512 or 1024"); return RL_E_INVALID; }
+        o.world_block = b;
+    } else if (!strcmp(name, "world_generic")) o.world_generic = value ? (atoi(value) != 0) : env.world_generic;
+    else if (!strcmp(name, "policy_variant")) {
+        const int v = value ? parse_variant(value) : env.policy_variant;
+        if (v < 0) { rl_set_error("rl_set_option: policy_variant must be auto, pair, dense, wave or nsplit"); return RL_E_INVALID; }
+        o.policy_variant = v;
+    } else if (!strcmp(name, "policy_per_kind")) o.policy_per_kind = value ? (atoi(value) != 0) : env.policy_per_kind;
+    else if (!strcmp(name, "run_always")) o.run_always = value ? (atoi(value) != 0) : env.run_always;
+    else { rl_set_error("rl_set_option: unknown option '%s'", name); return RL_E_INVALID; }
+    return RL_OK;
+}
+
+int rl_get_option(const rl_world* h, const char* name)
+{
+    const rl_options& o = h ? h->opt : rl_options_current();
+    if (!name) return -1;
+    if (!strcmp(name, "world_block")) return o.world_block;
+    if (!strcmp(name, "world_generic")) return o.world_generic;
+    if (!strcmp(name, "policy_variant")) return o.policy_variant;
+    if (!strcmp(name, "policy_per_kind")) return o.policy_per_kind;
+    if (!strcmp(name, "run_always")) return o.run_always;
+    return -1;
+}
+
 const char* rl_last_error(void) { return g_err; }
 const char* rl_version(void) { return "reinlife_hip 0.2 (gfx950)"; }
 
@@ -81,6 +148,7 @@ int rl_create(const rl_config* cfg, rl_world** out)
     rl_world* h = new (std::nothrow) rl_world();
     if (!h) { rl_set_error("rl_create: out of memory"); return RL_E_INVALID; }
     h->cfg = *cfg;
+    h->opt = rl_options_current();   // the handle's kernels are chosen from this snapshot: nothing reads the environment at a launch
     h->cells = cells;
     h->cpad = (cells + 63) & ~63;
     int hs = 64;

@@ -512,40 +512,52 @@ static int policy_grid(int64_t max_rows)  // tiles one brain can have: one 4-wav
     return (int)(blocks < 1 ? 1 : blocks);
 }
 
-// expected_rows: how many rows the launch will really process (max_rows only bounds the grid): picks the variant
-static int launch_policy(int kind, const PolicyArgs& a, int64_t max_rows, int64_t expected_rows, hipStream_t st)
+// Which kernel serves a stand-alone policy launch.
+//
+// ONE ARITHMETIC: the default ("auto") runs the tiles of the multi-tick kernel's policy half -- per output accumulator the partial products
+// hi.lo, hi.hi, lo.hi of every 16-k chunk in chunk order into ONE f32 accumulator, heads as three product chains joined at the end
+// (policy_tile1 / policy_tile1s / policy_tile1ds for the dueling kinds, policy_pair2 for DQN and PPO) -- so rl_policy_act + rl_tick,
+// rl_run, one GPU or eight, 256 worlds or 4096 give the same Q values, probabilities and actions BIT FOR BIT:
+//   pair    k_policy_pair: two waves per 32-row tile, brains of any kinds in one launch (the default below 1,536 tiles, and for DQN / PPO)
+//   dense   k_policy_dense: four one-wave tiles of one dueling brain per workgroup, weights through LDS -- the same bits as `pair` for
+//           the dueling kinds; the default from 1,536 tiles on (2,048 / 4,096 / 10,880 tiles: 32.4 / 60.9 / 148 us against 38.6 / 72.7 /
+//           188 for the 4-wave tile)
+//   wave    k_policy1: one wave per tile, no LDS (dueling kinds; the same bits again) -- measurement only
+//   nsplit  k_policy / k_policy_mixed: the 4-wave N-split tile of rounds 1-2 (main + cross accumulators: agrees with the others to ~1e-7,
+//           NOT bit for bit) -- kept for measurements and for k_run<1024>, never chosen automatically
+// The variant comes from the handle's option snapshot (rl_set_option / RL_POLICY_VARIANT at rl_create), not from getenv at the launch.
+static bool kind_is_dueling(int kind) { return kind == RL_D3QN || kind == RL_PERD3QN; }
+static int resolve_variant(int variant, bool all_dueling, int64_t expected_rows)
+{
+    if (variant == RL_PV_AUTO) return (all_dueling && expected_rows / 32 >= 1536) ? RL_PV_DENSE : RL_PV_PAIR;
+    if ((variant == RL_PV_DENSE || variant == RL_PV_WAVE) && !all_dueling) return RL_PV_PAIR;   // (those kernels exist for the dueling kinds)
+    return variant;
+}
+static int launch_check(const char* what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rl_set_error("%s launch failed: %s", what, hipGetErrorString(e)); return RL_E_LAUNCH; }
+    return RL_OK;
+}
+// One launch for the brains in `a` (<= kMaxBrainsPerLaunch); `variant` already resolved; nsplit: all brains of `kind`.
+static int launch_policy(int variant, int kind, const PolicyArgs& a, int64_t max_rows, int64_t expected_rows, hipStream_t st)
 {
     // grid = (tiles a brain can have at most, brains): the bound is several times the real tile count (a brain COULD own every
     // agent), but the ~2,500 empty workgroups cost < 1 us (a dense launch of the same 680 tiles without them: 17.6 vs 18.4 us).
     // Brain-fastest order (all real tiles dispatched first) is SLOWER: 21.6 vs 18.4 us.
     const dim3 grid(policy_grid(max_rows), a.nb), block(256);
-    // Dueling kinds, variants (env RL_POLICY_VARIANT, read at every launch): "wave" = one wave per 32-row tile (policy_tile1: set it to
-    // compare rl_run, whose workgroups run that arithmetic, with this path bit for bit); "dense" = four one-wave tiles of one brain per
-    // workgroup with the weights through LDS (policy_tile1ds), the default from 1,536 tiles on (dense launches of one brain, 2,048 / 4,096 /
-    // 10,880 tiles: 32.4 / 60.9 / 148 us against 38.6 / 72.7 / 188 for the 4-wave tile; below ~1,200 tiles its 30 stage barriers per tile
-    // cost more than the weight bytes it saves); "nsplit" forces the 4-wave 32-row tile, the default below that (at 256 worlds the fastest
-    // stand-alone launch: dense 680 tiles 17.6 us against 17.8; from freshly written rows 18.9 against 25.8 for the one-wave tile, whose
-    // row reads are not coalesced).
-    const char* variant = getenv("RL_POLICY_VARIANT");
-    if (variant && !strcmp(variant, "pair")) {   // two waves per tile, any kinds: the arithmetic of rl_run's policy half
+    if (variant == RL_PV_PAIR) {
         hipLaunchKernelGGL(k_policy_pair, grid, dim3(128), kPairKernelLds, st, a);
-        const hipError_t e1 = hipGetLastError();
-        if (e1 != hipSuccess) { rl_set_error("policy kernel launch failed: %s", hipGetErrorString(e1)); return RL_E_LAUNCH; }
-        return RL_OK;
+        return launch_check("policy kernel (pair)");
     }
-    if ((kind == RL_D3QN || kind == RL_PERD3QN) && !variant && expected_rows / 32 >= 1536) variant = "dense";
-    if ((kind == RL_D3QN || kind == RL_PERD3QN) && variant && (!strcmp(variant, "wave") || !strcmp(variant, "dense"))) {
-        if (!strcmp(variant, "dense")) {
-            const dim3 gridd((grid.x + kDenseTiles - 1) / kDenseTiles, a.nb);
-            if (kind == RL_D3QN) hipLaunchKernelGGL((k_policy_dense<RL_D3QN>), gridd, dim3(64 * kDenseTiles), 0, st, a);
-            else hipLaunchKernelGGL((k_policy_dense<RL_PERD3QN>), gridd, dim3(64 * kDenseTiles), 0, st, a);
-        } else {
-            if (kind == RL_D3QN) hipLaunchKernelGGL((k_policy1<RL_D3QN>), grid, dim3(64), 0, st, a);
-            else hipLaunchKernelGGL((k_policy1<RL_PERD3QN>), grid, dim3(64), 0, st, a);
-        }
-        const hipError_t e1 = hipGetLastError();
-        if (e1 != hipSuccess) { rl_set_error("policy kernel launch failed: %s", hipGetErrorString(e1)); return RL_E_LAUNCH; }
-        return RL_OK;
+    if (variant == RL_PV_DENSE) {
+        const dim3 gridd((grid.x + kDenseTiles - 1) / kDenseTiles, a.nb);
+        hipLaunchKernelGGL((k_policy_dense<RL_PERD3QN>), gridd, dim3(64 * kDenseTiles), 0, st, a);   // (D3QN and PERD3QN: one network)
+        return launch_check("policy kernel (dense)");
+    }
+    if (variant == RL_PV_WAVE) {
+        hipLaunchKernelGGL((k_policy1<RL_PERD3QN>), grid, dim3(64), 0, st, a);
+        return launch_check("policy kernel (wave)");
     }
     const bool deep = expected_rows / 32 <= 6 * 256;  // fewer than ~6 tiles per CU: latency-bound, deeper weight rings
 #define RL_LAUNCH(K) do { if (deep) hipLaunchKernelGGL((k_policy<K, true>), grid, block, 0, st, a); \
@@ -558,16 +570,15 @@ static int launch_policy(int kind, const PolicyArgs& a, int64_t max_rows, int64_
         default: rl_set_error("unknown brain kind %d", kind); return RL_E_INVALID;
     }
 #undef RL_LAUNCH
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { rl_set_error("policy kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
-    return RL_OK;
+    return launch_check("policy kernel (nsplit)");
 }
 
 int rl_policy_forward_impl(int kind, const float* packed, const float* obs, int64_t n_rows, float* out, hipStream_t st)
 {
+    if (kind < RL_DQN || kind > RL_PPO) { rl_set_error("unknown brain kind %d", kind); return RL_E_INVALID; }
     PolicyArgs a{};
     a.nb = 1; a.b[0].packed = packed; a.b[0].kind = kind; a.obs = obs; a.n_rows = n_rows; a.out = out; a.cap = 1;
-    return launch_policy(kind, a, n_rows, n_rows, st);
+    return launch_policy(resolve_variant(rl_options_current().policy_variant, kind_is_dueling(kind), n_rows), kind, a, n_rows, n_rows, st);
 }
 
 // work layout: int counts[2][64] (parity double buffer, zero-initialised once by the caller), then
@@ -625,24 +636,29 @@ int rl_policy_act_impl(rl_world* h, const rl_brain* brains, int n_brains, const 
         if (brains[b].kind < RL_DQN || brains[b].kind > RL_PPO) { rl_set_error("unknown brain kind %d", brains[b].kind); return RL_E_INVALID; }
         kinds |= 1u << canon(brains[b].kind);
     }
-    const char* variant = getenv("RL_POLICY_VARIANT");
-    if (variant && !strcmp(variant, "pair") && n_brains <= kMaxBrainsPerLaunch) {   // one launch, the tile code picked per workgroup
+    bool all_dueling = true;
+    for (int b = 0; b < n_brains; ++b) all_dueling = all_dueling && kind_is_dueling(brains[b].kind);
+    const int variant = resolve_variant(h->opt.policy_variant, all_dueling, expected);
+    if (variant != RL_PV_NSPLIT) {
+        // one arithmetic (see launch_policy): the tiles of rl_run's policy half, brains of any kinds side by side in a launch
         PolicyArgs a = base_args();
-        for (int b = 0; b < n_brains; ++b) a.b[a.nb++] = slot_of(b);
-        hipLaunchKernelGGL(k_policy_pair, dim3(policy_grid(bound), a.nb), dim3(128), kPairKernelLds, st, a);
-        const hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { rl_set_error("policy kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
+        for (int b = 0; b < n_brains; ++b) {
+            a.b[a.nb++] = slot_of(b);
+            if (a.nb == kMaxBrainsPerLaunch || b + 1 == n_brains) {
+                if (int rc = launch_policy(variant, RL_PERD3QN, a, bound, expected, st)) return rc;
+                a.nb = 0;
+            }
+        }
         return RL_OK;
     }
-    if ((kinds & (kinds - 1)) != 0 && n_brains <= kMaxBrainsPerLaunch && !getenv("RL_POLICY_PER_KIND")) {
+    // ---- nsplit (explicit option): the 4-wave tile of rounds 1-2
+    if ((kinds & (kinds - 1)) != 0 && n_brains <= kMaxBrainsPerLaunch && !h->opt.policy_per_kind) {
         // several kinds: ONE launch, the tile code picked per workgroup (k_policy_mixed)
         PolicyArgs a = base_args();
         for (int b = 0; b < n_brains; ++b) a.b[a.nb++] = slot_of(b);
         const dim3 grid(policy_grid(bound), a.nb), block(256);
         hipLaunchKernelGGL(k_policy_mixed, grid, block, 0, st, a);
-        const hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { rl_set_error("policy kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
-        return RL_OK;
+        return launch_check("policy kernel (nsplit, mixed kinds)");
     }
     for (int kind = RL_DQN; kind <= RL_PPO; ++kind) {
         if (kind == RL_D3QN) continue;   // (served by the PERD3QN pass)
@@ -651,11 +667,11 @@ int rl_policy_act_impl(rl_world* h, const rl_brain* brains, int n_brains, const 
             if (canon(brains[b].kind) != kind) continue;
             a.b[a.nb++] = slot_of(b);
             if (a.nb == kMaxBrainsPerLaunch) {
-                if (int rc = launch_policy(kind, a, bound, expected, st)) return rc;
+                if (int rc = launch_policy(RL_PV_NSPLIT, kind, a, bound, expected, st)) return rc;
                 a.nb = 0;
             }
         }
-        if (a.nb) if (int rc = launch_policy(kind, a, bound, expected, st)) return rc;
+        if (a.nb) if (int rc = launch_policy(RL_PV_NSPLIT, kind, a, bound, expected, st)) return rc;
     }
     return RL_OK;
 }

@@ -1070,11 +1070,10 @@ static int host_plane_stride(const rl_world* h, int T)
 }
 // Workgroup size of the multi-tick kernel: 512 threads for few worlds (the one-wave policy tile needs the 256-VGPR budget; the
 // tick half alone would prefer 1024: 10.6 vs 13.1 us at 256 worlds), 256 when there are many worlds (several per CU).
-// RL_WORLD_BLOCK overrides it like for the other world kernels.
+// The world_block option (rl_set_option / RL_WORLD_BLOCK at rl_create) overrides it like for the other world kernels.
 static int run_block(const rl_world* h)
 {
-    const char* env = getenv("RL_WORLD_BLOCK");
-    const int forced = env ? atoi(env) : 0;
+    const int forced = h->opt.world_block;
     if (forced == 256 || forced == 512 || forced == 1024) return forced;
     return h->cfg.n_worlds <= 768 ? 512 : 256;
 }
@@ -1117,7 +1116,7 @@ int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n
     const int kind = run_kind_of(brains, n_brains);
     rp.p.PS = kind == kKindAll ? host_plane_stride<kKindAll>(h, T) : host_plane_stride<RL_PERD3QN>(h, T);
     const size_t bytes = kind == kKindAll ? run_smem_bytes<kKindAll>(h, T, rp.p.PS) : run_smem_bytes<RL_PERD3QN>(h, T, rp.p.PS);
-    const bool fixed = p.W == kFixW && p.H == kFixH && rp.p.PS == run_plane_stride(T, kFixW, kFixH) && p.cap == kFixCap && p.hash_size == kFixHash && !getenv("RL_WORLD_GENERIC");
+    const bool fixed = p.W == kFixW && p.H == kFixH && rp.p.PS == run_plane_stride(T, kFixW, kFixH) && p.cap == kFixCap && p.hash_size == kFixHash && !h->opt.world_generic;
     const int train = (replays != nullptr || policy_out != nullptr) ? 2 : (eps_sched != nullptr || p.so.trk_tick != nullptr) ? 1 : 0;
     const void* fn = nullptr;
 #define RL_RUN_PICK(TT, FX, KD, TR) if (T == TT && fixed == FX && kind == KD && train == TR) fn = (const void*)k_run<TT, FX, KD, TR>;

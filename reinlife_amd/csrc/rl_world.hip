@@ -260,7 +260,7 @@ int launch_world_v(const rl_world* h, const KParams& p, hipStream_t stream)
     const int blk = pick_block(h);
     static const size_t fixed_bytes = rl_world_smem_bytes(kFixCp, kFixCap, kFixHash, kFixW, kFixH);  // inside the default 64 KB window
     const bool fixed = LEAN && MODE == MODE_TICK && p.W == kFixW && p.H == kFixH && p.cap == kFixCap && p.hash_size == kFixHash &&
-                       fixed_bytes <= 64 * 1024 && !getenv("RL_WORLD_GENERIC");  // (env: run the generic code -- tests, A/B)
+                       fixed_bytes <= 64 * 1024 && !h->opt.world_generic;  // (option: run the generic code -- tests, A/B)
     const dim3 grid(h->cfg.n_worlds);
     if (fixed) {
         if (blk == 1024) hipLaunchKernelGGL((k_world<1024, MODE_TICK, true, true>), grid, dim3(1024), fixed_bytes, stream, p);

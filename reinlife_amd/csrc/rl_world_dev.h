@@ -1719,8 +1719,7 @@ __device__ __forceinline__ int reset_world_lds(const KParams& p, Smem& s, int w,
 // (throughput-bound: several worlds per CU hide each other's barriers).
 inline int pick_block(const rl_world* h)
 {
-    const char* env = getenv("RL_WORLD_BLOCK");  // read at every launch (like RL_WORLD_GENERIC): tests and A/B runs switch it
-    const int forced = env ? atoi(env) : 0;
+    const int forced = h->opt.world_block;   // (rl_set_option / RL_WORLD_BLOCK at rl_create: tests and A/B runs)
     if (forced == 256 || forced == 512 || forced == 1024) return forced;
     return h->cfg.n_worlds <= 768 ? 1024 : 256;
 }

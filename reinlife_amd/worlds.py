@@ -5,7 +5,6 @@ Layout = `rl_state` (struct-of-arrays over worlds; a world's agent list is its o
 order, i.e. the reference's env.agents order -- World/grid.py:60-67).
 """
 import ctypes as C
-import os
 
 import numpy as np
 import torch
@@ -20,6 +19,12 @@ _STATE_SPEC = [  # name, torch dtype, shape suffix
     ("a_fitness", torch.float64, "cap"), ("max_gene", torch.int32, ""), ("next_uid", torch.int32, ""),
     ("tick", torch.int32, ""), ("epoch", torch.int32, ""), ("best_uid", torch.int32, "best"),
     ("best_fit", torch.float64, "best"), ("best_brain", torch.int32, "best")]
+
+
+# Pinned staging buffers for run()'s epsilon schedules, one small ring per device for the whole process: pinning a fresh buffer per
+# launch (or per Environment: trainer() builds a new one on every call) costs more than a short launch's kernel.  A slot is
+# [pinned host buffer, device buffer, event recorded behind the slot's last upload].
+_EPS_RING = {}
 
 
 def _ptr(t):
@@ -86,7 +91,6 @@ class DeviceWorlds:
         self._eps_keep = None
         self._capture_prob = False
         self._fused_key = self._fused = None
-        self._eps_ring, self._eps_slot = [], 0   # pinned staging of run()'s epsilon schedules (slot: host buffer, device buffer, copy-done event)
         self.launches = 0                        # kernel-launching C-ABI calls made by run() so far (bench.py reports it)
 
     def __del__(self):
@@ -289,11 +293,11 @@ class DeviceWorlds:
                 eps_schedule = eps_schedule.to(torch.float32).contiguous()
                 assert tuple(eps_schedule.shape) == (n_ticks, self.n_brains)
         # (with many worlds per GPU -- several per CU -- the two stand-alone launches are faster: 8.0e8 against 6.1e8 agent-steps/s
-        # at 1024 worlds, the cross-world policy tiles waste fewer rows; RL_RUN_ALWAYS=1 forces the single launch)
-        # (what the decision depends on: the brains' kinds -- set_brains() drops the cached answer -- and the two switches)
-        key = (os.environ.get("RL_WORLD_BLOCK"), os.environ.get("RL_RUN_ALWAYS"))
-        if self._fused_key != key:
-            self._fused_key, self._fused = key, self.run_supported() and (self.R <= 768 or bool(os.environ.get("RL_RUN_ALWAYS")))
+        # at 1024 worlds, the cross-world policy tiles waste fewer rows; the run_always option forces the single launch)
+        # (what the decision depends on: the brains' kinds -- set_brains() drops the cached answer -- and the handle's option snapshot)
+        if self._fused_key is None:
+            self._fused_key = True
+            self._fused = self.run_supported() and (self.R <= 768 or self.lib.rl_get_option(self.handle, b"run_always") == 1)
         fused = self._fused
         if not fused:
             if eps_schedule is not None and eps_host is None:
@@ -330,24 +334,24 @@ class DeviceWorlds:
         self._ticked = True
 
     def _stage_schedule(self, host):
-        """A host [n_ticks, n_brains] float32 schedule -> device, through a small ring of persistent pinned buffers (allocating and
-        pinning a fresh buffer per launch cost more than a short launch's kernel).  A slot is reused only once its previous
-        upload has executed (its event), and its device buffer only once the launch that read it has finished (stream order: the
-        next upload into it is queued behind that launch)."""
+        """A host [n_ticks, n_brains] float32 schedule -> device through the process-wide ring of pinned buffers (_EPS_RING).  A slot's
+        host buffer is rewritten only once its previous upload has executed (its event); its device buffer is rewritten by a copy
+        queued on this stream, i.e. behind the launch that read it when that launch was on this stream -- and eight further uploads
+        lie between two uses of a slot."""
         n = host.size
-        if len(self._eps_ring) < 4:
-            cap = max(4096, 1 << int(n - 1).bit_length())
+        ring = _EPS_RING.setdefault(str(self.device), {"slots": [], "next": 0})
+        if len(ring["slots"]) < 8:
+            cap = max(8192, 1 << int(n - 1).bit_length())
             slot = [torch.empty(cap, dtype=torch.float32).pin_memory(), torch.empty(cap, dtype=torch.float32, device=self.device),
                     torch.cuda.Event()]
-            self._eps_ring.append(slot)
+            ring["slots"].append(slot)
         else:
-            slot = self._eps_ring[self._eps_slot % 4]
-            self._eps_slot += 1
+            slot = ring["slots"][ring["next"] % 8]
+            ring["next"] += 1
+            slot[2].synchronize()
             if slot[0].numel() < n:
                 cap = 1 << int(n - 1).bit_length()
-                slot[2].synchronize()
                 slot[0], slot[1] = torch.empty(cap, dtype=torch.float32).pin_memory(), torch.empty(cap, dtype=torch.float32, device=self.device)
-            slot[2].synchronize()
         slot[0][:n].copy_(torch.from_numpy(host.reshape(-1)))
         dev = slot[1][:n]
         dev.copy_(slot[0][:n], non_blocking=True)

@@ -13,3 +13,18 @@ if TESTS not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture
+def hip_option():
+    """hip_option(name, value): a process-level option of the HIP library (rl_set_option; handles created afterwards snapshot it),
+    put back to what the environment says when the test ends."""
+    from reinlife_amd import _lib
+    touched = []
+
+    def set_(name, value):
+        touched.append(name)
+        _lib.set_option(name, value)
+    yield set_
+    for name in touched:
+        _lib.set_option(name, None)

@@ -173,3 +173,36 @@ def test_device_worlds_refuses_to_run_without_a_gpu():
     from reinlife_amd.worlds import DeviceWorlds
     with pytest.raises(_lib.ReinLifeHipError):
         DeviceWorlds(n_worlds=1)
+
+
+def test_options_are_process_level_snapshotted_by_handles_and_never_read_from_the_environment_later(monkeypatch):
+    """rl_set_option / rl_get_option (include/reinlife_hip.h "options"): values start from the environment once, a handle keeps the
+    snapshot rl_create took, unknown names / values are errors.  (No launch reads the environment: see `grep getenv csrc/`.)"""
+    from reinlife_amd import _lib
+    lib = _lib.lib()
+    get = lambda h, n: lib.rl_get_option(h, n.encode())  # noqa: E731
+    try:
+        assert get(None, "policy_variant") == 0 and get(None, "world_block") == 0      # auto: ONE arithmetic, block by world count
+        _lib.set_option("policy_variant", "nsplit"); _lib.set_option("world_block", 512)
+        monkeypatch.setenv("RL_WORLD_BLOCK", "256")                                     # later changes of the environment: not seen ...
+        cfg = _lib.Config(30, 30, 100, 2, 256, 4, 1, 0, 1, 0, 7)
+        h = C.c_void_p()
+        assert lib.rl_create(C.byref(cfg), C.byref(h)) == 0
+        assert (get(h, "policy_variant"), get(h, "world_block"), get(h, "world_generic"), get(h, "run_always")) == (1, 512, 0, 0)
+        _lib.set_option("policy_variant", "pair"); _lib.set_option("world_block", 1024); _lib.set_option("run_always", 1)
+        assert (get(h, "policy_variant"), get(h, "world_block"), get(h, "run_always")) == (1, 512, 0)   # the handle keeps its snapshot
+        assert (get(None, "policy_variant"), get(None, "world_block"), get(None, "run_always")) == (4, 1024, 1)
+        lib.rl_destroy(h)
+        _lib.set_option("world_block", None)                                            # ... until somebody asks for the environment's value
+        assert get(None, "world_block") == 256
+        for name, value in (("policy_variant", "fast"), ("world_block", "300"), ("no_such_option", "1")):
+            assert lib.rl_set_option(name.encode(), value.encode()) != 0 and lib.rl_last_error()
+        assert get(None, "no_such_option") == -1
+    finally:
+        monkeypatch.delenv("RL_WORLD_BLOCK", raising=False)
+        for name in ("policy_variant", "world_block", "world_generic", "policy_per_kind", "run_always"):
+            _lib.set_option(name, None)
+    assert get(None, "policy_variant") == 0 and get(None, "world_block") == 0
+    src = os.path.join(ROOT, "reinlife_amd", "csrc")
+    users = [f for f in sorted(os.listdir(src)) if "getenv(" in open(os.path.join(src, f)).read()]
+    assert users == ["rl_capi.hip"], users   # the one place that reads the environment: options_from_env

@@ -118,16 +118,16 @@ def test_hip_fused_tick_refill_matches_oracle():
 @pytest.mark.parametrize("static,limit,incentive", [(True, False, True), (False, False, True), (True, True, True), (False, True, False)],
                          ids=["static", "nonstatic", "static-limit", "nonstatic-limit-noincentive"])
 @pytest.mark.parametrize("generic", [False, True], ids=["specialised", "generic"])
-def test_hip_lean_tick_matches_oracle(static, limit, incentive, generic, monkeypatch):
+def test_hip_lean_tick_matches_oracle(static, limit, incentive, generic, hip_option):
     """The launch bench.py times: the lean fused tick (no tape, no tracker, no capture outputs) on the reference's default
     30x30 / 100-agent shape -- the shape-specialised kernel and, with RL_WORLD_GENERIC set, the generic code for the same
     worlds -- against the oracle: state, rewards, done flags, both permutations and both observation passes, every tick."""
     from oracle import oracle as orc
     from reinlife_amd.worlds import DeviceWorlds
     if generic:
-        monkeypatch.setenv("RL_WORLD_GENERIC", "1")   # read by the library at every launch
+        hip_option("world_generic", 1)   # read by the library at every launch
     else:
-        monkeypatch.delenv("RL_WORLD_GENERIC", raising=False)
+        hip_option("world_generic", 0)
     R = 32
     cfg = dict(width=30, height=30, max_agents=100, n_brains=2, static_families=static, limit_reproduction=limit,
                incentivize_killing=incentive)

@@ -44,14 +44,14 @@ def _cmp_rows(got, want, n, tag):
 @pytest.mark.parametrize("block", [256, 512, 1024])
 @pytest.mark.parametrize("generic", [False, True], ids=["specialised", "generic"])
 @pytest.mark.parametrize("static", [True, False], ids=["static", "nonstatic"])
-def test_lean_tick_every_block_size(block, generic, static, monkeypatch):
+def test_lean_tick_every_block_size(block, generic, static, hip_option):
     from oracle import oracle as orc
     from reinlife_amd.worlds import DeviceWorlds
-    monkeypatch.setenv("RL_WORLD_BLOCK", str(block))   # read by the library at every launch
+    hip_option("world_block", block)   # read by the library at every launch
     if generic:
-        monkeypatch.setenv("RL_WORLD_GENERIC", "1")
+        hip_option("world_generic", 1)
     else:
-        monkeypatch.delenv("RL_WORLD_GENERIC", raising=False)
+        hip_option("world_generic", 0)
     R = 24
     cfg = dict(width=30, height=30, max_agents=100, n_brains=2, static_families=static, limit_reproduction=False, incentivize_killing=True)
     dw = DeviceWorlds(n_worlds=R, seed=4711, world_base=7, **cfg)
@@ -85,11 +85,11 @@ def test_lean_tick_every_block_size(block, generic, static, monkeypatch):
 
 
 @pytest.mark.parametrize("block", [256, 512])
-def test_split_step_update_every_block_size(block, monkeypatch):
+def test_split_step_update_every_block_size(block, hip_option):
     """The non-lean kernels (step / update with tracker outputs) at the small block sizes."""
     from hip_backend import HipBackend
     from oracle import oracle as orc
-    monkeypatch.setenv("RL_WORLD_BLOCK", str(block))
+    hip_option("world_block", block)
     R = 12
     cfg = dict(width=30, height=30, max_agents=100, n_brains=3, static_families=True, limit_reproduction=True, incentivize_killing=True)
     hb = HipBackend(R, seed=99, **cfg)
@@ -404,15 +404,16 @@ def _same_device_state(a, b, tag):
 
 @pytest.mark.parametrize("static", [True, False], ids=["static", "nonstatic"])
 @pytest.mark.parametrize("block", [None, 256, 1024], ids=["T512", "T256", "T1024"])
-def test_multi_tick_launch_equals_the_two_launch_loop(static, block, monkeypatch):
+def test_multi_tick_launch_equals_the_two_launch_loop(static, block, hip_option):
     """rl_run(n) == n x (rl_policy_act + rl_tick_refill): world state, both observation buffers, the last tick's outputs and
     actions, the counters -- for chunks of 1, 2, 7 and 30 ticks (odd and even: the Agent.state ping-pong), with refills."""
     if block:
-        monkeypatch.setenv("RL_WORLD_BLOCK", str(block))
+        hip_option("world_block", block)
     # rl_run's workgroups run the one-wave policy tile (policy_tile1); the stand-alone launch uses it too when asked to, and
     # then the two paths must agree bit for bit (with its default 4-wave tile they agree to ~1e-7 in Q, like any two float32
     # summation orders)
-    monkeypatch.setenv("RL_POLICY_VARIANT", "wave" if block != 1024 else "nsplit")
+    if block == 1024:   # k_run<1024> runs the 4-wave tile of rounds 1-2: its stand-alone counterpart is the `nsplit` variant
+        hip_option("policy_variant", "nsplit")
     (fused, loop), *_ = _run_pair(20, static, 555)
     assert fused.run_supported()
     done = 0
@@ -463,12 +464,12 @@ def test_multi_tick_launch_tracks_the_oracle_tick_by_tick():
         _cmp_rows(fused.obs_state().cpu().numpy(), ow.obs2, ow.s["n_agents"], "tick %d obs2" % t)
 
 
-def test_multi_tick_launch_falls_back_when_unsupported(monkeypatch):
+def test_multi_tick_launch_falls_back_when_unsupported(hip_option):
     """Mixed-kind brains at a workgroup size other than 512 threads (or capture outputs) are outside rl_run's scope: DeviceWorlds.run
     loops over the two launches instead."""
     from reinlife_amd import _lib
     from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights
-    monkeypatch.setenv("RL_WORLD_BLOCK", "256")
+    hip_option("world_block", 256)
     cfg = dict(width=30, height=30, max_agents=100, n_brains=2, static_families=True)
     pair = []
     for _ in range(2):
@@ -486,15 +487,16 @@ def test_multi_tick_launch_falls_back_when_unsupported(monkeypatch):
 @pytest.mark.parametrize("width,height,max_agents,n_new,thr,limit", [(20, 15, 60, 50, 40, False), (30, 30, 100, 100, 70, True), (12, 9, 20, 18, 12, False)],
                          ids=["20x15", "30x30-limit_reproduction", "12x9"])
 @pytest.mark.parametrize("block", [None, 256, 1024], ids=["T512", "T256", "T1024"])
-def test_multi_tick_launch_other_shapes_and_the_sequential_update(width, height, max_agents, n_new, thr, limit, block, monkeypatch):
+def test_multi_tick_launch_other_shapes_and_the_sequential_update(width, height, max_agents, n_new, thr, limit, block, hip_option):
     """k_run's generic (not shape-specialised) instantiations and the limit_reproduction path (update_env not overlapped with the
     observation pass), at every workgroup size, against the two-launch loop AND the oracle."""
     from oracle import oracle as orc
     from reinlife_amd import _lib
     from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights
     if block:
-        monkeypatch.setenv("RL_WORLD_BLOCK", str(block))
-    monkeypatch.setenv("RL_POLICY_VARIANT", "wave" if block != 1024 else "nsplit")
+        hip_option("world_block", block)
+    if block == 1024:   # k_run<1024> runs the 4-wave tile of rounds 1-2: its stand-alone counterpart is the `nsplit` variant
+        hip_option("policy_variant", "nsplit")
     R = 10
     cfg = dict(width=width, height=height, max_agents=max_agents, n_brains=2, static_families=True, limit_reproduction=limit, incentivize_killing=True)
     wts = [_weights("PERD3QN", 7), _weights("D3QN", 8)]
@@ -529,8 +531,8 @@ def test_multi_tick_launch_other_shapes_and_the_sequential_update(width, height,
 # dense policy launches: four one-wave tiles per workgroup, weights through LDS (k_policy_dense)
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("kind_name", ["PERD3QN", "D3QN"])
-def test_dense_policy_kernel_is_the_one_wave_tile_bit_for_bit(kind_name, monkeypatch):
-    """RL_POLICY_VARIANT=dense against =wave (the same arithmetic per row) for ragged row counts, the automatic choice above
+def test_dense_policy_kernel_is_the_one_wave_tile_bit_for_bit(kind_name, hip_option):
+    """policy_variant "dense" against "wave" and the default (the same arithmetic per row) for ragged row counts, the automatic choice above
     1,536 tiles, and the f32 oracle forward (1e-5) on a sample."""
     import torch
     from oracle import oracle as orc
@@ -545,14 +547,15 @@ def test_dense_policy_kernel_is_the_one_wave_tile_bit_for_bit(kind_name, monkeyp
         outs = {}
         for v in ("wave", "dense", None):
             if v is None:
-                monkeypatch.delenv("RL_POLICY_VARIANT", raising=False)
+                hip_option("policy_variant", "auto")
             else:
-                monkeypatch.setenv("RL_POLICY_VARIANT", v)
+                hip_option("policy_variant", v)
             out = torch.full((n, 8), float("nan"), device="cuda:0")
             policy_forward(kind, packed, obs, out)
             torch.cuda.synchronize()
             outs[v] = out.cpu().numpy()
         assert np.array_equal(outs["wave"], outs["dense"]), n
+        assert np.array_equal(outs[None], outs["wave"]), "the default launch (pair tiles, or dense from 1,536 tiles on) is the same arithmetic"
         if n >= 1536 * 32:
             assert np.array_equal(outs[None], outs["dense"]), "the dense kernel is the default from 1,536 tiles on"
         sub = slice(max(0, n - 300), n)
@@ -560,7 +563,7 @@ def test_dense_policy_kernel_is_the_one_wave_tile_bit_for_bit(kind_name, monkeyp
         np.testing.assert_allclose(outs["dense"][sub], want, rtol=0, atol=1e-5)
 
 
-def test_dense_policy_kernel_through_the_row_lists_with_draws(monkeypatch):
+def test_dense_policy_kernel_through_the_row_lists_with_draws(hip_option):
     """rl_policy_act over 832 worlds of two PERD3QN brains (one of them epsilon-greedy: the Philox draw per row): the launch picks the
     dense kernel by itself; actions and Q values equal the one-wave tile's."""
     import torch
@@ -570,9 +573,9 @@ def test_dense_policy_kernel_through_the_row_lists_with_draws(monkeypatch):
     res = {}
     for v in ("wave", None):
         if v is None:
-            monkeypatch.delenv("RL_POLICY_VARIANT", raising=False)
+            hip_option("policy_variant", "auto")
         else:
-            monkeypatch.setenv("RL_POLICY_VARIANT", v)
+            hip_option("policy_variant", v)
         dw = DeviceWorlds(n_worlds=832, seed=21, **cfg)
         dw.set_brains([(_lib.PERD3QN, eps, pack_brain_weights(_lib.PERD3QN, _weights("PERD3QN", 40 + k))) for k, eps in enumerate((0.0, 0.3))])
         dw.reset_synthetic(100)
@@ -593,13 +596,12 @@ def test_dense_policy_kernel_through_the_row_lists_with_draws(monkeypatch):
 
 @pytest.mark.parametrize("n_brains,max_agents,n_new,thr", [(1, 100, 100, 70), (3, 100, 100, 70), (8, 100, 100, 70), (2, 200, 190, 120)],
                          ids=["1brain", "3brains", "8brains", "crowded-200"])
-def test_multi_tick_launch_brain_counts_and_crowded_worlds(n_brains, max_agents, n_new, thr, monkeypatch):
+def test_multi_tick_launch_brain_counts_and_crowded_worlds(n_brains, max_agents, n_new, thr):
     """rl_run == the two-launch loop for 1 / 3 / 8 brains (1-8 tiles per world: two waves per tile up to four tiles, one wave per tile
     above) and for worlds of up to 200+ agents (slot capacity 448, more than 128 rows per world), half of the brains epsilon-greedy."""
     import torch
     from reinlife_amd import _lib
     from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights
-    monkeypatch.setenv("RL_POLICY_VARIANT", "wave")
     cfg = dict(width=30, height=30, max_agents=max_agents, n_brains=n_brains, static_families=True, limit_reproduction=False, incentivize_killing=True)
     names = ["PERD3QN" if b % 2 == 0 else "D3QN" for b in range(n_brains)]
     wts = [_weights(n, 700 + k) for k, n in enumerate(names)]

@@ -25,13 +25,14 @@ def _same_tracker(a, b, tag):
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("static", [True, False], ids=["static", "nonstatic"])
 @pytest.mark.parametrize("block", [None, 256, 1024], ids=["T512", "T256", "T1024"])
-def test_training_launch_equals_the_two_launch_loop(static, block, monkeypatch):
+def test_training_launch_equals_the_two_launch_loop(static, block, hip_option):
     """rl_run_ex with a per-tick epsilon schedule and the Tracker accumulators == n x (set epsilons, rl_policy_act, rl_tick_refill
     with the Tracker outputs): worlds, observations, actions and trk_tick / trk_sum / trk_cnt / trk_pop, bit for bit, over launches
     of 1 / 3 / 20 / 37 ticks, with the caller zeroing the running sums between some of them (interval boundaries)."""
     if block:
-        monkeypatch.setenv("RL_WORLD_BLOCK", str(block))
-    monkeypatch.setenv("RL_POLICY_VARIANT", "wave" if block != 1024 else "nsplit")
+        hip_option("world_block", block)
+    if block == 1024:   # k_run<1024> runs the 4-wave tile of rounds 1-2: its stand-alone counterpart is the `nsplit` variant
+        hip_option("policy_variant", "nsplit")
     (fused, loop), *_ = _run_pair(14, static, 4242)
     for dw in (fused, loop):
         dw.enable_tracking(True)
@@ -87,12 +88,11 @@ def _brains(seed, training=True):
 
 
 @pytest.mark.parametrize("static", [True, False], ids=["static", "nonstatic"])
-def test_trainer_fused_loop_equals_the_tick_by_tick_loop(static, monkeypatch):
+def test_trainer_fused_loop_equals_the_tick_by_tick_loop(static):
     """trainer(..., fused=True) -- whole Tracker intervals per launch -- against fused=False (act / step / update_env launches and a
     host round trip per tick, the round-2 loop): identical Tracker.results, identical final worlds, identical brain epsilons.
     training=True: the brains' epsilon decays per episode (x 0.99), i.e. the launch runs on a schedule."""
     from reinlife_amd.Helpers.trainer import trainer
-    monkeypatch.setenv("RL_POLICY_VARIANT", "wave")   # the stand-alone policy launch with rl_run's tile arithmetic
     proto = _brains(5)
     envs = []
     for fused in (True, False):
@@ -303,8 +303,8 @@ def test_c2_step_only_twenty_seeds_two_hundred_ticks_against_the_oracle():
 # the multi-tick launch for brains of ANY kind (DQN, PPO, mixed): two waves per tile, the tile code picked per tile
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("kind_name", ["DQN", "PPO", "D3QN", "PERD3QN"])
-def test_pair_tiles_against_the_oracle_forward(kind_name, monkeypatch):
-    """RL_POLICY_VARIANT=pair (k_policy_pair: the two-waves-per-tile code rl_run's policy half runs, for every kind) against the oracle's
+def test_pair_tiles_against_the_oracle_forward(kind_name, hip_option):
+    """policy_variant "pair" (k_policy_pair: the two-waves-per-tile code rl_run's policy half runs, for every kind) against the oracle's
     f32 forward (1e-5) for ragged row counts; for the dueling kinds the pair IS the one-wave tile bit for bit."""
     import torch
     from oracle import oracle as orc
@@ -316,7 +316,7 @@ def test_pair_tiles_against_the_oracle_forward(kind_name, monkeypatch):
     g = torch.Generator(device="cuda:0").manual_seed(17)
     for n in (1, 31, 33, 257, 4099):
         obs = (torch.randn(n + 1, 153, device="cuda:0", generator=g) * torch.rand(n + 1, 1, device="cuda:0", generator=g) * 3)[:n].contiguous()
-        monkeypatch.setenv("RL_POLICY_VARIANT", "pair")
+        hip_option("policy_variant", "pair")
         out = torch.full((n, 8), float("nan"), device="cuda:0")
         policy_forward(kind, packed, obs, out)
         torch.cuda.synchronize()
@@ -324,7 +324,7 @@ def test_pair_tiles_against_the_oracle_forward(kind_name, monkeypatch):
         want = orc.policy_forward(orc.KIND_BY_NAME[kind_name], w, obs.cpu().numpy())
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-5, err_msg="%s n=%d" % (kind_name, n))
         if kind_name in ("D3QN", "PERD3QN"):
-            monkeypatch.setenv("RL_POLICY_VARIANT", "wave")
+            hip_option("policy_variant", "wave")
             ref = torch.full((n, 8), float("nan"), device="cuda:0")
             policy_forward(kind, packed, obs, ref)
             torch.cuda.synchronize()
@@ -353,11 +353,10 @@ KIND_SETS = [(("DQN",), (0.0,), True), (("DQN", "DQN"), (0.0, 0.2), True), (("PP
 
 
 @pytest.mark.parametrize("names,eps,static", KIND_SETS, ids=["+".join(k[0]) for k in KIND_SETS])
-def test_multi_tick_launch_any_brain_kinds_equals_the_two_launch_loop(names, eps, static, monkeypatch):
+def test_multi_tick_launch_any_brain_kinds_equals_the_two_launch_loop(names, eps, static):
     """rl_run with DQN / PPO / mixed-kind brains (the kKindAll kernel: per tile two waves running its kind's code, the waves dealt over
-    the SIMDs by cost) == n x (rl_policy_act + rl_tick_refill) with the same tiles as a stand-alone launch (RL_POLICY_VARIANT=pair):
+    the SIMDs by cost) == n x (rl_policy_act + rl_tick_refill) with the stand-alone launch (which runs the same tiles by default):
     worlds, observations, actions (PPO: the sampled ones), outputs, counters, for launches of 1 / 2 / 7 / 30 / 45 ticks with refills."""
-    monkeypatch.setenv("RL_POLICY_VARIANT", "pair")
     (fused, loop), wts, cfg = _kind_pair(names, eps, 14, static, 2026)
     assert fused.run_supported()
     done = 0
@@ -418,13 +417,12 @@ def test_multi_tick_launch_mixed_kinds_tracks_the_oracle_with_tracker_and_schedu
     assert checked > 1000
 
 
-def test_multi_tick_launch_many_tiles_take_several_rounds(monkeypatch):
+def test_multi_tick_launch_many_tiles_take_several_rounds():
     """Eight brains of all four kinds: every world has more than four tiles, so the kKindAll kernel runs the tiles in rounds (fixed wave
     pairs, 32 KB exchange buffer per slot, rows from memory) -- the same tiles, the same bits as the stand-alone pair launch; plus a
     crowded configuration (200 agents: slot capacity 448, a smaller mirror)."""
     names = ("DQN", "PPO", "D3QN", "PERD3QN", "PPO", "DQN", "PERD3QN", "D3QN")
     eps = (0.1, 0.0, 0.0, 0.2, 0.0, 0.0, 0.0, 0.0)
-    monkeypatch.setenv("RL_POLICY_VARIANT", "pair")
     for extra, thr in ((dict(), 70), (dict(max_agents=200), 120)):
         (fused, loop), wts, cfg = _kind_pair(names, eps, 10, True, 77, **extra)
         assert fused.run_supported()
@@ -456,14 +454,15 @@ def _ring_rows(dw, b, lo, hi):
 @pytest.mark.parametrize("names,eps,static,block", [(("PERD3QN", "D3QN"), (0.0, 0.15), True, None), (("PPO", "PERD3QN"), (0.0, 0.05), False, None),
                                                     (("PERD3QN", "D3QN"), (0.0, 0.15), False, 256), (("D3QN", "PERD3QN"), (0.1, 0.0), True, 1024)],
                          ids=["dueling", "PPO+PERD3QN", "dueling-T256", "dueling-T1024"])
-def test_capture_inside_the_multi_tick_launch(names, eps, static, block, monkeypatch):
+def test_capture_inside_the_multi_tick_launch(names, eps, static, block, hip_option):
     """DeviceWorlds.enable_capture + run(k): the launch appends every tick's transitions (state the policy read, action, reward,
     state_prime, done, age, the taken action's policy output) to the brains' rings -- the same transitions rl_capture_transitions stores
     after each stand-alone tick (trainer.py:95-96 / entities.py:194-208: agents of the post-step list with age > 1).  Within a tick the
     worlds' transitions interleave by atomics in both paths, so a tick's transitions are compared as sets; counts and worlds exactly."""
     if block:
-        monkeypatch.setenv("RL_WORLD_BLOCK", str(block))
-    monkeypatch.setenv("RL_POLICY_VARIANT", "pair" if block is None else ("wave" if block == 256 else "nsplit"))
+        hip_option("world_block", block)
+    if block == 1024:
+        hip_option("policy_variant", "nsplit")
     (fused, loop), wts, cfg = _kind_pair(names, eps, 9, static, 31)
     for dw in (fused, loop):
         dw.enable_capture(capacity=40_000, with_prob=True)

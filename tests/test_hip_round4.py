@@ -130,6 +130,46 @@ def test_c5_trainer_instantiation_one_launch_equals_many():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# one arithmetic on every path: a replica's trajectory does not depend on how many worlds share its GPU
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("workload", ["c4", "c5"])
+def test_one_handle_of_1024_worlds_equals_four_handles_of_256(workload):
+    """1 x 1,024 worlds (above 768 worlds per handle DeviceWorlds.run loops over rl_policy_act + rl_tick_refill: the stand-alone policy
+    kernel, 256-thread world kernels) against 4 x 256 worlds with world_base 0 / 256 / 512 / 768 (the multi-tick launch): 60
+    policy-driven ticks with refills, identical worlds, observations AND actions -- the stand-alone policy kernels run the tiles of
+    rl_run's policy half (DQN.py:126-139, D3QN.py:161-173, PPO.py:164-169 in one summation order everywhere), no option set."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    def make(n, base):
+        return bench.make_worlds(argparse.Namespace(worlds=256, workload=workload, seed=SEED), 0, "cuda:0", n_worlds=n, world_base=base)
+    big = make(1024, 0)
+    parts = [make(256, 256 * q) for q in range(4)]
+    for chunk in (1, 29, 30):
+        big.run(chunk, 70, 100)
+        for part in parts:
+            part.run(chunk, 70, 100)
+        big.check_error_flag()
+        for q, part in enumerate(parts):
+            part.check_error_flag()
+            sl = slice(256 * q, 256 * (q + 1))
+            n = part.s["n_agents"].cpu().numpy()
+            for key in part.s:
+                got, want = big.s[key][sl].cpu().numpy(), part.s[key].cpu().numpy()
+                if key.startswith("a_"):
+                    _cmp_rows(got, want, n, "%s part %d %s" % (workload, q, key))
+                else:
+                    assert np.array_equal(got, want), (workload, q, key)
+            _cmp_rows(big.obs_state()[sl].cpu().numpy(), part.obs_state().cpu().numpy(), n, "obs2 part %d" % q)
+            acted = part.n_acted.cpu().numpy()
+            assert np.array_equal(big.n_acted[sl].cpu().numpy(), acted)
+            _cmp_rows(big.actions[sl].cpu().numpy(), part.actions.cpu().numpy(), acted, "actions part %d" % q)
+    assert not big._fused and all(p._fused for p in parts)
+    assert int(big.acted_total.item()) == sum(int(p.acted_total.item()) for p in parts) > 4_000_000
+    assert int(big.refill_count.item()) == sum(int(p.refill_count.item()) for p in parts) > 100
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # replica sharding through the API on the GPU: the Tracker's collective over RCCL (world size 1), world_base from the rank
 # ---------------------------------------------------------------------------------------------------------------------
 def test_trainer_under_a_process_group_shards_by_rank_and_reduces_its_tracker_over_rccl():
@@ -166,7 +206,7 @@ if use_dist:
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         out = subprocess.run([sys.executable, "-c", code, mode], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
-        outs[mode] = json.loads(out.stdout.strip().splitlines()[-1])
+        outs[mode] = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])   # (RCCL prints its banner at exit)
     p, d = outs["plain"], outs["dist"]
     assert not p["has_dist"] and p["collectives"] == 0
     assert d["has_dist"] and d["collectives"] == 3 and d["rank"] == 0 and d["base"] == 0 and d["device"] == "cuda:0"
