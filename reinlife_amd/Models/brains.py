@@ -61,8 +61,13 @@ class _HipBrain(BasicBrain):
         """Packed MFMA layout of the current parameters on `device`, cached.  The cache key carries every parameter's storage
         address and in-place version counter, so load_state_dict(), optimizer steps, target/eval syncs or a replaced module
         repack automatically at the next use."""
-        net = self._net()   # (parameters() + buffers(), not state_dict(): no per-call detach of every tensor -- this runs once per launch)
-        key = (str(device), id(net)) + tuple((p.data_ptr(), p._version) for p in net.parameters()) + tuple((b.data_ptr(), b._version) for b in net.buffers())
+        net = self._net()
+        # (the module's tensors are listed once per module object: walking parameters() / buffers() through nn.Module's generators on
+        # every call cost 50 us per brain -- more than a short launch's whole host side; in-place updates bump _version, a replaced
+        # module has another id, and a parameter swapped for a new tensor object calls for invalidate())
+        if getattr(self, "_tensors_of", None) != id(net):
+            self._tensors, self._tensors_of = list(net.parameters()) + list(net.buffers()), id(net)
+        key = (str(device), id(net)) + tuple((t.data_ptr(), t._version) for t in self._tensors)
         if getattr(self, "_packed_key", None) != key:
             from ..worlds import pack_brain_weights
             self._packed = pack_brain_weights(self.kind, self.state_dict_flat(), device)
@@ -70,7 +75,7 @@ class _HipBrain(BasicBrain):
         return self._packed
 
     def invalidate(self):
-        self._packed_key = None
+        self._packed_key = self._tensors_of = None
 
     def forward_batch(self, states, device="cuda:0"):
         """[n,153] observations -> [n,8] Q values / probabilities on the GPU."""

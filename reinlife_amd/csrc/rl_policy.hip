@@ -205,21 +205,32 @@ __global__ __launch_bounds__(64 * kDenseTiles, 2) void k_policy_dense(const Poli
     policy_tile1ds<KIND>(io, lane, ws, lds_c);
 }
 
-// RL_POLICY_VARIANT=pair: TWO waves per 32-row tile -- policy_tile1s<PAIR> for the dueling kinds, policy_pair2 for DQN / PPO: the
-// tiles (and the arithmetic) of the multi-tick kernel's policy half, as a stand-alone launch for brains of any kinds: what rl_run is
-// compared with bit for bit, and the tiles' own check against the oracle.  128-thread workgroup per (tile, brain); dynamic LDS:
-// [the brain's constants kTileConstMax | partial row maxima 128 | role 1's head partials 256 | exchange buffer 32 KB].
-constexpr int kPairKernelLds = (kTileConstMax + 128 + kPairValFloats) * 4 + 16 * kPlanes * 64 * 16;
-__global__ __launch_bounds__(128) void k_policy_pair(const PolicyArgs A)
+// policy_variant "pair" (the default stand-alone launch): TWO waves per 32-row tile -- policy_tile1s<PAIR> for the dueling kinds,
+// policy_pair2 for DQN / PPO: the tiles (and the arithmetic) of the multi-tick kernel's policy half, for brains of any kinds.
+// A workgroup is what k_run's policy half is: kPairTiles tiles of ONE brain on 2 * kPairTiles waves, tile t on waves t and t + kPairTiles --
+// for four tiles the two roles of a tile share a SIMD (waves i and i + 4 do: tools/ubench/simd_map.hip), which is what the pair was
+// scheduled for: a role alone on its SIMD issues a VALU instruction every 8 cycles, two fill each other's waits.  With
+// one tile per 128-thread workgroup (round 3) the roles sat on different SIMDs: 25.4 us per launch at 256 worlds, 4.6 us behind the
+// 4-wave tile.  Grid = (groups of kPairTiles tiles a brain can have at most, brains).  Dynamic LDS:
+// [the brain's constants kTileConstMax | per tile: partial row maxima 128, role 1's head partials 256 | per tile: exchange buffer].
+#ifndef RL_PAIR_TILES
+#define RL_PAIR_TILES 4
+#endif
+constexpr int kPairStageStride = 164, kPairStageBytes = 32 * kPairStageStride * 4;   // the tile's 32 staged observation rows (20.5 KB)
+constexpr int kPairTiles = RL_PAIR_TILES;
+__host__ __device__ constexpr int pair_kernel_lds(int ex_bytes) { return (kTileConstMax + kPairTiles * (128 + kPairValFloats)) * 4 + kPairTiles * ex_bytes; }
+__global__ __launch_bounds__(128 * kPairTiles) void k_policy_pair(const PolicyArgs A, const int ex_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) char rl_dyn_lds[];
     float* lds_c = (float*)rl_dyn_lds;
-    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, role = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = wave % kPairTiles, role = wave / kPairTiles;
     typedef const int __attribute__((address_space(4))) cint;
-    const int bi = blockIdx.y, tile = blockIdx.x;
+    const int bi = blockIdx.y, tile = blockIdx.x * kPairTiles + slot;
     const BrainSlot B = A.b[bi];
     const int n = B.count_ptr ? ((cint*)B.count_ptr)[0] : (int)A.n_rows;
-    if (tile * 32 >= n) return;   // (uniform: the whole workgroup)
+    if ((int64_t)blockIdx.x * kPairTiles * 32 >= n) return;   // (uniform: the whole workgroup)
+    const bool have = tile * 32 < n;                           // (uniform per wave; a wave without a tile still meets the barriers)
     const int li = tile * 32 + j, lic = min(li, n - 1);
     const int entry = B.rowlist ? B.rowlist[lic] : 0;
     const int e_w = rl_list_world(entry), e_k = rl_list_slot(entry);
@@ -239,19 +250,49 @@ __global__ __launch_bounds__(128) void k_policy_pair(const PolicyArgs A)
     io.prof = nullptr;
 #endif
     const int kind = B.kind;
+    PairLds pl;
+    pl.pmax = lds_c + kTileConstMax + slot * (128 + kPairValFloats); pl.val = pl.pmax + 128;
+    pl.ex = (f32x4*)((char*)(lds_c + kTileConstMax + kPairTiles * (128 + kPairValFloats)) + (size_t)slot * ex_bytes);
     {
-        gfloat* pk = (gfloat*)B.packed;
-        for (int i = tid; i < tile_const_floats(kind); i += 128) lds_c[i] = pk[tile_const_src(kind, i)];
+        // The tile's 32 observation rows, staged through LDS: wave `role` fetches rows 16 role .. 16 role + 15 with ONE coalesced 612-byte
+        // read per row (lane m: floats 4m .. 4m+3; lane 38: the last float) -- read straight into B-operand order, as the tile does with
+        // rows that are not mirrored, every 16-byte load instruction touches 32 different rows (64 cache lines), twice over for the two
+        // roles.  The rows lie where the pair's exchange buffer will be (dead once both roles have read them: the first barrier inside
+        // the tile), 164 floats apart like k_run's mirror.
+        constexpr int kStride = kPairStageStride;   // (ex_bytes >= kPairStageBytes: the launcher sizes the slots)
+        float* stage = (float*)pl.ex;
+        const int lo = (int)(io.row & 0xffffffff), hi = (int)(io.row >> 32);
+        const int off = lane < 38 ? 4 * lane : 149;   // (every lane loads: lanes >= 38 read floats 149..152, inside the row)
+        f32x4 val[16];
+        if (have) {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int jj = 16 * role + rr;
+                const int64_t r = ((int64_t)__builtin_amdgcn_readlane(hi, jj) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, jj);
+                val[rr] = *(const f32x4u*)(A.obs + r * RL_OBS_DIM + off);
+            }
+        }
+        gfloat* pk = (gfloat*)B.packed;   // (the brain's epilogue / head constants meanwhile)
+        for (int i = tid; i < tile_const_floats(kind); i += 128 * kPairTiles) lds_c[i] = pk[tile_const_src(kind, i)];
+        if (have) {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                float* dst = stage + (16 * role + rr) * kStride;
+                if (lane < 38) *(f32x4*)(dst + 4 * lane) = val[rr];
+                else if (lane == 38) dst[152] = val[rr].w;
+            }
+        }
+        io.x_lds_off = (int)((char*)(stage + j * kStride) - rl_dyn_lds);
     }
     lds_barrier();
-    PairLds pl;
-    pl.pmax = lds_c + kTileConstMax; pl.val = pl.pmax + 128; pl.ex = (f32x4*)(pl.val + kPairValFloats);
     Tile1Part part;
-    if (kind == RL_DQN) policy_pair2<RL_DQN, false>(io, lane, role, &pl, &part);
-    else if (kind == RL_PPO) policy_pair2<RL_PPO, false>(io, lane, role, &pl, &part);
-    else policy_tile1s<RL_PERD3QN, false, true>(io, lane, role, &pl, &part);
+    if (have) {
+        if (kind == RL_DQN) policy_pair2<RL_DQN, false>(io, lane, role, &pl, &part);
+        else if (kind == RL_PPO) policy_pair2<RL_PPO, false>(io, lane, role, &pl, &part);
+        else policy_tile1s<RL_PERD3QN, false, true>(io, lane, role, &pl, &part);
+    } else { lds_barrier(); lds_barrier(); }   // (the two exchanges inside a tile)
     lds_barrier();
-    if (role == 0) {
+    if (have && role == 0) {
         if (kind == RL_DQN) pair_finish<RL_DQN>(io, lane, part, &pl);
         else if (kind == RL_PPO) pair_finish<RL_PPO>(io, lane, part, &pl);
         else tile1_finish<RL_PERD3QN>(io, lane, part.head, pl.val[j], part.draw, *(const f32x4*)(lds_c + 768 + 8 + 4 * (lane >> 5)));
@@ -547,7 +588,21 @@ static int launch_policy(int variant, int kind, const PolicyArgs& a, int64_t max
     // Brain-fastest order (all real tiles dispatched first) is SLOWER: 21.6 vs 18.4 us.
     const dim3 grid(policy_grid(max_rows), a.nb), block(256);
     if (variant == RL_PV_PAIR) {
-        hipLaunchKernelGGL(k_policy_pair, grid, dim3(128), kPairKernelLds, st, a);
+        int ex_bytes = kPairStageBytes;   // per tile: the staged rows (20.5 KB), then the exchange buffer of the widest kind (16 KB; PPO: 32 KB)
+        for (int b = 0; b < a.nb; ++b) ex_bytes = ex_bytes > pair_ex_bytes(a.b[b].kind) ? ex_bytes : pair_ex_bytes(a.b[b].kind);
+        const int lds = pair_kernel_lds(ex_bytes);
+        if (lds > 64 * 1024) {   // opt in to the large dynamic-LDS window, once per device and size
+            static int granted[64];
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+            if (granted[dev] < lds) {
+                const hipError_t e = hipFuncSetAttribute((const void*)k_policy_pair, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e != hipSuccess) { rl_set_error("hipFuncSetAttribute(%d bytes of LDS) failed: %s", lds, hipGetErrorString(e)); return RL_E_LAUNCH; }
+                granted[dev] = lds;
+            }
+        }
+        const dim3 gridp((grid.x + kPairTiles - 1) / kPairTiles, a.nb);
+        hipLaunchKernelGGL(k_policy_pair, gridp, dim3(128 * kPairTiles), lds, st, a, ex_bytes);
         return launch_check("policy kernel (pair)");
     }
     if (variant == RL_PV_DENSE) {
