@@ -874,15 +874,23 @@ __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int
     lds_barrier();
     RL_MARK(2);
     // ---- _execute_movement: Jacobi fixed point (environment.py:637-644) --------------------------------------------
+    // Every round of the loop also LOADS what _eat and the vanish rule need of the pre-move grid at the agent's current target (cell
+    // type, occupant) and of the agent itself: in the round whose vote finds no conflict the targets are final, so what was loaded is
+    // what _eat reads -- and the interval that follows only has to commit.  (Round 3: _eat, the clearing of the old cells and the
+    // placement were three barrier intervals of their own behind the loop; they are ONE now, see below.)
     int any_phase = 0;
+    // (parked in aux[a] next to the conflict flag: bits 0-2 the target's pre-move type, bit 3 = it held an agent, bit 4 = nobody targets
+    // the agent's own cell, bit 7 = conflict)
     for (; !RL_ABL(16);) {
         int conflict = 0;
         for (int a = tid; a < n0; a += T) {
             const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
             const int tg = s.tgt[a];
             const unsigned ct = cnt[tg];  // unconditional: behind `tg != cx &&` it would be a third dependent LDS trip
+            const int e_tt = s.type[tg], e_oc = s.occ[tg];
+            const unsigned e_cnt = cnt[cx];
             const bool c = tg != cx && ct > 1u;
-            s.aux[a] = c ? 0x80 : 0;
+            s.aux[a] = (uint8_t)((c ? 0x80 : 0) | (e_tt & 7) | (e_oc >= 0 ? 8 : 0) | (e_cnt == 0u ? 16 : 0));
             conflict |= c;
         }
         if (!block_any(&s.scal[S_ANYFLAG0], any_phase, conflict != 0)) break;
@@ -896,38 +904,20 @@ __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int
         lds_barrier();
     }
     RL_MARK(3);
-    // ---- _eat + vanish rule (reads the pre-move grid) ----------------------------------------------------------------
-    for (int a = tid; a < n0; a += T) {
-        const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
-        const int tg = s.tgt[a], act = s.action[a];
-        // everything the rule may need, in one batch (guarded loads would each be a dependent LDS trip)
-        const int tt = s.type[tg], oc = s.occ[tg], hp = s.health[a], ma = s.max_age[a], fl = s.flags[a];
-        uint8_t ax = 0;
-        if (act >= 0 && act <= 3) {
-            if (tt == RL_FOOD) s.health[a] = min(200, hp + 40);
-            else if (tt == RL_POISON) s.health[a] = min(200, hp - 40);
-            else if (tt == kSuper) {
-                s.health[a] = min(200, hp + 40);
-                s.max_age[a] = (int)((double)ma * 1.2);
-                s.flags[a] = (uint8_t)(fl | RL_F_ATE_SUPER);
-            }
-            // entering the cell of a later-ordered agent that is itself leaving: erased by its grid[old]=Empty
-            if (tg != cx && oc >= 0 && tg > cx) ax = AUX_VANISH;
-        }
-        s.aux[a] = ax;
-    }
+    // ---- _eat + vanish rule + _update_agent_position + _update_death_status, ONE interval -------------------------------------------
+    // The reference moves the agents one by one in list order: grid[old] = Empty; grid[target] = agent (environment.py:778-782).  As a
+    // parallel rule with ONE writer per cell: a mover empties its old cell only if NOBODY targets it (the final target counts say so);
+    // a cell that is entered is written by the agent entering it -- as an agent cell, or as an EMPTY cell when the entering agent is
+    // erased by the later-ordered occupant's grid[old] = Empty (the vanish rule).  A cell's pre-move content is only read in the loop
+    // above (before the last vote's barrier), so nothing here reads what another lane writes.
     // (the tick's draws: first needed by _add_food below.  Not in the first agent phase, where a preparing world's idle
     // waves are busy with their cells' Philox blocks)
     if (LEAN) precompute_draws<T>(p, s, w, n0);
-    if (SPEC && spec) spec_refill_stage<T>(p, s, w, spec_state, 1);
-    lds_barrier();
-    RL_MARK(35);
-    for (int a = tid; a < n0; a += T) {
-        const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
-        if (s.tgt[a] != cx) { s.type[cx] = RL_EMPTY; s.occ[cx] = -1; }
+    if (SPEC && spec) {   // the refill's counting sort keeps its barrier-separated stages (a preparing world only)
+        spec_refill_stage<T>(p, s, w, spec_state, 1); lds_barrier();
+        spec_refill_stage<T>(p, s, w, spec_state, 2); lds_barrier();
     }
-    if (SPEC && spec) spec_refill_stage<T>(p, s, w, spec_state, 2);
-    lds_barrier();
+    RL_MARK(35);
     RL_MARK(36);
     // (per-wave counts are taken with ballots and added by one lane: a per-lane atomicAdd on one LDS word is turned by the
     // compiler into a scalar loop over the active lanes, ~60 cycles per lane -- 2 us for a full wave)
@@ -939,20 +929,33 @@ __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int
         int gene = 0;
         if (valid) {
             const int cx = (s.pos[a] & 255) * W + (s.pos[a] >> 8);
-            const int tg = s.tgt[a];
+            const int tg = s.tgt[a], act = s.action[a];
+            int hp = s.health[a], ma = s.max_age[a], fl = s.flags[a];
+            const int ag = s.age[a], ex = s.aux[a];   // one batch
+            gene = s.gene[a];
+            const int e_tt = ex & 7;
+            const bool e_occupied = ex & 8, old_free = ex & 16;
+            bool vanish = false;
+            if (act >= 0 && act <= 3) {   // _eat (environment.py:701-715): the pre-move type at the final target
+                if (e_tt == RL_FOOD) hp = min(200, hp + 40);
+                else if (e_tt == RL_POISON) hp = min(200, hp - 40);
+                else if (e_tt == kSuper) { hp = min(200, hp + 40); ma = (int)((double)ma * 1.2); fl |= RL_F_ATE_SUPER; }
+                // entering the cell of a later-ordered agent that is itself leaving: erased by its grid[old]=Empty
+                vanish = tg != cx && e_occupied && tg > cx;
+            }
             if (tg != cx) {
-                if (!(s.aux[a] & AUX_VANISH)) { s.type[tg] = RL_AGENT; s.occ[tg] = (short)a; }
+                if (old_free) { s.type[cx] = RL_EMPTY; s.occ[cx] = -1; }            // nobody enters the old cell
+                if (vanish) { s.type[tg] = RL_EMPTY; s.occ[tg] = -1; }              // (the occupant left it; its own clear does not happen: its cell IS targeted)
+                else { s.type[tg] = RL_AGENT; s.occ[tg] = (short)a; }
                 const int ti = tg / W;
                 s.pos[a] = (unsigned short)(ti | ((tg - ti * W) << 8));
             }
             // _update_death_status (environment.py:789-793)
-            int fl = s.flags[a];
-            const int hp = s.health[a], ag = s.age[a], ma = s.max_age[a];  // one batch
             if (hp <= 0 || ag == ma) fl |= RL_F_DEAD;
-            s.flags[a] = (uint8_t)fl;
+            s.health[a] = hp; s.max_age[a] = ma; s.flags[a] = (uint8_t)fl;
+            s.aux[a] = vanish ? AUX_VANISH : 0;
             alive = (fl & RL_F_DEAD) ? 0u : 1u;
-            ongrid = (s.aux[a] & AUX_VANISH) ? 0u : 1u;
-            gene = s.gene[a];
+            ongrid = vanish ? 0u : 1u;
         }
         alive_wave += __popcll(__ballot(alive != 0u));
         hash_insert_wave(s, p.hash_mask, valid, a, gene, alive | (ongrid << 16));
@@ -984,7 +987,10 @@ __device__ __forceinline__ void phase_step(const KParams& p, Smem& s, int w, int
     // (the agent bitmap of the post-step ordering is taken in the same sweep: food placement does not touch agent cells,
     // so the ordering's prefix scan can run on wave 1 next to the placement on wave 0)
     int nf = 0, np_ = 0, ns = 0;  // per wave (Cp is a multiple of 64: whole waves run each iteration)
-    for (int c = tid; c < p.Cp; c += T) {
+    // (workgroups of >= 512 threads: the cells go to waves 2.., which have nothing else in this interval -- waves 0 and 1 carry the
+    // agents' rewards above, and as the last to arrive at the sweep they made it the interval's longest job)
+    constexpr int kSweep0 = T >= 512 ? 128 : 0;
+    for (int c = tid - kSweep0; c >= 0 && c < p.Cp; c += T - kSweep0) {
         const int t = s.type[c];
         nf += __popcll(__ballot(t == RL_FOOD)); np_ += __popcll(__ballot(t == RL_POISON)); ns += __popcll(__ballot(t == kSuper));
         const unsigned long long m = __ballot(t != RL_EMPTY);
