@@ -182,15 +182,18 @@ __device__ __forceinline__ void recycle_world(const KParams& p, Smem& s, int n, 
         s.pos[tid] = r_pos; s.health[tid] = r_h; s.age[tid] = r_age; s.max_age[tid] = r_ma; s.gene[tid] = r_g; s.brain[tid] = r_b;
         s.uid[tid] = r_u; s.flags[tid] = r_fl; s.action[tid] = r_act; s.fitness[tid] = r_f;
         s.aux[tid] = 0; s.src[tid] = (short)tid; s.order[tid] = (short)tid; s.newidx[tid] = (short)tid;
+        // the occupancy grid names the agents by slot: every live agent renames its own cell.  No other cell holds a slot: a cell an
+        // agent leaves, a corpse's cell and the target of an erased mover are set to -1 where that happens (phase_step, reproduce_wave0),
+        // a refill rewrites the whole grid -- so there is no sweep over the cells here, and no barrier between one and the renaming
+        // (round 3: clear all, barrier, rename)
+        s.occ[(r_pos & 255) * p.W + (r_pos >> 8)] = (short)tid;
     }
-    for (int c = tid; c < p.Cp; c += T) { s.occ[c] = -1; ((unsigned*)s.foodv)[c] = 0u; }
+    for (int c = tid; c < p.Cp; c += T) ((unsigned*)s.foodv)[c] = 0u;   // (the target counts of the next step live in the food plane)
     for (int i = tid; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
     if (tid < RL_MAX_BRAINS) s.present[tid] = 0;
     if (SPEC) for (int i = tid; i < 2 * p.cap; i += T) ((unsigned*)s.reward)[i] = 0u;
     if (tid < S_COUNT)
         s.scal[tid] = tid == S_NSLOTS ? n : tid == S_TICK ? tick : tid == S_EPOCH ? epoch : tid == S_NEXT_UID ? next_uid : tid == S_MAX_GENE ? max_gene : 0;
-    lds_barrier();
-    if (mine) s.occ[(r_pos & 255) * p.W + (r_pos >> 8)] = (short)tid;
     if (drain_stores || (also_drain && *also_drain)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tick's observation rows are in L2 before any wave reads them back
     lds_barrier();
 }
@@ -796,15 +799,27 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     if (!overlapped) lds_barrier();
     else { const int first_new = nslots; nslots = s.scal[S_NSLOTS]; patch_planes_after_update<T>(p, s, n1, first_new, nslots); }
     if (!overlapped) phase_update<T, true>(p, s, w, n1, nslots, true);
-    for (int c = tid; c < p.Cp; c += T) {
-        const unsigned long long m = __ballot(s.type[c] == RL_AGENT);
-        if (lane_id() == 0) s.agbits[c >> 6] = m;
+    // The agent bitmap of the post-update grid AND its prefix (scan_order_wave) by the LAST wave alone, lane l = bitmap word l: all words'
+    // loads in one trip, a ballot each, one DPP scan -- a barrier interval less than "every wave its cells, barrier, one wave scans"
+    // (the other waves clear the gene table meanwhile).
+    if (tid >= T - 64) {
+        const int l = tid - (T - 64);
+        unsigned long long mine = 0ull;
+        for (int wd = 0; wd < p.nW; ++wd) {
+            const unsigned long long m = __ballot(s.type[wd * 64 + l] == RL_AGENT);
+            if (l == wd) mine = m;
+        }
+        const int cntw = __popcll(mine);
+        const int incl = wave_incl_scan(cntw);
+        s.agbits[l] = mine;
+        s.wordbase[l] = incl - cntw;
+        if (l == 63) s.scal[S_N2] = incl;
     }
-    for (int i = tid; i < p.hash_size; i += T) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
+    static_assert(T > 64, "k_run: at least two waves");
+    if (tid < T - 64)
+        for (int i = tid; i < p.hash_size; i += T - 64) { s.hkey[i] = -1; s.hcnt[i] = 0u; }
     lds_barrier();
     RL_MARK(64);
-    if (tid < 64) scan_order_wave(p, s, tid, S_N2);
-    lds_barrier();
     RL_MARK(65);
     int n2 = s.scal[S_N2];
     int tick_next = s.scal[S_TICK] + 1, epoch_next = s.scal[S_EPOCH];
