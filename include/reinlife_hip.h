@@ -214,6 +214,7 @@ int rl_tick_refill(rl_world* h, const int8_t* actions, const rl_step_out* sout, 
  *   sout->trk_*   the Tracker accumulators of rl_step_out are maintained every tick (environment.py:206-207 -> tracker.py:107-121):
  *                 trk_tick holds the last tick's values, trk_sum / trk_cnt / trk_pop[1..2] are read at the start of the launch and
  *                 written back at its end (running sums over as many launches as the caller likes; it zeroes them at interval ends) */
+#define RL_EPS_INLINE_MAX 256
 typedef struct {
     int32_t threshold, n_agents;     /* refill rule as in rl_run (threshold < 0: none) */
     int32_t* refill_count;
@@ -221,6 +222,8 @@ typedef struct {
     int32_t trk_skip_ticks;          /* the first trk_skip_ticks ticks of the launch write trk_tick but stay out of the running sums:
                                       * episode 0 of a training run never reaches an aggregate (tracker.py:279-282 keeps the last
                                       * update_interval entries of update_interval + 1) */
+    int32_t eps_schedule_on_host;    /* != 0: eps_schedule is a HOST pointer and n_ticks * n_brains <= RL_EPS_INLINE_MAX: the table travels
+                                      * inside the kernel arguments (copied during the call) -- a short launch then waits for no upload */
     const rl_replay* replays;        /* host array [n_brains] or NULL: every tick's transitions are appended to the brains' replay rings
                                       * inside the launch -- what rl_capture_transitions does after a stand-alone tick (trainer.py:95-96,
                                       * entities.py:194-208); the rings' order is Agent.learn call order per world, worlds interleaved */

@@ -30,6 +30,7 @@ TAPE_FIELDS = ("food_k", "food_u", "repro_u", "birth_k", "produce_u", "produce_c
 STEP_OUT_FIELDS = ("n_acted", "reward", "done", "src", "obs", "acted_total", "trk_tick", "trk_sum", "trk_cnt", "trk_pop", "n_post",
                    "age", "brain")
 TRK_VARS = 7
+EPS_INLINE_MAX = 256   # rl_run_opts.eps_schedule_on_host: floats that fit into the kernel arguments
 UPDATE_OUT_FIELDS = ("src", "obs")
 
 
@@ -55,7 +56,7 @@ class Replay(C.Structure):
 
 class RunOpts(C.Structure):  # rl_run_opts
     _fields_ = [("threshold", C.c_int32), ("n_agents", C.c_int32), ("refill_count", C.c_void_p), ("eps_schedule", C.c_void_p),
-                ("trk_skip_ticks", C.c_int32), ("replays", C.c_void_p), ("policy_out", C.c_void_p)]
+                ("trk_skip_ticks", C.c_int32), ("eps_schedule_on_host", C.c_int32), ("replays", C.c_void_p), ("policy_out", C.c_void_p)]
 
 
 class Brain(C.Structure):

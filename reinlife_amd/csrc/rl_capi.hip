@@ -19,7 +19,7 @@ int rl_world_launch_observe(const rl_world*, float*, hipStream_t);
 int rl_world_launch_reset(rl_world*, int, int, float*, int32_t*, int, hipStream_t);
 int rl_world_launch_capture(rl_world*, const float*, const int8_t*, const float*, const rl_step_out*, const rl_replay*, int, hipStream_t);
 int rl_world_run_supported(const rl_world*, const rl_brain*, int);
-int rl_world_launch_run(rl_world*, const rl_brain*, int, int, int8_t*, const rl_step_out*, float* const*, int, int16_t*, int, int, int32_t*, const float*, int, const rl_replay*, float*, hipStream_t);
+int rl_world_launch_run(rl_world*, const rl_brain*, int, int, int8_t*, const rl_step_out*, float* const*, int, int16_t*, int, int, int32_t*, const float*, int, int, const rl_replay*, float*, hipStream_t);
 int64_t rl_policy_n_params_impl(int);
 int64_t rl_policy_packed_floats_impl(int);
 int rl_policy_pack_impl(int, const float*, float*);
@@ -312,7 +312,7 @@ int rl_run_ex(rl_world* h, const rl_brain* brains, int n_brains, int n_ticks, in
               float* const obs[2], int first_obs, int16_t* update_src, const rl_run_opts* opts, void* stream)
 {
     RL_CHECK_BOUND("rl_run")
-    const rl_run_opts none = {-1, 0, nullptr, nullptr, 0, nullptr, nullptr};
+    const rl_run_opts none = {-1, 0, nullptr, nullptr, 0, 0, nullptr, nullptr};
     if (!opts) opts = &none;
     if (!brains || !actions || !obs || !obs[0] || !obs[1]) { rl_set_error("rl_run: null argument"); return RL_E_INVALID; }
     if (n_brains != h->cfg.n_brains) { rl_set_error("rl_run: n_brains %d != config %d", n_brains, h->cfg.n_brains); return RL_E_INVALID; }
@@ -328,14 +328,18 @@ int rl_run_ex(rl_world* h, const rl_brain* brains, int n_brains, int n_ticks, in
     for (int b = 0; b < n_brains; ++b)
         if (brains[b].kind < RL_DQN || brains[b].kind > RL_PPO || !brains[b].packed) { rl_set_error("rl_run: brain %d invalid", b); return RL_E_INVALID; }
     if (n_ticks == 0) return RL_OK;
+    if (opts->eps_schedule_on_host && (!opts->eps_schedule || (int64_t)n_ticks * n_brains > RL_EPS_INLINE_MAX)) {
+        rl_set_error("rl_run: eps_schedule_on_host needs a table of at most %d floats (got %lld)", RL_EPS_INLINE_MAX, (long long)n_ticks * n_brains);
+        return RL_E_INVALID;
+    }
     return rl_world_launch_run(h, brains, n_brains, n_ticks, actions, sout, obs, first_obs, update_src, opts->threshold, opts->n_agents,
-                               opts->refill_count, opts->eps_schedule, opts->trk_skip_ticks, opts->replays, opts->policy_out, (hipStream_t)stream);
+                               opts->refill_count, opts->eps_schedule, opts->eps_schedule_on_host, opts->trk_skip_ticks, opts->replays, opts->policy_out, (hipStream_t)stream);
 }
 
 int rl_run(rl_world* h, const rl_brain* brains, int n_brains, int n_ticks, int8_t* actions, const rl_step_out* sout,
            float* const obs[2], int first_obs, int16_t* update_src, int threshold, int n_agents, int32_t* refill_count, void* stream)
 {
-    const rl_run_opts o = {threshold, n_agents, refill_count, nullptr, 0, nullptr, nullptr};
+    const rl_run_opts o = {threshold, n_agents, refill_count, nullptr, 0, 0, nullptr, nullptr};
     return rl_run_ex(h, brains, n_brains, n_ticks, actions, sout, obs, first_obs, update_src, &o, stream);
 }
 

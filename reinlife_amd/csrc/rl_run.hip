@@ -45,6 +45,8 @@ struct RunArgs {
     int n_ticks;
     int8_t* actions;                      // [R][cap] chosen actions of the LAST tick (API-visible)
     const float* eps_sched;               // optional device [n_ticks][n_brains]: the brains' exploration rates tick by tick (else eps[])
+    int eps_inline_on;                    // the schedule is eps_inline[] (a short launch: no upload to wait for), not eps_sched
+    float eps_inline[RL_EPS_INLINE_MAX];
     int trk_skip;                         // the Tracker's running sums leave out the first trk_skip ticks of the launch
     int capture;                          // TRAIN launches: append every tick's transitions to the brains' replay rings (rp[])
     float* policy_out;                    // [R][cap][8] or null: the policy's outputs of the tick (PPO: probabilities) for rl_replay.prob
@@ -213,6 +215,8 @@ __device__ inline float run_eps(RunParamsC* ka, int b, int n_brains, const PolSm
 {
     typedef const float __attribute__((address_space(4))) cfloat;
     if (TRAIN) {
+        if (*(const int __attribute__((address_space(4)))*)&ka->ra.eps_inline_on)
+            return ((cfloat*)ka->ra.eps_inline)[__builtin_amdgcn_readfirstlane(ps.meta[3]) * n_brains + b];
         const float* es = *(const float* const __attribute__((address_space(4)))*)&ka->ra.eps_sched;
         if (es) return ((cfloat*)es)[__builtin_amdgcn_readfirstlane(ps.meta[3]) * n_brains + b];
     }
@@ -1109,7 +1113,7 @@ int rl_world_run_supported(const rl_world* h, const rl_brain* brains, int n_brai
 }
 int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n_ticks, int8_t* actions, const rl_step_out* so,
                         float* const obs[2], int first, int16_t* upd_src, int refill_threshold, int refill_n_agents,
-                        int32_t* refill_count, const float* eps_sched, int trk_skip, const rl_replay* replays, float* policy_out, hipStream_t st)
+                        int32_t* refill_count, const float* eps_sched, int eps_on_host, int trk_skip, const rl_replay* replays, float* policy_out, hipStream_t st)
 {
     if (!rl_world_run_supported(h, brains, n_brains)) { rl_set_error("rl_run: unsupported configuration (brain kinds / slot_cap / LDS)"); return RL_E_UNSUPPORTED; }
     KParams p = make_params(h);
@@ -1122,7 +1126,11 @@ int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n
     rp.p = p;
     RunArgs& ra = rp.ra;
     for (int b = 0; b < n_brains; ++b) { ra.packed[b] = brains[b].packed; ra.eps[b] = brains[b].epsilon; ra.kind[b] = brains[b].kind; }
-    ra.obs[0] = obs[0]; ra.obs[1] = obs[1]; ra.first = first; ra.n_ticks = n_ticks; ra.actions = actions; ra.eps_sched = eps_sched; ra.trk_skip = trk_skip;
+    ra.obs[0] = obs[0]; ra.obs[1] = obs[1]; ra.first = first; ra.n_ticks = n_ticks; ra.actions = actions; ra.trk_skip = trk_skip;
+    if (eps_on_host) {   // (checked by the caller: a host table of at most RL_EPS_INLINE_MAX floats) -- it rides in the kernel arguments
+        ra.eps_sched = nullptr; ra.eps_inline_on = 1;
+        for (int i = 0; i < n_ticks * n_brains; ++i) ra.eps_inline[i] = eps_sched[i];
+    } else { ra.eps_sched = eps_sched; ra.eps_inline_on = 0; }
     ra.capture = replays != nullptr; ra.policy_out = policy_out;
     if (replays) for (int b = 0; b < n_brains; ++b) ra.rp[b] = replays[b];
     ra.debug = g_run_debug;
@@ -1132,7 +1140,7 @@ int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n
     rp.p.PS = kind == kKindAll ? host_plane_stride<kKindAll>(h, T) : host_plane_stride<RL_PERD3QN>(h, T);
     const size_t bytes = kind == kKindAll ? run_smem_bytes<kKindAll>(h, T, rp.p.PS) : run_smem_bytes<RL_PERD3QN>(h, T, rp.p.PS);
     const bool fixed = p.W == kFixW && p.H == kFixH && rp.p.PS == run_plane_stride(T, kFixW, kFixH) && p.cap == kFixCap && p.hash_size == kFixHash && !h->opt.world_generic;
-    const int train = (replays != nullptr || policy_out != nullptr) ? 2 : (eps_sched != nullptr || p.so.trk_tick != nullptr) ? 1 : 0;
+    const int train = (replays != nullptr || policy_out != nullptr) ? 2 : (eps_sched != nullptr || p.so.trk_tick != nullptr) ? 1 : 0;   // (eps_sched: device table or host table, either way a schedule)
     const void* fn = nullptr;
 #define RL_RUN_PICK(TT, FX, KD, TR) if (T == TT && fixed == FX && kind == KD && train == TR) fn = (const void*)k_run<TT, FX, KD, TR>;
 #ifdef RL_RUN_DEV_BUILD   /* tuning builds: only the instantiations bench.py times (compile time) */

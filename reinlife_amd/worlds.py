@@ -81,6 +81,7 @@ class DeviceWorlds:
         _lib.check(self.lib.rl_bind_state(self.handle, C.byref(self._state)), "rl_bind_state")
         _lib.check(self.lib.rl_bind_error_flag(self.handle, _ptr(self.err)), "rl_bind_error_flag")
         self.tracking = False
+        self._trk_dirty = False     # a launch has added to trk_sum / trk_cnt / trk_pop since they were last zeroed
         self.replays = None
         self._build_step_out()
         self._work = None
@@ -218,7 +219,9 @@ class DeviceWorlds:
                    "rl_capture_transitions")
 
     def reset_tracking(self):
-        self.trk_sum.zero_(); self.trk_cnt.zero_(); self.trk_pop[:, 1:].zero_()
+        if self._trk_dirty:   # (fresh accumulators are zero: a new Environment's first launch is not preceded by three memsets)
+            self.trk_sum.zero_(); self.trk_cnt.zero_(); self.trk_pop[:, 1:].zero_()
+            self._trk_dirty = False
 
     def set_actions(self, actions):
         a = torch.as_tensor(np.ascontiguousarray(actions, dtype=np.int8) if not torch.is_tensor(actions) else actions,
@@ -229,6 +232,7 @@ class DeviceWorlds:
     def step(self, actions=None, tape=None):
         if actions is not None:
             self.set_actions(actions)
+        self._trk_dirty = self._trk_dirty or self.tracking
         _lib.check(self.lib.rl_step(self.handle, _ptr(self.actions), C.byref(tape) if tape is not None else None,
                                     C.byref(self._step_out), self._stream()), "rl_step")
         self._ticked = False  # Agent.state of this tick is still the current buffer
@@ -239,6 +243,7 @@ class DeviceWorlds:
             self.set_actions(actions)
         if not hasattr(self, "pre_counts"):
             self.pre_counts = torch.zeros((self.R, 4), dtype=torch.int32, device=self.device)
+        self._trk_dirty = self._trk_dirty or self.tracking
         _lib.check(self.lib.rl_step_split(self.handle, _ptr(self.actions), C.byref(self._step_out), _ptr(self.pre_counts),
                                           self._stream()), "rl_step_split")
         self._ticked = False
@@ -258,6 +263,7 @@ class DeviceWorlds:
         if actions is not None:
             self.set_actions(actions)
         uo = self._next_upd_out()
+        self._trk_dirty = self._trk_dirty or self.tracking
         _lib.check(self.lib.rl_tick(self.handle, _ptr(self.actions), C.byref(tape) if tape is not None else None,
                                     C.byref(self._step_out), C.byref(uo), self._stream()), "rl_tick")
         self._ticked = True
@@ -265,6 +271,7 @@ class DeviceWorlds:
     def tick_refill(self, threshold, n_agents):
         """tick() + refill(threshold, n_agents) in one launch (Philox draws)."""
         uo = self._next_upd_out()
+        self._trk_dirty = self._trk_dirty or self.tracking
         _lib.check(self.lib.rl_tick_refill(self.handle, _ptr(self.actions), C.byref(self._step_out), C.byref(uo),
                                            threshold, n_agents, _ptr(self.refill_count), self._stream()), "rl_tick_refill")
         self._ticked = True
@@ -319,16 +326,20 @@ class DeviceWorlds:
                 if keep is not None and t + 1 == trk_skip:
                     self.trk_sum.copy_(keep[0]); self.trk_cnt.copy_(keep[1]); self.trk_pop[:, 1:].copy_(keep[2])
             return
-        if eps_host is not None:
+        inline = eps_host is not None and eps_host.size <= _lib.EPS_INLINE_MAX
+        if eps_host is not None and not inline:
             eps_schedule = self._stage_schedule(eps_host)
         if self._run_pair is None:
             self._run_pair = (C.c_void_p * 2)(_ptr(self._obs2[0]), _ptr(self._obs2[1]))
         cap = self.replays is not None
-        opts = _lib.RunOpts(threshold, n_agents, _ptr(self.refill_count), _ptr(eps_schedule), trk_skip,
+        # (a short schedule rides in the kernel arguments -- rl_run_opts.eps_schedule_on_host: the launch waits for no upload)
+        eps_arg = C.c_void_p(eps_host.ctypes.data) if inline else _ptr(eps_schedule)
+        opts = _lib.RunOpts(threshold, n_agents, _ptr(self.refill_count), eps_arg, trk_skip, 1 if inline else 0,
                             C.cast(self._replay_arr, C.c_void_p) if cap else None, _ptr(self.out_q) if (cap and self._capture_prob) else None)
+        self._trk_dirty = self._trk_dirty or self.tracking
         _lib.check(self.lib.rl_run_ex(self.handle, self._brains, self.n_brains, n_ticks, _ptr(self.actions), C.byref(self._step_out),
                                       self._run_pair, self._cur, _ptr(self.src2), C.byref(opts), self._stream()), "rl_run_ex")
-        self._eps_keep = eps_schedule   # the launch reads it asynchronously
+        self._eps_keep = None if inline else eps_schedule   # the launch reads a device table asynchronously
         self.launches += 1
         self._cur = (self._cur + n_ticks) & 1
         self._ticked = True

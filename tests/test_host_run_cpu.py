@@ -157,5 +157,5 @@ def test_run_opts_struct_matches_the_header():
     body = re.sub(r"/\*.*?\*/", "", hdr[hdr.rindex("typedef struct {", 0, end) + len("typedef struct {"):end], flags=re.S)
     names = [re.findall(r"[A-Za-z_][A-Za-z_0-9]*", part)[-1] for decl in body.split(";") if decl.strip() for part in decl.split(",")]
     assert [n for n, _ in _lib.RunOpts._fields_] == names
-    assert C.sizeof(_lib.RunOpts) == 48 and _lib.RunOpts.eps_schedule.offset == 16 and _lib.RunOpts.trk_skip_ticks.offset == 24
+    assert C.sizeof(_lib.RunOpts) == 48 and _lib.RunOpts.eps_schedule.offset == 16 and _lib.RunOpts.trk_skip_ticks.offset == 24 and _lib.RunOpts.eps_schedule_on_host.offset == 28
     assert _lib.RunOpts.replays.offset == 32 and _lib.RunOpts.policy_out.offset == 40
