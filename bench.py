@@ -496,7 +496,7 @@ def main():
                      "unit": "GB/s", "frac": round(tick_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "avg_launch_us": round(t_tick * 1e6, 2), "agent_steps_per_launch": round(per_launch, 1),
                      "bytes_per_agent_step": TICK_BYTES_PER_AGENT_STEP}
-        pol_roof = {"kernel": "k_policy (rl_policy_act: one launch per brain kind)", "bound": "mfma", "achieved": round(pol_tflops, 3),
+        pol_roof = {"kernel": "k_policy_pair / k_policy_dense (rl_policy_act: the tiles of rl_run's policy half as a stand-alone launch)", "bound": "mfma", "achieved": round(pol_tflops, 3),
                     "peak": round(MFMA_F32_EQUIV_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
                     "frac": round(pol_tflops / MFMA_F32_EQUIV_PEAK_TFLOPS, 5),
                     "peak_note": "algorithmic f32-equivalent FLOP/s; peak = f16 dense %.1f TF / %d partial products of the "
