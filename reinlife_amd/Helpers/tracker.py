@@ -54,6 +54,9 @@ class Tracker:
             # and every rank then sums the job's worlds in global replica order with the same reduction a single-rank job uses: the
             # aggregates are bit-identical whatever the number of ranks (a sum of per-rank partial sums -- an all-reduce(SUM) -- would
             # re-associate the float64 additions: equal to 1e-16 relative, not exactly)
+            backend = getattr(self.dist, "get_backend", lambda: "")()
+            if rows.is_cuda and str(backend) == "gloo":   # (a CPU-only backend under GPU worlds: the few hundred bytes go through the host)
+                rows = rows.cpu()
             flat = torch.empty(self.dist.get_world_size() * rows.numel(), dtype=torch.float64, device=rows.device)
             self.dist.all_gather_into_tensor(flat, rows.reshape(-1).contiguous())
             self.collectives_executed += 1
