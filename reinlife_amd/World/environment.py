@@ -256,11 +256,12 @@ class Environment:
             return
         # replicas: the same construction (one agent per brain, gene = its index; environment.py:147-149) on the device, from the
         # Philox streams keyed by (seed, global replica id): ONE launch for any number of worlds ...
-        if self.n_worlds > 1 or self.world_base != 0:
+        if self.rng == "philox" and (self.n_worlds > 1 or self.world_base != 0):
             self.worlds.reset_families()
         # ... and the job's replica 0 alone (world 0 of the rank with world_base 0) consumes the process-global np.random, in the
-        # reference's order: a sharded job builds the same replicas whatever the number of ranks
-        if self.world_base == 0:
+        # reference's order: a sharded job builds the same replicas whatever the number of ranks.  (rng="reference" -- one world per
+        # process, the reference's own generator calls -- always does.)
+        if self.world_base == 0 or self.rng == "reference":
             snap = host_reset(self.width, self.height, len(self.brains))
             self.worlds.load_world(0, snap)
             self.worlds.observe()
