@@ -1267,6 +1267,28 @@ __device__ __forceinline__ void reproduce_wave0(const KParams& p, Smem& s, int w
     }
 }
 
+// (fitness, list index) of the wave's fittest agent -- first on ties, like np.argmax -- in every lane.  DPP moves (row_shr 1 / 2 / 4 / 8, then
+// the two row broadcasts: lane 63 ends up with the wave's best) instead of six xor-shuffle steps of three ds_bpermute each: a dependent
+// LDS-crossbar trip apiece on the wave that is the longest of its interval.
+__device__ inline void wave_argmax_f64(double& f, int& k)
+{
+#define RL_ARGMAX_STEP(CTRL, RMASK) do { \
+        const long long bits_ = __double_as_longlong(f); \
+        const int lo_ = (int)(unsigned)bits_, hi_ = (int)(unsigned)((unsigned long long)bits_ >> 32); \
+        const unsigned olo_ = (unsigned)__builtin_amdgcn_update_dpp(lo_, lo_, CTRL, RMASK, 0xF, false); \
+        const unsigned ohi_ = (unsigned)__builtin_amdgcn_update_dpp(hi_, hi_, CTRL, RMASK, 0xF, false); \
+        const int ok_ = __builtin_amdgcn_update_dpp(k, k, CTRL, RMASK, 0xF, false); \
+        const double of_ = __longlong_as_double((long long)(((unsigned long long)ohi_ << 32) | olo_)); \
+        if (of_ > f || (of_ == f && ok_ < k)) { f = of_; k = ok_; } } while (0)   /* (a lane without a source gets its own value back) */
+    RL_ARGMAX_STEP(0x111, 0xF); RL_ARGMAX_STEP(0x112, 0xF); RL_ARGMAX_STEP(0x114, 0xF); RL_ARGMAX_STEP(0x118, 0xF);
+    RL_ARGMAX_STEP(0x142, 0xA); RL_ARGMAX_STEP(0x143, 0xC);
+#undef RL_ARGMAX_STEP
+    const long long bits = __double_as_longlong(f);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)bits >> 32), 63);
+    f = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    k = __builtin_amdgcn_readlane(k, 63);
+}
 // _update_best_agents (environment.py:728-739) by ONE wave (no workgroup barrier): used when the update's serial section
 // runs on wave 0 next to the other waves' observation pass
 __device__ inline void best_agents_wave(Smem& s, int n1)
@@ -1277,11 +1299,7 @@ __device__ inline void best_agents_wave(Smem& s, int n1)
         const double f = s.fitness[s.order[k]];
         if (f > bf || (f == bf && k < bk)) { bf = f; bk = k; }
     }
-#pragma unroll
-    for (int m = 32; m; m >>= 1) {
-        const double of = shfl_xor_f64(bf, m); const int ok = __shfl_xor(bk, m);
-        if (of > bf || (of == bf && ok < bk)) { bf = of; bk = ok; }
-    }
+    wave_argmax_f64(bf, bk);
     if (lane == 0 && n1 > 0) {
         int mi = 0;
         for (int b = 1; b < RL_N_BEST; ++b) if (s.best_fit[b] < s.best_fit[mi]) mi = b;
