@@ -7,11 +7,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from reinlife_amd import _lib
 NAMES = ["policy half end -> tick entry (params, carve)", "Environment.step: act, attack, conflicts, eat/move/death, rewards, food", "order 1 + planes 1 (+ barrier)",
-         "reproduce (wave 0) || obs1 rows + step outputs (others)", "src, agent bitmap, hash clear (+ barrier)", "scan order 2", "refill or order 2 + gene hash", "planes 2 (+ barrier)",
-         "policy lists (wave 0) || obs2 rows -> memory + LDS mirror", "recycle world (compaction, clears, 3 barriers)"]
+         "reproduce (wave 0) || obs1 rows + step outputs (others)", "src, planes patch, agent bitmap + prefix (last wave), hash clear (+ barrier)", "(scan order 2: merged into the interval before, round 4)", "refill or order 2 + gene hash", "planes 2 (+ barrier)",
+         "policy lists (wave 0) || obs2 rows -> memory + LDS mirror", "recycle world (compaction, clears, 2 barriers)"]
 IDX = [112, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69]
 SUB = [60, 2, 3, 35, 36, 37, 4, 5, 6, 61]   # inside Environment.step
-SUBN = ["act + attack + prep", "conflict loop", "eat + vanish flags (+bar)", "clear old cells (+bar)", "place + death + hash", "(mark 4)", "rewards", "food count + bitmap", "food placement .. end"]
+SUBN = ["act + attack + prep", "conflict loop (+ the loads of eat / vanish)", "precompute draws (round 4: no barrier here)", "(no interval: merged)", "commit: eat + clear + place + death + hash", "(mark 4)", "rewards", "food count + bitmap", "food placement .. end"]
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 args = __import__("argparse").Namespace(worlds=R, workload=os.environ.get("RL_AB_WORKLOAD", "c4"), seed=1)
 dw = bench.make_worlds(args, 0, "cuda:0")
