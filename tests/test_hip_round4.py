@@ -221,3 +221,50 @@ def test_random_configurations_through_the_launch_64_cases():
     import subprocess
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "64", "11"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "fuzz ok: 64 cases" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_policy_act_with_more_brains_than_one_launch_holds():
+    """Twelve brains of all four kinds (more than the eight a policy launch serves: the canonical tiles in two batches; rl_run does not cover it,
+    DeviceWorlds.run loops over the two launches): Q values / probabilities against the oracle's f32 forward (1e-5), the selected actions
+    against the oracle's rule where they are clear of a tie, and 20 ticks of worlds against the oracle fed the actions."""
+    import torch
+    from oracle import oracle as orc
+    from reinlife_amd import _lib
+    from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights
+    from test_hip_round2 import _weights
+    names = ["DQN", "PPO", "D3QN", "PERD3QN"] * 3
+    eps = [0.0, 0.0, 0.0, 0.2] * 3
+    wts = [_weights(n, 900 + k) for k, n in enumerate(names)]
+    cfg = dict(width=30, height=30, max_agents=100, n_brains=len(names), static_families=True, limit_reproduction=False, incentivize_killing=True)
+    dw = DeviceWorlds(n_worlds=10, seed=1212, world_base=3, **cfg)
+    ow = orc.OracleWorlds(n_worlds=10, seed=1212, world_base=3, **cfg)
+    dw.set_brains([(_lib.KIND_BY_METHOD[n], e, pack_brain_weights(_lib.KIND_BY_METHOD[n], w)) for n, e, w in zip(names, eps, wts)])
+    dw.reset_synthetic(100); ow.reset_synthetic(100)
+    assert not dw.run_supported()
+    checked = 0
+    for t in range(20):
+        n = ow.s["n_agents"].copy()
+        dw.act(want_q=True)
+        torch.cuda.synchronize()
+        acts, q = dw.actions.cpu().numpy().copy(), dw.out_q.cpu().numpy()
+        for b, name in enumerate(names):
+            ws, ks = np.nonzero((np.arange(dw.cap)[None, :] < n[:, None]) & (ow.s["a_brain"] == b))
+            if not len(ws):
+                continue
+            want = orc.policy_forward(orc.KIND_BY_NAME[name], wts[b], ow.obs2[ws, ks])
+            np.testing.assert_allclose(q[ws, ks], want, rtol=0, atol=1e-5, err_msg="%s (brain %d) tick %d" % (name, b, t))
+            if eps[b] == 0.0 and name != "PPO":
+                srt = np.sort(want, axis=1)
+                clear = srt[:, -1] - srt[:, -2] > 1e-5
+                assert np.array_equal(acts[ws, ks][clear], want.argmax(1)[clear]), (name, b, t)
+                checked += int(clear.sum())
+        ow.step(acts); ow.update(); ow.refill(70, 100)
+        dw.tick_refill(70, 100)
+        dw.check_error_flag()
+        _cmp_state(dw, ow, "tick %d" % t)
+        _cmp_rows(dw.obs_state().cpu().numpy(), ow.obs2, ow.s["n_agents"], "tick %d obs2" % t)
+    assert checked > 3000
+    # ... and DeviceWorlds.run() (the two-launch loop for this configuration) continues the same worlds
+    dw.run(5, 70, 100)
+    dw.check_error_flag()
+    assert int(dw.s["tick"].max().item()) >= 5
