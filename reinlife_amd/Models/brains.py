@@ -168,10 +168,16 @@ class _DuelingAgent(_HipBrain):
         rate has reached its floor -- after ~290 episodes -- the rest of the range is one fill."""
         out = np.empty(k, np.float64)
         t = 0
-        while t < k and self.training and self.epsilon > self.epsilon_min:
-            self.update_epsilon(n_epi + t)
-            out[t] = self.epsilon
-            t += 1
+        if self.training:   # (update_epsilon's rule on locals: a short schedule is host time in front of a short launch)
+            e, last, floor, decay = self.epsilon, self.n_epi, self.epsilon_min, self.decay
+            while t < k and e > floor:
+                ne = n_epi + t
+                if ne > last:
+                    e = e * decay   # (e > floor holds here)
+                    last = ne
+                out[t] = e
+                t += 1
+            self.epsilon, self.n_epi = e, last
         if t < k:
             out[t:] = self.epsilon
             if self.training:

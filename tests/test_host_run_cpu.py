@@ -159,3 +159,23 @@ def test_run_opts_struct_matches_the_header():
     assert [n for n, _ in _lib.RunOpts._fields_] == names
     assert C.sizeof(_lib.RunOpts) == 48 and _lib.RunOpts.eps_schedule.offset == 16 and _lib.RunOpts.trk_skip_ticks.offset == 24 and _lib.RunOpts.eps_schedule_on_host.offset == 28
     assert _lib.RunOpts.replays.offset == 32 and _lib.RunOpts.policy_out.offset == 40
+
+
+def test_epsilon_schedules_equal_the_brains_own_update_rule():
+    """epsilon_schedule(n_epi, k) (one call per brain and chunk: Environment.run) == k calls of update_epsilon (D3QN.py:84-89, DQN.py:67-69 of the
+    reference): the same float64 values bit for bit, the brain left in the same state -- for training and inference brains, chunks of any
+    shape, repeated and overlapping episode ranges."""
+    from reinlife_amd import Models
+    makers = (lambda: Models.PERD3QN(), lambda: Models.D3QN(training=False), lambda: Models.DQN(max_epi=1000),
+              lambda: Models.DQN(max_epi=200, training=False), lambda: Models.PPO())
+    for mk in makers:
+        for pieces in ([(0, 700)], [(0, 1), (1, 7), (8, 30), (38, 400), (438, 100)], [(5, 20), (25, 500)], [(0, 21)], [(3, 3), (3, 5), (2, 9)]):
+            a, b = mk(), mk()
+            for n0, k in pieces:
+                want = []
+                for t in range(k):
+                    a.update_epsilon(n0 + t)
+                    want.append(getattr(a, "epsilon", 0.0))
+                got = b.epsilon_schedule(n0, k)
+                assert np.array_equal(np.array(want, np.float64), got), (type(a).__name__, pieces, n0)
+                assert getattr(a, "epsilon", 0.0) == getattr(b, "epsilon", 0.0) and getattr(a, "n_epi", 0) == getattr(b, "n_epi", 0)
