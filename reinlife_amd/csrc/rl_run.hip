@@ -698,7 +698,7 @@ __device__ __forceinline__ void capture_rows(const KParams& p, Smem& s, RunParam
         const rl_replay R = load_replay(ka, s.brain[a]);
         const int same = (int)(s.hcnt[s.hslot[a]] >> 16);
         float* d1 = R.state_prime + (size_t)sl * RL_OBS_DIM + 147;
-        d1[0] = (float)((double)s.health[a] * 0.005);
+        d1[0] = (float)((double)s.health[a] * rl_one_200th());
         d1[1] = (s.flags[a] & RL_F_REPRODUCED) ? 1.f : 0.f;
         d1[2] = (float)((double)same / (double)n1);
         d1[3] = (float)((double)n1 / (double)p.max_agents);

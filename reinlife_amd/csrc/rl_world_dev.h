@@ -203,6 +203,16 @@ __host__ __device__ inline size_t carve(Smem& s, char* base, int Cp, int cap, in
 // small device helpers
 // ---------------------------------------------------------------------------------------------------------------
 __device__ inline int lane_id() { return rl_tidx() & 63; }
+// float64 constants that must NOT be hoisted out of k_run's tick loop: loop-invariant 64-bit values are kept alive across the policy half's
+// 250-VGPR tile code, i.e. spilled, and every use becomes a scratch reload -- a memory round trip, on wave 0's serial sections at that
+// (the ISA of round 3 reloaded -1e300 twice per tick in _update_best_agents and 0.005 in the planes).  Built from opaque halves at the use site.
+__device__ inline double rl_opaque_f64(unsigned hi, unsigned lo)
+{
+    asm volatile("" : "+v"(hi), "+v"(lo));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ inline double rl_minus_huge() { return rl_opaque_f64(0xFE37E43Cu, 0x8800759Cu); }   // -1.0e300
+__device__ inline double rl_one_200th() { return rl_opaque_f64(0x3F747AE1u, 0x47AE147Bu); }    // 0.005
 
 // The kernel argument block (KParams is the only kernel parameter, so it starts at offset 0 of the kernarg segment), made
 // opaque so that every use site re-reads the few pointers it needs with s_load instead of keeping all ~45 pointers alive
@@ -659,7 +669,7 @@ __device__ __forceinline__ void build_planes(const KParams& p, Smem& s, int t0 =
             const int ps = s.pos[a], hp = s.health[a], fl = s.flags[a], ge = s.gene[a];  // one batch
             const int i = ps & 255, j = ps >> 8, c = i * p.W + j;
             if (s.type[c] != RL_AGENT || s.occ[c] != a) continue;   // (vanished: not on the grid)
-            const double v = (double)hp * 0.005;                      // see below
+            const double v = (double)hp * rl_one_200th();            // see below
             const int pc = i * p.PS + j;
             s.foodv[pc] = hp < 0 ? 1.f : 0.f;
             s.healthv[pc] = float_mode ? (float)v : (float)(double)(long long)v;
@@ -680,7 +690,7 @@ __device__ __forceinline__ void build_planes(const KParams& p, Smem& s, int t0 =
             if (hp < 0) f = 1.f;                                   // _get_food, environment.py:440-444
             // hp / 200.0 as one f64 multiply: (float)(hp * 0.005) == (float)(hp / 200.0) and trunc() of both agree for every
             // integer |hp| <= 1e5 (checked exhaustively; health stays within [-300, 200]); an f64 division is ~20 instructions
-            const double v = (double)hp * 0.005;
+            const double v = (double)hp * rl_one_200th();
             h = float_mode ? (float)v : (float)(double)(long long)v;  // astype(int64) truncates toward zero
             if (s.flags[a] & RL_F_DEAD) g = s.gene[a];             // _get_genes, environment.py:448-456
         }
@@ -759,7 +769,7 @@ __device__ __forceinline__ void write_observations(const KParams& p, Smem& s, in
         const int a = s.order[k];
         const int same = (int)(s.hcnt[s.hslot[a]] >> 16);
         float* o = base + (size_t)k * RL_OBS_DIM + 147;
-        const float v0 = (float)((double)s.health[a] * 0.005);  // == (float)(health / 200.0), see build_planes
+        const float v0 = (float)((double)s.health[a] * rl_one_200th());  // == (float)(health / 200.0), see build_planes
         const float v1 = (s.flags[a] & RL_F_REPRODUCED) ? 1.f : 0.f;
         const float v2 = (float)((double)same / (double)n);
         const float v3 = (float)((double)n / (double)p.max_agents);
@@ -1294,7 +1304,7 @@ __device__ inline void wave_argmax_f64(double& f, int& k)
 __device__ inline void best_agents_wave(Smem& s, int n1)
 {
     const int lane = lane_id();
-    double bf = -1.0e300; int bk = 0x7fffffff;
+    double bf = rl_minus_huge(); int bk = 0x7fffffff;
     for (int k = lane; k < n1; k += 64) {
         const double f = s.fitness[s.order[k]];
         if (f > bf || (f == bf && k < bk)) { bf = f; bk = k; }
@@ -1317,7 +1327,7 @@ __device__ __forceinline__ void phase_update(const KParams& p, Smem& s, int w, i
     const int tid = rl_tidx();
     // ---- _update_best_agents (environment.py:728-739) ----------------------------------------------------------------
     if (!p.static_families) {
-        double bf = -1.0e300; int bk = 0x7fffffff;
+        double bf = rl_minus_huge(); int bk = 0x7fffffff;
         for (int k = tid; k < n1; k += T) {
             const double f = s.fitness[s.order[k]];
             if (f > bf || (f == bf && k < bk)) { bf = f; bk = k; }
