@@ -1509,7 +1509,14 @@ __device__ inline void policy_pair2(const TileIO& io, int lane, int role, const 
         RL_PMARK1(15);
     }
     if (role) {
-        *(f32x4*)(pair_lds->val + 4 * lane) = f32x4{head4[0], head4[1], head4[2], head4[3]};
+        // (the lane index taken afresh: computed from `lane` this address is formed at the top of the tile, lives through all of it in a
+        // VGPR the 250-register tile does not have -- spilled -- and comes back by a scratch reload + s_waitcnt vmcnt(0) right here, on the
+        // role that finishes last)
+        int l2 = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l2));
+#endif
+        *(f32x4*)(pair_lds->val + 4 * l2) = f32x4{head4[0], head4[1], head4[2], head4[3]};
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) part->head[r] = head4[r];
