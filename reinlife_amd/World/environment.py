@@ -315,8 +315,7 @@ class Environment:
         """environment.py:188-215"""
         if self.training:
             if self.tracker.update_results(None, n_epi):   # (the per-tick statistics were accumulated inside the step launch)
-                self.worlds.check_error_flag()             # an interval closed: the Tracker has just synchronised
-                self._ticks_since_check = 0
+                self._ticks_since_check = 0                # an interval closed: the error flag came back with its sums (Tracker.resolve)
         self._ticks_since_check += 1
         if self._ticks_since_check >= 256:   # a loop that never reads env.agents / env.grid still learns of a device error
             self._sync()
@@ -442,13 +441,16 @@ class Environment:
                 self.worlds.reset_tracking()
             self.worlds.run(k, thr, self.synthetic_agents or 0, eps_schedule=None if (eps == eps[-1]).all() else eps,
                             trk_skip=1 if (self.training and n_epi == 0) else 0)
+            # The interval the PREVIOUS chunk closed: its sums (and the error flag) were copied out behind that chunk; the host
+            # reads, divides and prints them now, with this chunk queued -- the device does not wait for any of it.
+            self.tracker.resolve()
             self._refresh(after="update")
             last = n_epi + k - 1
             if self.training and last > 0 and last % interval == 0:
-                self.tracker.update_results(None, last)
-                self.worlds.check_error_flag()   # (the Tracker has just synchronised: a corrupted world stops the loop at the interval)
+                self.tracker.update_results(None, last, defer=True)   # the device half of the close: queued behind the chunk
             n_epi += k
             n_ticks -= k
+        self.tracker.resolve()   # (a close behind the last chunk: a corrupted world stops the loop here at the latest)
 
     # -- host mirrors ----------------------------------------------------------------------------------------------------
     def agents_of(self, world):

@@ -31,6 +31,17 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class _Readback:
+    """Host copies in flight (DeviceWorlds.readback): wait() blocks until THEY have arrived, not until the stream is idle."""
+
+    def __init__(self, host, done):
+        self.host, self.done = host, done
+
+    def wait(self):
+        self.done.synchronize()
+        return [h.numpy() for h in self.host]
+
+
 class DeviceWorlds:
     def __init__(self, n_worlds=1, width=30, height=30, max_agents=100, n_brains=2, static_families=True,
                  limit_reproduction=False, incentivize_killing=True, seed=0, slot_cap=None, device="cuda:0",
@@ -93,6 +104,7 @@ class DeviceWorlds:
         self._capture_prob = False
         self._fused_key = self._fused = None
         self.launches = 0                        # kernel-launching C-ABI calls made by run() so far (bench.py reports it)
+        self._side = None                        # side stream of readback()
 
     def __del__(self):
         try:
@@ -115,9 +127,35 @@ class DeviceWorlds:
         return self.obs1[: self.R * self.cap].view(self.R, self.cap, _lib.OBS_DIM)
 
     def check_error_flag(self):
-        e = self.err.cpu().numpy()
+        self.raise_on_error_flag(self.err.cpu().numpy())
+
+    @staticmethod
+    def raise_on_error_flag(e):
         if e[0] != 0:
             raise _lib.ReinLifeHipError("device error flag: code %d world %d detail (%d, %d)" % tuple(int(x) for x in e))
+
+    def readback(self, tensors):
+        """Small device tensors on their way to pinned host memory BEHIND everything queued on the current stream so far and NEXT TO
+        whatever is queued afterwards: the copies run on a side stream that waits for an event recorded here, so a caller can queue
+        the next multi-tick launch first and collect the values while it runs (`.wait()` -> list of numpy arrays).  The Tracker
+        closes its intervals this way (Helpers/tracker.py): the device does not idle for the host's read-back, the statistics'
+        arithmetic and the next launch's set-up."""
+        cur = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        self._side.wait_event(ready)
+        host = []
+        with torch.cuda.stream(self._side):
+            for t in tensors:
+                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                h.copy_(t, non_blocking=True)
+                t.record_stream(self._side)
+                host.append(h)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        return _Readback(host, done)
 
     # -- host <-> device state (parity I/O) ----------------------------------------------------------------------
     def load_world(self, w, snap):

@@ -112,6 +112,50 @@ def test_run_cuts_chunks_at_tracker_boundaries_and_builds_the_brains_own_schedul
     assert sum(1 for c in env.worlds.calls if c[0] == "set_brains") == 1
 
 
+def test_the_next_chunk_is_queued_before_the_host_reads_a_closed_interval(fake_env, capsys):
+    """Tracker intervals close in two halves (Helpers/tracker.py): sums copied out behind the chunk that ends the interval, read on the
+    host only after the NEXT chunk has been queued; `results` and the end of run() resolve what is pending; the error flag that
+    travelled with the sums raises where they are read."""
+    from reinlife_amd import _lib
+    env = fake_env(update_interval=10)
+    w = env.worlds
+    w.err = torch.zeros(4, dtype=torch.int32)
+
+    class _Copies:
+        def __init__(self, arrays): self.arrays = arrays
+        def wait(self):
+            w.calls.append(("wait",))
+            return self.arrays
+
+    def readback(tensors):
+        w.calls.append(("readback",))
+        return _Copies([t.clone().numpy() for t in tensors])
+
+    def raise_on_error_flag(e):
+        if e[0]:
+            raise _lib.ReinLifeHipError("device error flag: code %d" % e[0])
+    w.readback, w.raise_on_error_flag = readback, raise_on_error_flag
+    env.tracker.print_results = True
+    env.reset()
+    env.run(0, 31)
+    seq = [c[0] for c in w.calls if c[0] in ("run", "readback", "wait")]
+    assert seq == ["run", "readback", "run", "wait", "readback", "run", "wait", "readback", "wait"]   # the last close: resolved at the end of run()
+    assert capsys.readouterr().out.count("| Gene |") == 3 and len(env.tracker.results["Avg Number of Populations"]) == 3
+    # a piece that ends on a boundary leaves nothing pending either; reading `results` never sees a half-closed interval
+    env.run(31, 10)
+    assert env.tracker._pending is None and len(env.tracker._results["Avg Number of Populations"]) == 4
+    env.tracker.update_results(None, 50, defer=True)
+    assert env.tracker._pending is not None and len(env.tracker.results["Avg Number of Populations"]) == 5 and env.tracker._pending is None
+    # the tick-by-tick path closes both halves at once
+    env.tracker.update_results(None, 60)
+    assert env.tracker._pending is None and len(env.tracker._results["Avg Number of Populations"]) == 6
+    # a device error surfaces with the interval's read-back
+    w.err[0] = 3
+    env.tracker.update_results(None, 70, defer=True)
+    with pytest.raises(_lib.ReinLifeHipError):
+        env.tracker.resolve()
+
+
 def test_run_in_arbitrary_pieces_and_constant_epsilon(fake_env):
     env = fake_env(update_interval=20)
     env.reset()
