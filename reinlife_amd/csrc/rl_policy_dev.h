@@ -1260,6 +1260,338 @@ __device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, c
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// FOUR waves per tile for the dueling kinds in 1024-thread workgroups (128 VGPRs per wave, FOUR waves per SIMD: the SIMD issues a VALU
+// instruction every 2 cycles instead of every 4, tools/ubench/valu_rate.hip, and the tick half runs on sixteen waves).  The layers are
+// split by OUTPUT TILE: wave q of a tile owns output tile q of the input layer and of both branches' hidden layers -- ONE accumulator
+// per big layer (16 registers), the canonical chain per accumulator (chunk 0 .. NS-1, hi.lo, hi.hi, lo.hi: section 5.2.1), so the bits
+// are those of policy_tile1s / policy_tile1.  The four waves of a tile sit on ONE SIMD (waves t, t + 4, t + 8, t + 12 of the
+// workgroup): four independent accumulator chains keep that SIMD's matrix pipe busy, and no weight byte is fetched twice per tile.
+//   rows        wave q reads K-chunks q, q + 4, q + 8 of the tile's rows from the LDS mirror of the Agent.state rows (nothing else of
+//               them, ever), the partial row maxima cross through LDS (barrier 1), it splits ITS chunks into the tile's exchange slice
+//               (barrier 2), and the input layer's K loop takes the B operand from there: a split costs VALU issue that only hides
+//               under the issuing wave's OWN MFMAs (~2 v_fma_mix per MFMA) -- split by all four waves inside the loop, the first
+//               version, the input layer took 9.6k cycles for 120 MFMAs;
+//   exchanges   after each big layer every wave knows 32 of the 128 activations of a row: partial row maxima through LDS (barriers 3
+//               and 5), then each wave splits ITS two K-chunks of the next layer's B operand into the slice (barriers 4 and 6); the
+//               slice aliases the mirror -- every row has been read when barrier 1 is passed;
+//   heads       advantage head on wave 0, value head on wave 1 (three accumulators each, as head_stream): their own two chunks stay in
+//               registers, the other six come out of the slice (24 KB per tile: 3 waves x 2 chunks x 2 planes x 1 KB, twice);
+//   finish      the value crosses through LDS (the caller's barrier), wave 0 combines, picks the action (tile1_finish).
+// Waves without a tile meet the same six barriers.
+// ---------------------------------------------------------------------------------------------------------------
+struct QuadLds {
+    float* pmax;   // [3 buffers][32 rows][4 waves]: stage 0 (the row) and stage 2 (advantage branch) share buffer 0 -- two barriers lie between them --, stage 1 (input layer) 1, stage 3 (value branch) 2
+    f32x4* ex;     // the tile's exchange slice, kQuadExBytes
+    float* val;    // [32]
+#ifdef RL_PHASE_PROFILE
+    long long* prof;   // tuning build: arrival stamps of tile 0's four waves (slots 116 + 4 * point + q)
+#endif
+};
+#ifdef RL_PHASE_PROFILE
+#define RL_QMARK(pt) do { if (ql->prof && lane == 0) ql->prof[116 + 4 * (pt) + q] = (long long)clock64(); } while (0)
+#else
+#define RL_QMARK(pt) do { } while (0)
+#endif
+constexpr int kQuadExBytes = 24 * 1024;
+constexpr int kQuadFloats = 3 * 32 * 4 + 32;   // per tile: partial row maxima (three buffers), the row values
+constexpr int kQuadBarriers = 6;
+
+// chunk c of this lane's half row (x[row][16c + 8h + 0..7], zero beyond 152).  XL: from the LDS mirror (`xr`: the lane's row there);
+// else from memory (`goff`: byte offset of the lane's row in io.obs).  The choice is made per WAVE, not per lane: memory loads inside
+// the K loop share the weight ring's counter (vmcnt), and a wait for one of them is a wait for every weight load issued before it.
+template <bool COHERENT, bool XL>
+__device__ inline void quad_load_x(const TileIO& io, const float* xr, int goff, int c, int h, f32x4& x0, f32x4& x1)
+{
+    if (XL) {   // (a mirror row is zero from float 153 to 159: write_observations)
+        x0 = *(const f32x4*)(xr + 16 * c + 8 * h);
+        x1 = *(const f32x4*)(xr + 16 * c + 8 * h + 4);
+        return;
+    }
+    const bool last = c == kInChunks - 1 && h == 1;   // k 152 .. 159: one value
+    const int k0 = last ? 149 : 16 * c + 8 * h;
+    if (COHERENT) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)io.obs, 0, 0x7fffffff, 0x00027000);
+        x0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff + 4 * k0, 0, 16 /* sc1 */));
+        x1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff + 4 * (last ? k0 : k0 + 4), 0, 16));
+    } else {
+        const float* g = (const float*)((const char*)io.obs + goff);
+        x0 = *(const f32x4u*)(g + k0);
+        x1 = *(const f32x4u*)(g + (last ? k0 : k0 + 4));
+    }
+}
+template <bool XL>
+__device__ inline void quad_fix_x(int c, int h, f32x4& x0, f32x4& x1)
+{
+    if (!XL && c == kInChunks - 1 && h == 1) { x0 = f32x4{x0.w, 0.0f, 0.0f, 0.0f}; x1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+}
+__device__ inline float quad_row_max(const QuadLds* ql, int stage, int q, int lane, float m)   // partial maximum in -> the row's maximum out (one barrier)
+{
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float* pm = ql->pmax + (stage * 32 + (lane & 31)) * 4;
+    if (lane < 32) pm[q] = m;
+    lds_barrier();
+    const f32x4 v = *(const f32x4*)pm;
+    return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+}
+// One-tile weight ring of a big layer: step i = K-chunk i of output tile `tile` (TOUT tiles per chunk), fragments hi / lo.
+template <int NS, int D, int TOUT = 4>
+struct WRingQ {
+    f32x4 a[D][kPlanes];
+    gf32x4* p;
+    __device__ inline void start(gfloat* __restrict__ pw, int lane, int tile)
+    {
+        p = (gf32x4*)pw + tile * kPlanes * 64 + lane;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int pl = 0; pl < kPlanes; ++pl) a[d][pl] = p[(d * TOUT * kPlanes + pl) * 64];
+        p += D * TOUT * kPlanes * 64;
+        asm volatile("" : "+v"(p));
+    }
+    __device__ inline void take(int i, f32x4 (&ac)[kPlanes])
+    {
+        const int cur = i % D;
+#pragma unroll
+        for (int pl = 0; pl < kPlanes; ++pl) ac[pl] = a[cur][pl];
+        if (i + D < NS) {
+#pragma unroll
+            for (int pl = 0; pl < kPlanes; ++pl) a[cur][pl] = p[pl * 64];
+            p += TOUT * kPlanes * 64;
+            asm volatile("" : "+v"(p));
+        }
+    }
+};
+// epilogue of one output tile from the brain's LDS constants ([unscale 16 | bias 16] of this lane's half): y = relu(acc * (unscale * row_un) + bias)
+__device__ inline float quad_epilogue(f32x16& a, const float* c, float row_un)
+{
+    float m = 0.0f;
+#pragma unroll
+    for (int Q = 0; Q < 4; ++Q) {
+        const f32x4 un = *(const f32x4*)(c + 4 * Q), bi = *(const f32x4*)(c + 16 + 4 * Q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float y = fmaxf(__builtin_fmaf(a[4 * Q + e], un[e] * row_un, bi[e]), 0.0f);
+            a[4 * Q + e] = y;
+            m = fmaxf(m, y);
+        }
+    }
+    return m;
+}
+// A head on one wave (Q = 0: advantage, own chunks 0, 1; Q = 1: value, own chunks 2, 3): three accumulators over the eight chunks in order
+template <int Q, int D>
+__device__ inline void quad_head(gfloat* __restrict__ hw, int lane, const f32x4 (&own)[2][kPlanes], const f32x4* __restrict__ others, const f32x4& un4, float row_un, float (&out)[4])
+{
+    WRing<1, 1, 1, D> w;
+    w.start(hw, lane, 0);
+    f32x16 a0, a1, a2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; a2[r] = 0.0f; }
+    auto src = [&](int c, int pl) -> f32x4 {
+        const int wv = c >> 1;
+        if (wv == Q) return own[c & 1][pl];
+        const int idx = Q == 0 ? wv - 1 : (wv == 0 ? 0 : wv - 1);
+        return others[((idx * 2 + (c & 1)) * kPlanes + pl) * 64 + lane];
+    };
+    f32x4 B[2][kPlanes];
+#pragma unroll
+    for (int pl = 0; pl < kPlanes; ++pl) B[0][pl] = src(0, pl);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        f32x4 ac[1][kPlanes];
+        w.template next<8>(s, ac);
+        if (s + 1 < 8) {
+#pragma unroll
+            for (int pl = 0; pl < kPlanes; ++pl) B[(s + 1) & 1][pl] = src(s + 1, pl);
+        }
+        a0 = mfma16(ac[0][0], B[s & 1][1], a0);
+        a1 = mfma16(ac[0][0], B[s & 1][0], a1);
+        a2 = mfma16(ac[0][1], B[s & 1][0], a2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = ((a0[r] + a1[r]) + a2[r]) * (un4[r] * row_un);
+}
+
+template <int KIND, bool COHERENT, bool XL>
+__device__ inline void quad_input_layer(const TileIO& io, int lane, int q, const QuadLds* ql, rl_u4& draw, f32x16& F, float& un0)
+{
+    extern __shared__ __attribute__((aligned(16))) char rl_dyn_lds[];
+    const int h = lane >> 5;
+    const Layout L = layout_of(KIND);
+    const float* const xr = (const float*)(rl_dyn_lds + (XL ? io.x_lds_off : 0));   // (+ 8 h floats: folded into the loads' offsets)
+    const int goff = XL ? 0 : (int)(io.row * (RL_OBS_DIM * 4));
+    // ---- this wave's K-chunks of the row: q, q + 4, q + 8 (waves 2, 3: two chunks) -- all it ever reads of the rows
+    f32x4 X[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = q + 4 * i;   // (uniform)
+        if (c < kInChunks) { quad_load_x<COHERENT, XL>(io, xr, goff, c, h, X[i][0], X[i][1]); quad_fix_x<XL>(c, h, X[i][0], X[i][1]); }
+        else { X[i][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; X[i][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    }
+    WRingQ<kInChunks, 4> w1;
+    w1.start(io.packed + L.l1, lane, q);
+    if (q == 0 && io.actions && io.eps > 0.0f) draw = rl_philox4x32(io.seed, io.key_epoch, io.key_world, io.key_tick, RL_SITE_ACT, io.key_index);
+    float m4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        max3_abs(m4[0], X[i][0].x, X[i][0].y); max3_abs(m4[1], X[i][0].z, X[i][0].w); max3_abs(m4[2], X[i][1].x, X[i][1].y); max3_abs(m4[3], X[i][1].z, X[i][1].w);
+    }
+    RL_PMARK1(1);
+    RL_QMARK(0);
+    float sc0;
+    row_scale(quad_row_max(ql, 0, q, lane, fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]))), sc0, un0);   // barrier 1: every row of the tile has been read
+    // ---- the wave's chunks split into the tile's exchange slice (which aliases the mirror): [chunk][plane][lane]
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = q + 4 * i;
+        if (c < kInChunks) {
+            const float x[8] = {X[i][0].x, X[i][0].y, X[i][0].z, X[i][0].w, X[i][1].x, X[i][1].y, X[i][1].z, X[i][1].w};
+            f32x4 hi, lo;
+            split8(x, sc0, hi, lo);
+            ql->ex[(c * kPlanes + 0) * 64 + lane] = hi;
+            ql->ex[(c * kPlanes + 1) * 64 + lane] = lo;
+        }
+    }
+    lds_barrier();   // 2
+    RL_PMARK1(2);
+    // ---- input layer: output tile q, the B operand chunk by chunk out of the slice (one chunk ahead)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) F[r] = 0.0f;
+    f32x4 B[2][kPlanes];
+#pragma unroll
+    for (int pl = 0; pl < kPlanes; ++pl) B[0][pl] = ql->ex[pl * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < kInChunks; ++s) {
+        f32x4 ac[kPlanes];
+        w1.take(s, ac);
+        if (s + 1 < kInChunks) {
+#pragma unroll
+            for (int pl = 0; pl < kPlanes; ++pl) B[(s + 1) & 1][pl] = ql->ex[((s + 1) * kPlanes + pl) * 64 + lane];
+        }
+        F = mfma16(ac[0], B[s & 1][1], F);
+        F = mfma16(ac[0], B[s & 1][0], F);
+        F = mfma16(ac[1], B[s & 1][0], F);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int KIND, bool COHERENT>
+__device__ inline void policy_quad(const TileIO& io, int lane, int q, const QuadLds* ql, Tile1Part* part)
+{
+    static_assert(KIND == RL_D3QN || KIND == RL_PERD3QN, "four-wave tile: dueling kinds");
+    extern __shared__ __attribute__((aligned(16))) char rl_dyn_lds[];
+    const int h = lane >> 5;
+    const Layout L = layout_of(KIND);
+    gfloat* __restrict__ packed = io.packed;
+    const float* const cc = (const float*)(rl_dyn_lds + io.c_lds_off);
+    const float* const consts = cc + 64 * q + 32 * h;   // + 256 per layer: l1, l2a, l2b
+    const float* const hconsts = cc + 768;              // heads: [un 8 | bias 8] advantage, value
+    rl_u4 draw = {0u, 0u, 0u, 0u};
+    // ---- the row's maximum (barrier 1) and the input layer's output tile q: rows from the mirror, or -- if ANY row of the wave is not
+    // there (more rows than the mirror holds, several rounds of tiles, a launch's first tick without preload) -- all from memory, which
+    // recycle_world drained in exactly those cases
+    f32x16 F;
+    float un0;
+    if (__builtin_amdgcn_ballot_w64(io.x_lds_off < 0) == 0ull) quad_input_layer<KIND, COHERENT, true>(io, lane, q, ql, draw, F, un0);
+    else quad_input_layer<KIND, COHERENT, false>(io, lane, q, ql, draw, F, un0);
+    RL_PMARK1(3);
+    // ---- both branches' weight rings start here: their first trip overlaps the exchange
+    WRingQ<8, 3> wa, wv;
+    wa.start(packed + L.l2a, lane, q);
+    wv.start(packed + L.l2b, lane, q);
+    float sc1, un1;
+    RL_QMARK(1);
+    row_scale(quad_row_max(ql, 1, q, lane, quad_epilogue(F, consts, un0)), sc1, un1);   // barrier 3: every wave is through its K loop
+    RL_PMARK1(4);
+    {   // this wave's two K-chunks of the hidden layers' input: registers 0 .. 7 / 8 .. 15 = chunks 2q, 2q + 1
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float x[8] = {F[8 * c + 0], F[8 * c + 1], F[8 * c + 2], F[8 * c + 3], F[8 * c + 4], F[8 * c + 5], F[8 * c + 6], F[8 * c + 7]};
+            f32x4 hi, lo;
+            split8(x, sc1, hi, lo);
+            ql->ex[((2 * q + c) * kPlanes + 0) * 64 + lane] = hi;
+            ql->ex[((2 * q + c) * kPlanes + 1) * 64 + lane] = lo;
+        }
+    }
+    lds_barrier();   // 4
+    RL_PMARK1(5);
+    // ---- hidden layers: output tile q of the advantage branch and of the value branch (relu(feature) feeds both: PERD3QN.py:200-201)
+    f32x16 A, V;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { A[r] = 0.0f; V[r] = 0.0f; }
+    f32x4 B[2][kPlanes];
+#pragma unroll
+    for (int pl = 0; pl < kPlanes; ++pl) B[0][pl] = ql->ex[pl * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        f32x4 aa[kPlanes], av[kPlanes];
+        wa.take(s, aa);
+        wv.take(s, av);
+        if (s + 1 < 8) {
+#pragma unroll
+            for (int pl = 0; pl < kPlanes; ++pl) B[(s + 1) & 1][pl] = ql->ex[(((s + 1) * kPlanes) + pl) * 64 + lane];
+        }
+        A = mfma16(aa[0], B[s & 1][1], A);
+        V = mfma16(av[0], B[s & 1][1], V);
+        A = mfma16(aa[0], B[s & 1][0], A);
+        V = mfma16(av[0], B[s & 1][0], V);
+        A = mfma16(aa[1], B[s & 1][0], A);
+        V = mfma16(av[1], B[s & 1][0], V);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    RL_PMARK1(6);
+    RL_QMARK(2);
+    const float ma = quad_epilogue(A, consts + 256, un1), mv = quad_epilogue(V, consts + 512, un1);
+    {   // both branches' row maxima in one exchange (stages 2 and 3)
+        const float pa = fmaxf(ma, __shfl_xor(ma, 32)), pv = fmaxf(mv, __shfl_xor(mv, 32));
+        float* pm = ql->pmax + (lane & 31) * 4;
+        if (lane < 32) { pm[q] = pa; pm[256 + q] = pv; }
+    }
+    lds_barrier();   // 5: the hidden layers' input has been read by every wave
+    RL_PMARK1(7);
+    float sca, una, scv, unv;
+    {
+        const float* pm = ql->pmax + (lane & 31) * 4;
+        const f32x4 a = *(const f32x4*)pm, v = *(const f32x4*)(pm + 256);
+        row_scale(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), sca, una);
+        row_scale(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)), scv, unv);
+    }
+    f32x4 own[2][kPlanes];   // wave 0: its advantage chunks; wave 1: its value chunks
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float xa[8] = {A[8 * c + 0], A[8 * c + 1], A[8 * c + 2], A[8 * c + 3], A[8 * c + 4], A[8 * c + 5], A[8 * c + 6], A[8 * c + 7]};
+        const float xv[8] = {V[8 * c + 0], V[8 * c + 1], V[8 * c + 2], V[8 * c + 3], V[8 * c + 4], V[8 * c + 5], V[8 * c + 6], V[8 * c + 7]};
+        f32x4 ah, al, vh, vl;
+        split8(xa, sca, ah, al);
+        split8(xv, scv, vh, vl);
+        f32x4* const adv_o = ql->ex, * const val_o = ql->ex + 3 * 2 * kPlanes * 64;
+        if (q == 0) { own[c][0] = ah; own[c][1] = al; }
+        else { adv_o[(((q - 1) * 2 + c) * kPlanes + 0) * 64 + lane] = ah; adv_o[(((q - 1) * 2 + c) * kPlanes + 1) * 64 + lane] = al; }
+        if (q == 1) { own[c][0] = vh; own[c][1] = vl; }
+        else {
+            const int iv = q == 0 ? 0 : q - 1;
+            val_o[((iv * 2 + c) * kPlanes + 0) * 64 + lane] = vh; val_o[((iv * 2 + c) * kPlanes + 1) * 64 + lane] = vl;
+        }
+    }
+    lds_barrier();   // 6
+    RL_PMARK1(8);
+    // ---- heads
+    if (q == 0) {
+        float adv[4];
+        quad_head<0, 3>(packed + L.ha, lane, own, ql->ex, *(const f32x4*)(hconsts + 4 * h), una, adv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part->head[r] = adv[r];
+        part->draw = draw;
+        RL_PMARK1(9);
+    } else if (q == 1) {
+        float val[4];
+        quad_head<1, 3>(packed + L.hb, lane, own, ql->ex + 3 * 2 * kPlanes * 64, *(const f32x4*)(hconsts + 16 + 4 * h), unv, val);
+        if (h == 0) ql->val[lane] = val[0] + hconsts[16 + 8];
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
 // Two waves per tile for the plain kinds -- DQN (153 -> 128 -> 64 -> 8) and PPO (153 -> 256 -> 256 -> 8 -> softmax) -- with the protocol of
 // policy_tile1s<PAIR>: both roles meet two workgroup barriers inside (partial row maxima, then the split activations of the input layer
 // through pair_lds->ex), the caller adds a third, and role 0 finishes (pair_finish).  Every layer is split by OUTPUT features:

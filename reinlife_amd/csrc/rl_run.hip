@@ -22,8 +22,8 @@ namespace {
 // (state_prime / state rows, reward, done, both permutations, actions), so a tick moves the same algorithmic bytes as
 // rl_policy_act + rl_tick_refill; what disappears is two launches, the world's load / store, the row lists, and the trip of
 // the observation rows through the fabric to another CU (the policy reads its own world's rows back from L2, sc1).
-// The 4-wave tile code runs on groups of four waves of the world's workgroup (T / 256 tiles at a time); every group executes
-// the same number of workgroup barriers per round.
+// The policy tiles run on the waves of the world's workgroup -- one, two or four waves per 32-row tile (run_policy1) -- and every wave
+// executes the same number of workgroup barriers.
 // ---------------------------------------------------------------------------------------------------------------
 #include "rl_policy_dev.h"
 
@@ -55,8 +55,6 @@ struct RunArgs {
 };
 
 struct PolSmem {
-    char* group0;       // per-group block: lds_h | lds_aux | lds_part, group g at group0 + g * group_bytes
-    int group_bytes;
     short* prow;        // [cap] T = 1024: list indices grouped by brain; T <= 512: per list entry, brain << 10 | position in the brain's list
     int* bstart;        // [64] first entry of brain b in prow
     int* bcnt;          // [64]
@@ -77,13 +75,8 @@ struct PolSmem {
     int* texoff;        // [4]  per tile: byte offset of its exchange buffer inside the mirror
     int* bkind;         // [8]  the brains' kinds (filled once per launch)
 };
-template <int KIND>
-__host__ __device__ constexpr int policy_group_bytes()
-{
-    return (int)(align16(sizeof(f32x4) * (size_t)policy_lds_units(kind_widest(KIND))) + align16(sizeof(float) * kAuxFloats) + align16(sizeof(float) * 4 * 32 * 9));
-}
-// groups > 0: `groups` blocks for the 4-wave tile (T = 1024).  groups == 0: the one-wave tile needs no LDS of its own; with
-// mirror_budget > 0 the Agent.state rows are mirrored in LDS instead (as many rows as fit below the budget, at most cap).
+// With mirror_budget > 0 the Agent.state rows are mirrored in LDS (as many rows as fit below the budget, at most cap); the two- and
+// four-wave tiles' exchange buffers alias the mirror.  (`groups`: LDS blocks of the 4-wave tile of rounds 1-2 in k_run<1024> -- always 0 now.)
 constexpr int kMaxTiles = 32;                // 32-row tiles of one brain per world: <= cap / 32 + n_brains
 constexpr int kPairFloats = 32 + 2 * 64;     // per tile pair: row values, partial row maxima of the two roles
 constexpr int kPairExBytes = 8 * kPlanes * 64 * 16;   // per tile pair: the split activations of the input layer (aliases the Agent.state mirror)
@@ -91,14 +84,13 @@ constexpr int kPairFloatsAll = kPairValFloats + 2 * 64;   // kKindAll: role 1's 
 template <int KIND> __host__ __device__ constexpr int run_const_floats() { return KIND == kKindAll ? kTileConstMax : kTileConstFloats; }
 template <int KIND> __host__ __device__ constexpr int run_pair_floats() { return KIND == kKindAll ? kPairFloatsAll : kPairFloats; }
 template <int KIND>
-__host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o, int cap, int groups, size_t mirror_budget = 0, int n_cbrains = 0)
+__host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o, int cap, int groups, size_t mirror_budget = 0, int n_cbrains = 0,
+                                               int pair_floats = run_pair_floats<KIND>())   // per tile: the tile waves' small exchanges (kQuadFloats for the four-wave tile)
 {
     o = align16(o);
-    ps.group0 = base + o; ps.group_bytes = policy_group_bytes<KIND>();
-    o += (size_t)groups * policy_group_bytes<KIND>();
     ps.xmirror = nullptr; ps.xrows = 0;
     // what follows the mirror: row lists and tile descriptors (2 * cap + ~3.5 KB), the Tracker's scratch and sums (8 * cap + ~0.8 KB), ...
-    const size_t tail = 10 * (size_t)cap + 5120 + sizeof(float) * 4 * run_pair_floats<KIND>() + sizeof(float) * run_const_floats<KIND>() * (size_t)n_cbrains;
+    const size_t tail = 10 * (size_t)cap + 5120 + sizeof(float) * 4 * (size_t)pair_floats + sizeof(float) * run_const_floats<KIND>() * (size_t)n_cbrains;
     if (groups == 0 && mirror_budget > o + tail) {
         const size_t rows = (mirror_budget - o - tail) / (sizeof(float) * kXStride);
         ps.xrows = (int)(rows < (size_t)cap ? rows : (size_t)cap);
@@ -115,7 +107,7 @@ __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o
     ps.cconst = nullptr;
     if (n_cbrains > 0) { ps.cconst = (float*)(base + o); o = align16(o + sizeof(float) * run_const_floats<KIND>() * (size_t)n_cbrains); }
     ps.pairv = nullptr;
-    if (n_cbrains > 0) { ps.pairv = (float*)(base + o); o = align16(o + sizeof(float) * 4 * run_pair_floats<KIND>()); }
+    if (n_cbrains > 0) { ps.pairv = (float*)(base + o); o = align16(o + sizeof(float) * 4 * (size_t)pair_floats); }
     ps.wtask = (int*)(base + o); o = align16(o + sizeof(int) * 8);
     ps.texoff = (int*)(base + o); o = align16(o + sizeof(int) * 4);
     ps.bkind = (int*)(base + o); o = align16(o + sizeof(int) * kRunMaxBrains);
@@ -125,16 +117,6 @@ __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o
     ps.trk.cnt = (int*)(base + o); o = align16(o + sizeof(int) * kRunMaxBrains * RL_TRK_VARS);
     return o;
 }
-template <int KIND> __device__ inline f32x4* pol_h(const PolSmem& ps, int g) { return (f32x4*)(ps.group0 + g * ps.group_bytes); }
-template <int KIND> __device__ inline float* pol_aux(const PolSmem& ps, int g)
-{
-    return (float*)(ps.group0 + g * ps.group_bytes + align16(sizeof(f32x4) * (size_t)policy_lds_units(kind_widest(KIND))));
-}
-template <int KIND> __device__ inline float (*pol_part(const PolSmem& ps, int g))[32][9]
-{
-    return (float (*)[32][9])(ps.group0 + g * ps.group_bytes + align16(sizeof(f32x4) * (size_t)policy_lds_units(kind_widest(KIND))) + align16(sizeof(float) * kAuxFloats));
-}
-
 // Agent.get_action for the n agents of this world (slot k == list index k): actions into s.action[] and the global
 // `actions` buffer.  Must be called by the whole workgroup; leaves with a barrier behind the last action store.
 // (Per-brain arguments are fetched from the kernel-argument block with a uniform index -- scalar loads; a by-value copy of the
@@ -142,8 +124,6 @@ template <int KIND> __device__ inline float (*pol_part(const PolSmem& ps, int g)
 // is 1 MB of memory traffic per tick.)
 struct RunParams;
 typedef const RunParams __attribute__((address_space(4))) RunParamsC;
-template <int T, int KIND, int TRAIN>
-__device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base);
 
 // Between two ticks of k_run: the post-update list becomes slots 0..n-1 (slot == list index, what load_world establishes),
 // and every per-tick scratch is reset to what load_world leaves behind.  slot_cap <= T: one agent per thread.
@@ -247,86 +227,16 @@ __device__ inline KParams run_params(RunParamsC* ka)
 // tile with the Agent.state rows mirrored in what is left of the CU's 160 KB; T = 256 (several worlds per CU) the one-wave tile
 // reading its rows back from L2.
 constexpr size_t kRunLdsBudget = 160 * 1024;
-__host__ __device__ constexpr int run_groups(int T) { return T == 1024 ? 4 : 0; }
-__host__ __device__ constexpr size_t run_mirror_budget(int T) { return T == 512 ? kRunLdsBudget : 0; }
-__host__ __device__ constexpr int run_cbrains(int T, int n_brains) { return T == 512 ? n_brains : 0; }   // the hand-scheduled tile keeps its epilogue constants in LDS
+__host__ __device__ constexpr int run_groups(int T) { return 0; }   // (round 2: four blocks for the 4-wave tile of 1024-thread workgroups; round 4: policy_quad needs none)
+__host__ __device__ constexpr size_t run_mirror_budget(int T) { return T >= 512 ? kRunLdsBudget : 0; }
+__host__ __device__ constexpr int run_cbrains(int T, int n_brains) { return T >= 512 ? n_brains : 0; }   // the hand-scheduled tiles keep their epilogue constants in LDS
+template <int KIND> __host__ __device__ constexpr int run_tile_floats(int T) { return T == 1024 ? kQuadFloats : run_pair_floats<KIND>(); }
 template <bool FIXED, int KIND>
 __device__ inline void run_carve(const KParams& p, Smem& s, PolSmem& ps, char* smem_raw, int T)
 {
     const size_t o0 = FIXED ? carve(s, smem_raw, kFixCp, kFixCap, kFixHash, plane_words(run_plane_stride(T, kFixW, kFixH), kFixH, kFixCp))
                             : carve(s, smem_raw, p.Cp, p.cap, p.hash_size, plane_words(p.PS, p.H, p.Cp));
-    carve_policy<KIND>(ps, smem_raw, o0, p.cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, p.n_brains));
-}
-
-template <int T, int KIND, int TRAIN>
-__device__ __forceinline__ void run_policy(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base)
-{
-    constexpr int GROUPS = T / 256;
-    const int tid = rl_tidx(), lane = tid & 63, wave = tid >> 6, grp = wave >> 2, v = wave & 3, j = lane & 31;
-#ifdef RL_PHASE_PROFILE
-    if (p.prof && (int)blockIdx.x == p.prof_world && rl_tidx() == 0) p.prof[100] = (long long)clock64();
-#endif
-    if (wave == 0) {   // rows grouped by brain (ballots; lane b keeps brain b's count), tiles of 32 rows per brain
-        int cnt = 0;
-        for (int base = 0; base < n; base += 64) {
-            const int k = base + lane;
-            const int b = k < n ? s.brain[k] : -1;
-            for (int bb = 0; bb < p.n_brains; ++bb) { const int c = __popcll(__ballot(b == bb)); if (lane == bb) cnt += c; }
-        }
-        const int mine = lane < p.n_brains ? cnt : 0;
-        const int incl = wave_incl_scan(mine);
-        const int tiles = (mine + 31) >> 5;
-        const int tincl = wave_incl_scan(tiles);
-        if (lane < p.n_brains) { ps.bstart[lane] = incl - mine; ps.bcnt[lane] = mine; ps.tstart[lane] = tincl - tiles; }
-        if (lane == 63) ps.meta[0] = tincl;
-        int pos = incl - mine;
-        for (int base = 0; base < n; base += 64) {
-            const int k = base + lane;
-            const int b = k < n ? s.brain[k] : -1;
-            for (int bb = 0; bb < p.n_brains; ++bb) {
-                const unsigned long long m = __ballot(b == bb);
-                const int start = read_lane(pos, bb);
-                if (b == bb) ps.prow[start + __popcll(m & lowmask(lane))] = (short)k;
-                if (lane == bb) pos += __popcll(m);
-            }
-        }
-    }
-    lds_barrier();
-    int ntiles = __builtin_amdgcn_readfirstlane(ps.meta[0]);
-    {   // measurement only (run mask & 4 / & 8): run at most 2 / 1 tiles (results WRONG)
-        const int dbg = *(const int __attribute__((address_space(4)))*)&ka->ra.debug;
-        if (dbg & 4) ntiles = min(ntiles, 2);
-        if (dbg & 8) ntiles = min(ntiles, 1);
-    }
-    for (int t0 = 0; t0 < ntiles; t0 += GROUPS) {   // uniform trip count: every group runs the same barriers
-        const int ti = t0 + grp;
-        const bool have = ti < ntiles;
-        int b = 0;
-        if (have) for (int bb = 1; bb < p.n_brains; ++bb) if (ps.tstart[bb] <= ti && ps.bcnt[bb] > 0) b = bb;
-        b = __builtin_amdgcn_readfirstlane(b);   // uniform per wave: the brain's arguments come by scalar loads
-        const int cntb = have ? ps.bcnt[b] : 0;
-        const int li = have ? (ti - ps.tstart[b]) * 32 + j : 0;
-        const bool valid = have && li < cntb;
-        const int k = (have && cntb > 0) ? ps.prow[ps.bstart[b] + min(li, cntb - 1)] : 0;
-        TileIO io;
-        io.packed = (gfloat*)((const float* const __attribute__((address_space(4)))*)ka->ra.packed)[b];
-        io.obs = obs_rows;
-        io.row = (int64_t)w * p.cap + k;
-        io.valid = valid;
-        io.eps = run_eps<TRAIN>(ka, b, p.n_brains, ps);
-        io.out = TRAIN == 2 ? *(float* const __attribute__((address_space(4)))*)&ka->ra.policy_out : nullptr;
-        io.actions = *(int8_t* const __attribute__((address_space(4)))*)&ka->ra.actions;
-        io.seed = p.seed;
-        io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
-        io.key_index = (uint32_t)k;
-        io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
-        io.x_lds_off = -1; io.c_lds_off = -1;
-#ifdef RL_PHASE_PROFILE
-        io.prof = (p.prof && (int)blockIdx.x == p.prof_world) ? p.prof : nullptr;
-        if (io.prof && rl_tidx() == 0) io.prof[101] = (long long)clock64();
-#endif
-        policy_tile<KIND, false, RL_RUN_COHERENT>(io, pol_h<KIND>(ps, grp), pol_aux<KIND>(ps, grp), pol_part<KIND>(ps, grp), lane, v);
-    }
+    carve_policy<KIND>(ps, smem_raw, o0, p.cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, p.n_brains), run_tile_floats<KIND>(T));
 }
 
 // Rows of a world grouped by brain, 32-row tiles per brain, by ONE wave: trow / tbrain / tstart / bcnt / meta[0].  `brain_of(k)`:
@@ -414,10 +324,11 @@ __device__ inline void policy_schedule_wave0(const KParams& p, PolSmem& ps, RunP
     }
 }
 
-// The policy half for workgroups of at most 512 threads (the tiles below need the 256-VGPR budget).  T = 512, up to four tiles: TWO waves per
-// tile on one SIMD (policy_tile1s<PAIR>); five to eight tiles: one hand-scheduled tile per wave (policy_tile1s); T = 256: one
-// policy_tile1 per wave (no LDS, no barrier inside a tile), wave i takes tiles i, i + 4, ...  Tile rows, validity and brain come from the
-// descriptors wave 0 wrote next to the row lists (policy_lists_wave0).
+// The policy half of the dueling-kind kernels.  T = 512 (256 VGPRs per wave), up to four tiles: TWO waves per tile on one SIMD
+// (policy_tile1s<PAIR>); five to eight tiles: one hand-scheduled tile per wave (policy_tile1s); T = 256: one policy_tile1 per
+// wave (no LDS, no barrier inside a tile), wave i takes tiles i, i + 4, ...; T = 1024 (128 VGPRs per wave): FOUR waves per tile on one SIMD
+// (policy_quad), rounds of four tiles.  Tile rows, validity and brain come from the descriptors wave 0 wrote next to the
+// row lists (policy_lists_wave0).
 template <int T, int KIND, int TRAIN>
 __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base, int wave)
 {
@@ -436,7 +347,7 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
         if (dbg & 16) ntiles = min(ntiles, 3);
     }
     const bool mirrored = ps.xmirror != nullptr && __builtin_amdgcn_readfirstlane(ps.meta[4]) != 0;
-    auto tile_io = [&](int ti, TileIO& io) {
+    auto tile_io = [&](int ti, TileIO& io, int j) {   // j: tile row of the lane
         const int b = __builtin_amdgcn_readfirstlane(ps.tbrain[ti]);
         const int e = (unsigned short)ps.trow[ti * 32 + j], k = e & 0x7fff;
         io.packed = (gfloat*)((const float* const __attribute__((address_space(4)))*)ka->ra.packed)[b];
@@ -457,6 +368,35 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
         if (io.prof && lane == 0) { io.prof[100] = t_entry; io.prof[110] = (long long)clock64(); }
 #endif
     };
+    if constexpr (T == 1024) {
+        // FOUR waves per tile, all on one SIMD (waves t, t + 4, t + 8, t + 12): policy_quad.  More than four tiles (> 128 agents or an uneven
+        // brain split): rounds of four, rows from memory (the exchange slices alias the mirror; recycle_world drained the rows: meta[5]).
+        const int q = __builtin_amdgcn_readfirstlane(wave >> 2), slot = wave & 3;
+        for (int t0 = 0; t0 < ntiles; t0 += 4) {
+            // (a fresh lane index per round: nothing per-lane can be hoisted out of this loop and kept alive -- spilled -- across the tile)
+            const int lane = rl_lane_fresh(), j = lane & 31;
+            const int ti = t0 + slot;
+            const bool have = ti < ntiles;
+            TileIO io;
+            Tile1Part part;
+            QuadLds ql;
+            ql.pmax = ps.pairv + kQuadFloats * slot; ql.val = ql.pmax + 3 * 32 * 4;
+            ql.ex = (f32x4*)((char*)ps.xmirror + (size_t)kQuadExBytes * slot);
+#ifdef RL_PHASE_PROFILE
+            ql.prof = (p.prof && (int)blockIdx.x == p.prof_world && slot == 0) ? p.prof : nullptr;
+#endif
+            if (have) {
+                tile_io(ti, io, j);
+                if (ntiles > 4) io.x_lds_off = -1;
+                policy_quad<KIND, RL_RUN_COHERENT>(io, lane, q, &ql, &part);
+            } else {
+#pragma unroll
+                for (int i = 0; i < kQuadBarriers; ++i) lds_barrier();
+            }
+            lds_barrier();
+            if (have && q == 0) tile1_finish<KIND>(io, lane, part.head, ql.val[j], part.draw, *(const f32x4*)((const float*)(smem_base + io.c_lds_off) + 768 + 8 + 4 * (lane >> 5)));
+        }
+    } else
     if (T == 512 && ps.pairv != nullptr && ntiles <= 4 && (size_t)ps.xrows * kXStride * sizeof(float) >= 4 * (size_t)kPairExBytes) {
         // TWO waves per tile, on the same SIMD (waves i and i + 4): policy_tile1s<PAIR>
         const int role = __builtin_amdgcn_readfirstlane(wave >> 2), slot = wave & 3;
@@ -467,7 +407,7 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
         pl.val = ps.pairv + kPairFloats * slot; pl.pmax = pl.val + 32;
         pl.ex = (f32x4*)((char*)ps.xmirror + (size_t)kPairExBytes * slot);
         if (have) {
-            tile_io(slot, io);
+            tile_io(slot, io, j);
             policy_tile1s<KIND, RL_RUN_COHERENT, true>(io, lane, role, &pl, &part);
         } else { lds_barrier(); lds_barrier(); }   // (the two exchanges inside the tile)
 #ifdef RL_PHASE_PROFILE
@@ -478,7 +418,7 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
     } else
     for (int ti = wave; ti < ntiles; ti += T / 64) {
         TileIO io;
-        tile_io(ti, io);
+        tile_io(ti, io, j);
         if (T == 512) policy_tile1s<KIND, RL_RUN_COHERENT>(io, lane);
         else policy_tile1<KIND, RL_RUN_COHERENT, true>(io, lane);
     }
@@ -585,8 +525,7 @@ __device__ __forceinline__ void run_policy_half(RunParamsC* ka, int wave)
     const int n = __builtin_amdgcn_readfirstlane(ps.meta[1]), cur = __builtin_amdgcn_readfirstlane(ps.meta[2]);
     const float* obs_in = ((float* const __attribute__((address_space(4)))*)ka->ra.obs)[cur];
     if constexpr (KIND == kKindAll) run_policy_all<T, TRAIN>(p, s, ps, ka, w, n, obs_in, smem_raw, wave);
-    else if constexpr (T <= 512) run_policy1<T, KIND, TRAIN>(p, s, ps, ka, w, n, obs_in, smem_raw, wave);
-    else run_policy<T, KIND, TRAIN>(p, s, ps, ka, w, n, obs_in, smem_raw);
+    else run_policy1<T, KIND, TRAIN>(p, s, ps, ka, w, n, obs_in, smem_raw, wave);
 }
 
 // The observation planes of the post-UPDATE grid are the post-step planes with two kinds of cells changed: a corpse's cell holds Food now
@@ -858,9 +797,10 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
     if (p.uo.src)
         for (int k = tid; k < n2; k += T) p.uo.src[b + k] = refill ? (short)-1 : s.src[s.order[k]];
     const RecycleRegs rr = recycle_read(s, n2);
-    if (T <= 512) {   // wave 0 prepares the next tick's policy (rows grouped by brain) while the others write the Agent.state rows
+    {   // wave 0 prepares the next tick's policy (rows grouped by brain) while the others write the Agent.state rows
         if (tid < 64) {
             policy_lists_wave0(p, ps, n2, tid, [&](int k) { return s.brain[s.order[k]]; });
+            if (T == 1024 && tid == 0) ps.meta[5] = ps.meta[0] > 4;   // rounds of four tiles read their rows from memory: drain them
             RL_MARK_T(96, 0);
             if constexpr (KIND == kKindAll) policy_schedule_wave0(p, ps, ka, tid);
             RL_MARK_T(97, 0);
@@ -868,14 +808,13 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
             write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n2, obs_out, tid - 64, ps.xmirror, ps.xrows);
             RL_MARK_T(98, 64); RL_MARK_T(99, T - 64);
         }
-    } else
-        write_observations<T>(p, s, w, n2, obs_out, ps.xmirror, ps.xrows);
+    }
     RL_MARK(68);
     if (tid == 0) { ps.meta[1] = n2; ps.meta[2] = cur ^ 1; ps.meta[3] = ticks_done + 1; ps.meta[4] = ps.xmirror != nullptr; }
     // (rows the policy will read back from memory must have reached L2 first; with every row mirrored in LDS the stores just drain)
     // (capture copies the rows the policy read back from memory a tick later: they must have arrived)
     recycle_world<T, kSpec>(p, s, n2, tick_next, epoch_next, next_uid, max_gene, ps.xmirror == nullptr || n2 > ps.xrows || (TRAIN == 2 && cap), rr,
-                            KIND == kKindAll ? &ps.meta[5] : nullptr);   // (tiles that take several rounds read their rows from memory)
+                            (KIND == kKindAll || T == 1024) ? &ps.meta[5] : nullptr);   // (tiles that take several rounds read their rows from memory)
     RL_MARK(69);
 }
 
@@ -954,6 +893,11 @@ __device__ __forceinline__ void run_load_call(RunParamsC* ka)   // (inlined: loa
             for (int u = 0; u < U; ++u) put_rows(base + u * NT + pt, rv[u]);
         }
     }
+    if (preload && pt >= 0)   // (the rows' zero padding: write_observations)
+        for (int r = pt; r < n_pre; r += NT) {
+            float* m = ps.xmirror + r * kXStride + 153;
+            m[0] = 0.0f; m[1] = 0.0f; m[2] = 0.0f; *(float4*)(m + 3) = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
     RL_MARK(92);
     if (tid == 0) { ps.meta[1] = n0; ps.meta[2] = first; ps.meta[3] = 0; ps.meta[4] = preload ? 1 : 0; }
     if (TRAIN && p.so.trk_tick) {   // the Tracker's running sums live in LDS for the length of the launch
@@ -962,9 +906,10 @@ __device__ __forceinline__ void run_load_call(RunParamsC* ka)   // (inlined: loa
         if (t < G * RL_TRK_VARS) { ps.trk.sum[t] = p.so.trk_sum[o + t]; ps.trk.cnt[t] = p.so.trk_cnt[o + t]; }
         if (t < 2) ps.trk.pop[t] = p.so.trk_pop[(size_t)blockIdx.x * 3 + 1 + t];
     }
-    if (T <= 512 && tid < 64) {
+    if (tid < 64) {
         if constexpr (KIND == kKindAll) { if (tid < kRunMaxBrains) ps.bkind[tid] = tid < p.n_brains ? ((const int __attribute__((address_space(4)))*)ka->ra.kind)[tid] : RL_D3QN; }
         policy_lists_wave0(p, ps, n0, tid, [&](int k) { return s.brain[k]; });   // (slot == list index after load_world)
+        if (T == 1024 && tid == 0) ps.meta[5] = ps.meta[0] > 4;
         if constexpr (KIND == kKindAll) policy_schedule_wave0(p, ps, ka, tid);
     }
     RL_MARK(93);
@@ -1077,7 +1022,7 @@ static size_t run_smem_bytes(const rl_world* h, int T, int stride, int* xrows = 
 {
     PolSmem ps;
     const size_t world = rl_world_smem_bytes(h->cpad, h->cfg.slot_cap, h->hash_size, stride, h->cfg.height);
-    const size_t b = carve_policy<KIND>(ps, nullptr, world, h->cfg.slot_cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, h->cfg.n_brains));
+    const size_t b = carve_policy<KIND>(ps, nullptr, world, h->cfg.slot_cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, h->cfg.n_brains), run_tile_floats<KIND>(T));
     if (xrows) *xrows = ps.xrows;
     return b;
 }
@@ -1109,7 +1054,15 @@ int rl_world_run_supported(const rl_world* h, const rl_brain* brains, int n_brai
         if (run_smem_bytes<kKindAll>(h, T, host_plane_stride<kKindAll>(h, T), &xrows) > 160 * 1024) return 0;
         return (size_t)xrows * kXStride * sizeof(float) >= (size_t)pair_ex_bytes(RL_PPO);   // (at least one tile per round)
     }
-    return run_smem_bytes<RL_PERD3QN>(h, T, host_plane_stride<RL_PERD3QN>(h, T)) <= 160 * 1024;
+    int xrows = 0;
+    if (run_smem_bytes<RL_PERD3QN>(h, T, host_plane_stride<RL_PERD3QN>(h, T), &xrows) > 160 * 1024) return 0;
+    // 1024 threads: the four-wave tiles' exchange slices (24 KB each) lie in the mirror
+    if (T == 1024 && (size_t)xrows * kXStride * sizeof(float) < 4 * (size_t)kQuadExBytes) {
+        rl_set_error("rl_run: 1024-thread workgroups need %zu bytes of mirror for the tiles' exchange slices, this world leaves %zu (%d rows)",
+                     4 * (size_t)kQuadExBytes, (size_t)xrows * kXStride * sizeof(float), xrows);
+        return 0;
+    }
+    return 1;
 }
 int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n_ticks, int8_t* actions, const rl_step_out* so,
                         float* const obs[2], int first, int16_t* upd_src, int refill_threshold, int refill_n_agents,

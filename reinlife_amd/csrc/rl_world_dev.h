@@ -776,7 +776,13 @@ __device__ __forceinline__ void write_observations(const KParams& p, Smem& s, in
         const float v4 = (s.flags[a] & RL_F_KILLED) ? 1.f : 0.f;
         const float v5 = (s.flags[a] & RL_F_ATE_SUPER) ? 1.f : -1.f;
         o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4; o[5] = v5;
-        if (mirror && k < xrows) { float* m = mirror + k * kXStride + 147; m[0] = v0; m[1] = v1; m[2] = v2; m[3] = v3; m[4] = v4; m[5] = v5; }
+        if (mirror && k < xrows) {
+            float* m = mirror + k * kXStride + 147;
+            m[0] = v0; m[1] = v1; m[2] = v2; m[3] = v3; m[4] = v4; m[5] = v5;
+            // floats 153 .. 159 of a mirror row are the zero padding of the input layer's last K-chunk (the four-wave tile reads the chunk
+            // as it lies; the tiles' exchange buffers alias the mirror, so the padding is rewritten with the row)
+            m[6] = 0.0f; m[7] = 0.0f; m[8] = 0.0f; *(float4*)(m + 9) = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
     }
 }
 template <int T>

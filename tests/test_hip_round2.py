@@ -412,8 +412,6 @@ def test_multi_tick_launch_equals_the_two_launch_loop(static, block, hip_option)
     # rl_run's workgroups run the one-wave policy tile (policy_tile1); the stand-alone launch uses it too when asked to, and
     # then the two paths must agree bit for bit (with its default 4-wave tile they agree to ~1e-7 in Q, like any two float32
     # summation orders)
-    if block == 1024:   # k_run<1024> runs the 4-wave tile of rounds 1-2: its stand-alone counterpart is the `nsplit` variant
-        hip_option("policy_variant", "nsplit")
     (fused, loop), *_ = _run_pair(20, static, 555)
     assert fused.run_supported()
     done = 0
@@ -495,8 +493,6 @@ def test_multi_tick_launch_other_shapes_and_the_sequential_update(width, height,
     from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights
     if block:
         hip_option("world_block", block)
-    if block == 1024:   # k_run<1024> runs the 4-wave tile of rounds 1-2: its stand-alone counterpart is the `nsplit` variant
-        hip_option("policy_variant", "nsplit")
     R = 10
     cfg = dict(width=width, height=height, max_agents=max_agents, n_brains=2, static_families=True, limit_reproduction=limit, incentivize_killing=True)
     wts = [_weights("PERD3QN", 7), _weights("D3QN", 8)]

@@ -31,8 +31,6 @@ def test_training_launch_equals_the_two_launch_loop(static, block, hip_option):
     of 1 / 3 / 20 / 37 ticks, with the caller zeroing the running sums between some of them (interval boundaries)."""
     if block:
         hip_option("world_block", block)
-    if block == 1024:   # k_run<1024> runs the 4-wave tile of rounds 1-2: its stand-alone counterpart is the `nsplit` variant
-        hip_option("policy_variant", "nsplit")
     (fused, loop), *_ = _run_pair(14, static, 4242)
     for dw in (fused, loop):
         dw.enable_tracking(True)
@@ -461,8 +459,6 @@ def test_capture_inside_the_multi_tick_launch(names, eps, static, block, hip_opt
     worlds' transitions interleave by atomics in both paths, so a tick's transitions are compared as sets; counts and worlds exactly."""
     if block:
         hip_option("world_block", block)
-    if block == 1024:
-        hip_option("policy_variant", "nsplit")
     (fused, loop), wts, cfg = _kind_pair(names, eps, 9, static, 31)
     for dw in (fused, loop):
         dw.enable_capture(capacity=40_000, with_prob=True)
