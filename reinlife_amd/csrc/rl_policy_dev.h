@@ -1354,8 +1354,12 @@ struct WRingQ {
 #pragma unroll
         for (int pl = 0; pl < kPlanes; ++pl) ac[pl] = a[cur][pl];
         if (i + D < NS) {
+#ifdef RL_ABL_HALFW   /* tuning experiment: half the weight bytes (the lo plane is the hi plane; results WRONG) */
+            a[cur][0] = p[0]; a[cur][1] = a[cur][0];
+#else
 #pragma unroll
             for (int pl = 0; pl < kPlanes; ++pl) a[cur][pl] = p[pl * 64];
+#endif
             p += TOUT * kPlanes * 64;
             asm volatile("" : "+v"(p));
         }

@@ -67,6 +67,7 @@ struct PolSmem {
     float* cconst;      // [n_brains][3][256] epilogue constants of the brains' three 128-wide layers for policy_tile1s (T = 512), or null
     float* xmirror;     // [xrows][kXStride] Agent.state rows of this world for the one-wave policy tile (T <= 512), or null
     int xrows;
+    int xbytes;         // bytes reserved for the mirror: xrows rows, or more where the tiles' exchange slices (which alias it) need more
     double* trk_scr;    // [cap] scratch of the Tracker pass (track_world_wave0)
     TrkLds trk;         // the Tracker's running sums for the length of the launch
     // kKindAll kernels: the policy half's schedule, written by wave 0 next to the row lists (policy_schedule_wave0).  meta[5]: 0 = every
@@ -85,17 +86,21 @@ template <int KIND> __host__ __device__ constexpr int run_const_floats() { retur
 template <int KIND> __host__ __device__ constexpr int run_pair_floats() { return KIND == kKindAll ? kPairFloatsAll : kPairFloats; }
 template <int KIND>
 __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o, int cap, int groups, size_t mirror_budget = 0, int n_cbrains = 0,
-                                               int pair_floats = run_pair_floats<KIND>())   // per tile: the tile waves' small exchanges (kQuadFloats for the four-wave tile)
+                                               int pair_floats = run_pair_floats<KIND>(),   // per tile: the tile waves' small exchanges (kQuadFloats for the four-wave tile)
+                                               size_t min_region = 0)                       // the four-wave tiles' exchange slices: the mirror's region is at least this large
 {
     o = align16(o);
-    ps.xmirror = nullptr; ps.xrows = 0;
+    ps.xmirror = nullptr; ps.xrows = 0; ps.xbytes = 0;
     // what follows the mirror: row lists and tile descriptors (2 * cap + ~3.5 KB), the Tracker's scratch and sums (8 * cap + ~0.8 KB), ...
     const size_t tail = 10 * (size_t)cap + 5120 + sizeof(float) * 4 * (size_t)pair_floats + sizeof(float) * run_const_floats<KIND>() * (size_t)n_cbrains;
     if (groups == 0 && mirror_budget > o + tail) {
         const size_t rows = (mirror_budget - o - tail) / (sizeof(float) * kXStride);
         ps.xrows = (int)(rows < (size_t)cap ? rows : (size_t)cap);
-        if (ps.xrows >= 32) { ps.xmirror = (float*)(base + o); o = align16(o + sizeof(float) * kXStride * (size_t)ps.xrows); }
-        else ps.xrows = 0;
+        if (ps.xrows >= 32) {
+            size_t bytes = sizeof(float) * kXStride * (size_t)ps.xrows;
+            if (bytes < min_region && o + tail + min_region <= mirror_budget) bytes = min_region;
+            ps.xmirror = (float*)(base + o); ps.xbytes = (int)bytes; o = align16(o + bytes);
+        } else ps.xrows = 0;
     }
     ps.prow = (short*)(base + o); o = align16(o + sizeof(short) * (size_t)cap);
     ps.bstart = (int*)(base + o); o = align16(o + sizeof(int) * 64);
@@ -231,12 +236,13 @@ __host__ __device__ constexpr int run_groups(int T) { return 0; }   // (round 2:
 __host__ __device__ constexpr size_t run_mirror_budget(int T) { return T >= 512 ? kRunLdsBudget : 0; }
 __host__ __device__ constexpr int run_cbrains(int T, int n_brains) { return T >= 512 ? n_brains : 0; }   // the hand-scheduled tiles keep their epilogue constants in LDS
 template <int KIND> __host__ __device__ constexpr int run_tile_floats(int T) { return T == 1024 ? kQuadFloats : run_pair_floats<KIND>(); }
+__host__ __device__ constexpr size_t run_min_region(int T) { return T == 1024 ? 4 * (size_t)kQuadExBytes : 0; }
 template <bool FIXED, int KIND>
 __device__ inline void run_carve(const KParams& p, Smem& s, PolSmem& ps, char* smem_raw, int T)
 {
     const size_t o0 = FIXED ? carve(s, smem_raw, kFixCp, kFixCap, kFixHash, plane_words(run_plane_stride(T, kFixW, kFixH), kFixH, kFixCp))
                             : carve(s, smem_raw, p.Cp, p.cap, p.hash_size, plane_words(p.PS, p.H, p.Cp));
-    carve_policy<KIND>(ps, smem_raw, o0, p.cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, p.n_brains), run_tile_floats<KIND>(T));
+    carve_policy<KIND>(ps, smem_raw, o0, p.cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, p.n_brains), run_tile_floats<KIND>(T), run_min_region(T));
 }
 
 // Rows of a world grouped by brain, 32-row tiles per brain, by ONE wave: trow / tbrain / tstart / bcnt / meta[0].  `brain_of(k)`:
@@ -1018,12 +1024,13 @@ static int run_kind_of(const rl_brain* brains, int n_brains)
 }
 // LDS of a launch with planes of row stride `stride`; host_plane_stride picks the stride: padded where it fits, else row-major
 template <int KIND>
-static size_t run_smem_bytes(const rl_world* h, int T, int stride, int* xrows = nullptr)
+static size_t run_smem_bytes(const rl_world* h, int T, int stride, int* xrows = nullptr, size_t* xbytes = nullptr)
 {
     PolSmem ps;
     const size_t world = rl_world_smem_bytes(h->cpad, h->cfg.slot_cap, h->hash_size, stride, h->cfg.height);
-    const size_t b = carve_policy<KIND>(ps, nullptr, world, h->cfg.slot_cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, h->cfg.n_brains), run_tile_floats<KIND>(T));
+    const size_t b = carve_policy<KIND>(ps, nullptr, world, h->cfg.slot_cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, h->cfg.n_brains), run_tile_floats<KIND>(T), run_min_region(T));
     if (xrows) *xrows = ps.xrows;
+    if (xbytes) *xbytes = (size_t)ps.xbytes;
     return b;
 }
 template <int KIND>
@@ -1055,11 +1062,12 @@ int rl_world_run_supported(const rl_world* h, const rl_brain* brains, int n_brai
         return (size_t)xrows * kXStride * sizeof(float) >= (size_t)pair_ex_bytes(RL_PPO);   // (at least one tile per round)
     }
     int xrows = 0;
-    if (run_smem_bytes<RL_PERD3QN>(h, T, host_plane_stride<RL_PERD3QN>(h, T), &xrows) > 160 * 1024) return 0;
-    // 1024 threads: the four-wave tiles' exchange slices (24 KB each) lie in the mirror
-    if (T == 1024 && (size_t)xrows * kXStride * sizeof(float) < 4 * (size_t)kQuadExBytes) {
-        rl_set_error("rl_run: 1024-thread workgroups need %zu bytes of mirror for the tiles' exchange slices, this world leaves %zu (%d rows)",
-                     4 * (size_t)kQuadExBytes, (size_t)xrows * kXStride * sizeof(float), xrows);
+    size_t xbytes = 0;
+    if (run_smem_bytes<RL_PERD3QN>(h, T, host_plane_stride<RL_PERD3QN>(h, T), &xrows, &xbytes) > 160 * 1024) return 0;
+    // 1024 threads: the four-wave tiles' exchange slices (24 KB each) lie in the mirror's region
+    if (T == 1024 && xbytes < 4 * (size_t)kQuadExBytes) {
+        rl_set_error("rl_run: 1024-thread workgroups need %zu bytes of LDS for the tiles' exchange slices, this world leaves %zu (%d mirror rows)",
+                     4 * (size_t)kQuadExBytes, xbytes, xrows);
         return 0;
     }
     return 1;

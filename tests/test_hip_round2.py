@@ -482,8 +482,9 @@ def test_multi_tick_launch_falls_back_when_unsupported(hip_option):
     _same_device_state(pair[0], pair[1], "fallback")
 
 
-@pytest.mark.parametrize("width,height,max_agents,n_new,thr,limit", [(20, 15, 60, 50, 40, False), (30, 30, 100, 100, 70, True), (12, 9, 20, 18, 12, False)],
-                         ids=["20x15", "30x30-limit_reproduction", "12x9"])
+@pytest.mark.parametrize("width,height,max_agents,n_new,thr,limit", [(20, 15, 60, 50, 40, False), (30, 30, 100, 100, 70, True), (12, 9, 20, 18, 12, False),
+                                                                      (30, 30, 150, 140, 100, False)],
+                         ids=["20x15", "30x30-limit_reproduction", "12x9", "30x30-140agents-six-tiles"])
 @pytest.mark.parametrize("block", [None, 256, 1024], ids=["T512", "T256", "T1024"])
 def test_multi_tick_launch_other_shapes_and_the_sequential_update(width, height, max_agents, n_new, thr, limit, block, hip_option):
     """k_run's generic (not shape-specialised) instantiations and the limit_reproduction path (update_env not overlapped with the

@@ -132,6 +132,54 @@ def test_c5_trainer_instantiation_one_launch_equals_many():
 # ---------------------------------------------------------------------------------------------------------------------
 # one arithmetic on every path: a replica's trajectory does not depend on how many worlds share its GPU
 # ---------------------------------------------------------------------------------------------------------------------
+def test_sixteen_wave_workgroups_equal_eight_wave_workgroups_at_the_benched_size(hip_option):
+    """k_run<1024> (four waves per tile, policy_quad: the same arithmetic per accumulator as the two-wave tiles of k_run<512>) against
+    k_run<512> at 256 worlds: one launch of 120 ticks each, world state, both observation buffers, actions and the last tick's outputs bit
+    for bit -- and the TRAIN instantiation with a per-tick epsilon schedule and the Tracker."""
+    for train in (False, True):
+        a, wl = _worlds("c4", tracking=train)
+        hip_option("world_block", 1024)
+        b, _ = _worlds("c4", tracking=train)
+        hip_option("world_block", None)
+        kw = dict(eps_schedule=_schedule(2, 0, 120), trk_skip=1) if train else {}
+        a.run(120, 70, 100, **kw); b.run(120, 70, 100, **kw)
+        a.check_error_flag(); b.check_error_flag()
+        _same_device_state(a, b, "120 ticks, train=%s" % train)
+        assert int(a.acted_total.item()) == int(b.acted_total.item()) > 2_000_000 and int(a.refill_count.item()) == int(b.refill_count.item()) > 100
+        _cmp_rows(a.actions.cpu().numpy(), b.actions.cpu().numpy(), a.n_acted.cpu().numpy(), "actions")
+        assert np.array_equal(a.obs_state_prime().cpu().numpy(), b.obs_state_prime().cpu().numpy())
+        if train:
+            _same_tracker(a, b, "120 ticks")
+
+
+def test_sixteen_wave_workgroups_with_more_than_four_tiles(hip_option):
+    """Three dueling brains on 120 agents = six 32-row tiles per world: k_run<1024> takes them in two rounds of four-wave tiles with the rows
+    read from memory (the tiles' exchange slices alias the LDS mirror); against the two-launch loop, every tick for 40 ticks."""
+    from reinlife_amd import _lib
+    from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights
+    from test_hip_round2 import _weights
+    hip_option("world_block", 1024)
+    # (24 x 24: with three brains' constants next to a 30 x 30 world the exchange slices no longer fit into LDS -- rl_run says so)
+    cfg = dict(width=24, height=24, max_agents=120, n_brains=3, static_families=True, limit_reproduction=False, incentivize_killing=True)
+    pair = []
+    for _ in range(2):
+        dw = DeviceWorlds(n_worlds=12, seed=31, **cfg)
+        dw.set_brains([(_lib.PERD3QN, 0.0, pack_brain_weights(_lib.PERD3QN, _weights("PERD3QN", 3))),
+                       (_lib.D3QN, 0.1, pack_brain_weights(_lib.D3QN, _weights("D3QN", 4))),
+                       (_lib.PERD3QN, 0.0, pack_brain_weights(_lib.PERD3QN, _weights("PERD3QN", 5)))])
+        dw.reset_synthetic(120)
+        pair.append(dw)
+    fused, loop = pair
+    assert fused.run_supported()
+    for t in range(40):
+        fused.run(1, 90, 120)
+        loop.act(); loop.tick_refill(90, 120)
+        fused.check_error_flag()
+        _same_device_state(fused, loop, "tick %d" % t)
+        _cmp_rows(fused.actions.cpu().numpy(), loop.actions.cpu().numpy(), fused.n_acted.cpu().numpy(), "tick %d actions" % t)
+    assert int(fused.acted_total.item()) == int(loop.acted_total.item()) > 40_000
+
+
 @pytest.mark.parametrize("workload", ["c4", "c5"])
 def test_one_handle_of_1024_worlds_equals_four_handles_of_256(workload):
     """1 x 1,024 worlds (above 768 worlds per handle DeviceWorlds.run loops over rl_policy_act + rl_tick_refill: the stand-alone policy
