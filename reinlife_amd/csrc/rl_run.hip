@@ -55,7 +55,7 @@ struct RunArgs {
 };
 
 struct PolSmem {
-    short* prow;        // [cap] T = 1024: list indices grouped by brain; T <= 512: per list entry, brain << 10 | position in the brain's list
+    short* prow;        // [cap] per list entry: brain << 10 | position in the brain's list
     int* bstart;        // [64] first entry of brain b in prow
     int* bcnt;          // [64]
     int* tstart;        // [64] first tile of brain b
@@ -77,7 +77,7 @@ struct PolSmem {
     int* bkind;         // [8]  the brains' kinds (filled once per launch)
 };
 // With mirror_budget > 0 the Agent.state rows are mirrored in LDS (as many rows as fit below the budget, at most cap); the two- and
-// four-wave tiles' exchange buffers alias the mirror.  (`groups`: LDS blocks of the 4-wave tile of rounds 1-2 in k_run<1024> -- always 0 now.)
+// four-wave tiles' exchange buffers alias the mirror.
 constexpr int kMaxTiles = 32;                // 32-row tiles of one brain per world: <= cap / 32 + n_brains
 constexpr int kPairFloats = 32 + 2 * 64;     // per tile pair: row values, partial row maxima of the two roles
 constexpr int kPairExBytes = 8 * kPlanes * 64 * 16;   // per tile pair: the split activations of the input layer (aliases the Agent.state mirror)
@@ -85,7 +85,7 @@ constexpr int kPairFloatsAll = kPairValFloats + 2 * 64;   // kKindAll: role 1's 
 template <int KIND> __host__ __device__ constexpr int run_const_floats() { return KIND == kKindAll ? kTileConstMax : kTileConstFloats; }
 template <int KIND> __host__ __device__ constexpr int run_pair_floats() { return KIND == kKindAll ? kPairFloatsAll : kPairFloats; }
 template <int KIND>
-__host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o, int cap, int groups, size_t mirror_budget = 0, int n_cbrains = 0,
+__host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o, int cap, size_t mirror_budget = 0, int n_cbrains = 0,
                                                int pair_floats = run_pair_floats<KIND>(),   // per tile: the tile waves' small exchanges (kQuadFloats for the four-wave tile)
                                                size_t min_region = 0)                       // the four-wave tiles' exchange slices: the mirror's region is at least this large
 {
@@ -93,7 +93,7 @@ __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o
     ps.xmirror = nullptr; ps.xrows = 0; ps.xbytes = 0;
     // what follows the mirror: row lists and tile descriptors (2 * cap + ~3.5 KB), the Tracker's scratch and sums (8 * cap + ~0.8 KB), ...
     const size_t tail = 10 * (size_t)cap + 5120 + sizeof(float) * 4 * (size_t)pair_floats + sizeof(float) * run_const_floats<KIND>() * (size_t)n_cbrains;
-    if (groups == 0 && mirror_budget > o + tail) {
+    if (mirror_budget > o + tail) {
         const size_t rows = (mirror_budget - o - tail) / (sizeof(float) * kXStride);
         ps.xrows = (int)(rows < (size_t)cap ? rows : (size_t)cap);
         if (ps.xrows >= 32) {
@@ -228,11 +228,10 @@ __device__ inline KParams run_params(RunParamsC* ka)
     }
     return p;
 }
-// LDS of the multi-tick kernel per workgroup size: T = 1024 runs the 4-wave policy tile (four tile blocks); T = 512 the one-wave
-// tile with the Agent.state rows mirrored in what is left of the CU's 160 KB; T = 256 (several worlds per CU) the one-wave tile
-// reading its rows back from L2.
+// LDS of the multi-tick kernel per workgroup size: T >= 512 (one world per CU) mirrors the Agent.state rows in what is left of the CU's
+// 160 KB -- the two-wave (T = 512) and four-wave (T = 1024) tiles read their rows there, and their exchange buffers alias it; T = 256
+// (several worlds per CU) runs the one-wave tile, which reads its rows back from L2.
 constexpr size_t kRunLdsBudget = 160 * 1024;
-__host__ __device__ constexpr int run_groups(int T) { return 0; }   // (round 2: four blocks for the 4-wave tile of 1024-thread workgroups; round 4: policy_quad needs none)
 __host__ __device__ constexpr size_t run_mirror_budget(int T) { return T >= 512 ? kRunLdsBudget : 0; }
 __host__ __device__ constexpr int run_cbrains(int T, int n_brains) { return T >= 512 ? n_brains : 0; }   // the hand-scheduled tiles keep their epilogue constants in LDS
 template <int KIND> __host__ __device__ constexpr int run_tile_floats(int T) { return T == 1024 ? kQuadFloats : run_pair_floats<KIND>(); }
@@ -242,7 +241,7 @@ __device__ inline void run_carve(const KParams& p, Smem& s, PolSmem& ps, char* s
 {
     const size_t o0 = FIXED ? carve(s, smem_raw, kFixCp, kFixCap, kFixHash, plane_words(run_plane_stride(T, kFixW, kFixH), kFixH, kFixCp))
                             : carve(s, smem_raw, p.Cp, p.cap, p.hash_size, plane_words(p.PS, p.H, p.Cp));
-    carve_policy<KIND>(ps, smem_raw, o0, p.cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, p.n_brains), run_tile_floats<KIND>(T), run_min_region(T));
+    carve_policy<KIND>(ps, smem_raw, o0, p.cap, run_mirror_budget(T), run_cbrains(T, p.n_brains), run_tile_floats<KIND>(T), run_min_region(T));
 }
 
 // Rows of a world grouped by brain, 32-row tiles per brain, by ONE wave: trow / tbrain / tstart / bcnt / meta[0].  `brain_of(k)`:
@@ -1028,7 +1027,7 @@ static size_t run_smem_bytes(const rl_world* h, int T, int stride, int* xrows = 
 {
     PolSmem ps;
     const size_t world = rl_world_smem_bytes(h->cpad, h->cfg.slot_cap, h->hash_size, stride, h->cfg.height);
-    const size_t b = carve_policy<KIND>(ps, nullptr, world, h->cfg.slot_cap, run_groups(T), run_mirror_budget(T), run_cbrains(T, h->cfg.n_brains), run_tile_floats<KIND>(T), run_min_region(T));
+    const size_t b = carve_policy<KIND>(ps, nullptr, world, h->cfg.slot_cap, run_mirror_budget(T), run_cbrains(T, h->cfg.n_brains), run_tile_floats<KIND>(T), run_min_region(T));
     if (xrows) *xrows = ps.xrows;
     if (xbytes) *xbytes = (size_t)ps.xbytes;
     return b;
