@@ -15,6 +15,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _seeded_torch():
+    """Brains built with `Models.X()` take their initial weights from torch's global generator: seed it per test, so that a run's outcome
+    (which agents eat, whether a three-agent tester() world survives its 25 ticks) does not depend on the process."""
+    import torch
+    torch.manual_seed(20260929)
+    yield
+
+
 @pytest.fixture
 def hip_option():
     """hip_option(name, value): a process-level option of the HIP library (rl_set_option; handles created afterwards snapshot it),

@@ -49,8 +49,11 @@ def test_environment_protocol_matches_oracle_with_per_agent_actions():
 
 
 def test_trainer_and_tester_run_the_batched_loop():
+    import torch
     from reinlife_amd import Models, tester, trainer
     np.random.seed(3)
+    torch.manual_seed(3)   # the brains' initial weights: tester()'s three agents starve at tick 20 unless they eat, and with unseeded weights
+                           # they all did in 1 of 40 runs (the assertion on the last frame needs a living agent)
     env = trainer([Models.PERD3QN(), Models.PERD3QN()], n_episodes=40, width=30, height=30, max_agents=100,
                   static_families=True, save=False, print_results=False, n_worlds=4)
     assert env.worlds.s["tick"].cpu().numpy().tolist() == [41] * 4
