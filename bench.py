@@ -6,6 +6,9 @@
     --nproc-per-node N ... bench.py --gpus N ...) this process is one rank; started plainly with --gpus N > 1 it re-executes
     itself under torch.distributed.run with N ranks.  The JSON carries `rccl_ranks` = the world size RCCL saw; a mismatch with
     --gpus is an error, never a silent single-rank run.
+    Dry run of the N > 1 path on ONE GPU (tests/test_hip_round5.py): --dist-backend gloo --share-gpu puts every rank on cuda:0 and
+    sends the (host-hopped) collectives through gloo; the line then says "dist_backend": "gloo" and "rccl_ranks": 0 -- it exercises
+    every line of the multi-rank code except RCCL itself and the device index, and is no evidence about scaling.
 
 One "step" = one trainer-loop tick (Helpers/trainer.py:85-99 minus learn) of EVERY world on the GPU:
     policy forward + action selection for all agents  ->  step + update_env  ->  re-generation of worlds below 70 agents
@@ -225,11 +228,132 @@ def api_trainer(args, device, dist=None, rank=0):
             "timed": "the loop inside trainer() (env.loop_seconds), device idle before and after; agent-steps from the device counter"}
 
 
-def c5_leg(args, rank, device):
-    """BASELINE configs[4]'s per-GPU workload next to the main line: PPO + PERD3QN mixed brains, static_families=False (the mixed-kind
+# the reference's own CPU path, measured at survey time by importing it (Python 3.10, 1 thread of 8 host cores of the
+# survey container; it cannot travel to the GPU box): agent-steps/s.  Context for `single_world`, not measured in this run.
+REFERENCE_SURVEY_FIGURES = {"C1 trainer([PERD3QN(),PERD3QN()]) natural population, full loop incl. learn": 1300, "C1 get_action + step only": 2600,
+                            "C2 100 agents, random actions, env.step only": 10400, "C2 step + update_env": 5900,
+                            "C3 100 agents, DQN forward + step": 7100, "C3 with update_env": 4700,
+                            "source": "BASELINE.md section 2 (survey-time, reference imported read-only, 1 core)"}
+
+
+def single_world(args, device):
+    """BASELINE configs[1] / configs[2] and the literal drop-in default as throughput figures (parity for them lives in tests/): ONE 30x30
+    world on one MI355X -- one workgroup on one of 256 CUs, so these are latency figures of a single world, not a use of the chip.
+      c2: 100 agents (re-generated below 70), uniform random actions, Environment.step only (rl_step between HIP events; update_env + refill
+          run untimed between the pairs) -- SURVEY.md 8d C2;
+      c3: the same world, two greedy DQN brains (153 -> 128 -> 64 -> 8), policy forward + step + update_env in the multi-tick launch (rl_run) -- C3;
+      trainer_default: trainer([DQN(max_epi=300), DQN(max_epi=300)], n_episodes=300, save=False, print_results=False) with NO extra
+          keyword -- n_worlds=1 -> rng="reference": the host makes the reference's draws from `random` / np.random tick by tick
+          (Helpers/trainer.py, reference loop trainer.py:85-99), natural population (two families, one agent each at reset);
+      trainer_configs0: BASELINE configs[0]'s literal call, trainer([PERD3QN(), PERD3QN()], width=30, height=30, max_agents=100,
+          static_families=True, n_episodes=300, save=False, print_results=False).
+    ~0.1 s of GPU time + the two host-driven loops (~1 s)."""
+    import random
+    import warnings
+    from reinlife_amd import Models
+    from reinlife_amd.Helpers.trainer import trainer
+    out = {"reference_cpu_survey_time": REFERENCE_SURVEY_FIGURES}
+    one = argparse.Namespace(**dict(vars(args), worlds=1))
+
+    # ---- c2: random actions, step only --------------------------------------------------------------------------------------
+    dw = DeviceWorlds(n_worlds=1, width=30, height=30, max_agents=100, n_brains=2, static_families=True, seed=args.seed, device=device)
+    dw.reset_synthetic(100)
+    n = 400
+    acts = torch.randint(0, 8, (n + 20, 1, dw.cap), dtype=torch.int8, device=device, generator=torch.Generator(device).manual_seed(args.seed))
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(n)]
+    acted, t0 = [], None
+    for t in range(n + 20):
+        if t == 20:
+            torch.cuda.synchronize()
+            dw.acted_total.zero_()
+            t0 = time.perf_counter()
+        dw.actions.copy_(acts[t])
+        if t >= 20:
+            ev[t - 20][0].record()
+        dw.step()
+        if t >= 20:
+            ev[t - 20][1].record()
+        dw.update(); dw.refill(70, 100)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dw.check_error_flag()
+    steps = int(dw.acted_total.item())
+    t_step = float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e-3
+    out["c2"] = {"workload": "1 world x 30x30 x 100 agents (refill below 70), uniform random actions (BASELINE configs[1])",
+                 "step_only": {"value": round(steps / n / t_step, 1), "unit": "agent-steps/s", "us_per_step": round(t_step * 1e6, 2),
+                               "timed": "rl_step (Environment.step) between HIP events, median of %d; update_env + refill untimed between the pairs" % n},
+                 "host_loop": {"value": round(steps / wall, 1), "unit": "agent-steps/s", "us_per_tick": round(wall / n * 1e6, 2),
+                               "timed": "wall clock over %d ticks of copy-actions + rl_step + rl_update + rl_refill launched from Python (4 launches per tick, no synchronise inside)" % n},
+                 "mean_agents": round(steps / n, 1)}
+    del dw
+
+    # ---- c3: two greedy DQN brains, the multi-tick launch ----------------------------------------------------------------------
+    dw = DeviceWorlds(n_worlds=1, width=30, height=30, max_agents=100, n_brains=2, static_families=True, seed=args.seed, device=device)
+    dw.set_brains([(_lib.DQN, 0.0, pack_brain_weights(_lib.DQN, brain_weights("DQN", 100 + k), device)) for k in range(2)])
+    dw.reset_synthetic(100)
+    n = 2000
+    res = {"workload": "1 world x 30x30 x 100 agents (refill below 70), 2 x DQN 153->128->64->8 greedy, policy forward + step + update_env (BASELINE configs[2])"}
+    if dw.run_supported():
+        dw.run(n, 70, 100)
+        torch.cuda.synchronize()
+        dw.acted_total.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(); dw.run(n, 70, 100); e1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        steps = int(dw.acted_total.item())
+        res.update({"value": round(steps / wall, 1), "unit": "agent-steps/s", "us_per_tick": round(wall / n * 1e6, 2),
+                    "kernel_us_per_tick": round(e0.elapsed_time(e1) * 1e-3 / n * 1e6, 2), "mean_agents": round(steps / n, 1),
+                    "timed": "wall clock around ONE rl_run launch of %d ticks + synchronise (one workgroup, the world resident in its LDS)" % n})
+    dw.acted_total.zero_()
+    m = 300
+    for _ in range(20):
+        one_step(dw)
+    torch.cuda.synchronize()
+    dw.acted_total.zero_()
+    t0 = time.perf_counter()
+    for _ in range(m):
+        one_step(dw)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dw.check_error_flag()
+    steps = int(dw.acted_total.item())
+    res["two_launch"] = {"value": round(steps / wall, 1), "unit": "agent-steps/s", "us_per_tick": round(wall / m * 1e6, 2),
+                         "timed": "wall clock over %d ticks of rl_policy_act + rl_tick_refill launched from Python (what Environment.act/step/update_env cost per tick without the fused loop)" % m}
+    out["c3"] = res
+    del dw
+
+    # ---- the drop-in defaults: trainer(brains, ...) exactly as a user of the reference calls it -----------------------------------------
+    def call(make, n_epi, **kw):
+        random.seed(args.seed); np.random.seed(args.seed % (2 ** 32)); torch.manual_seed(args.seed)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            env = trainer(make(), n_episodes=n_epi, save=False, print_results=False, **kw)
+        steps = int(env.worlds.acted_total.item())
+        return {"value": round(steps / env.loop_seconds, 1), "unit": "agent-steps/s", "episodes": n_epi + 1,
+                "us_per_tick": round(env.loop_seconds / (n_epi + 1) * 1e6, 1), "mean_agents": round(steps / (n_epi + 1), 2),
+                "rng": env.rng, "n_worlds": env.n_worlds, "device": str(env.device),
+                "timed": "the loop inside trainer() (env.loop_seconds); agent-steps from the device counter"}
+    dqn = lambda: [Models.DQN(max_epi=300), Models.DQN(max_epi=300)]  # noqa: E731
+    call(dqn, 30)   # warm-up: first launches of the tick-by-tick kernels, the brains' first forward
+    r = call(dqn, 300)
+    r["call"] = "trainer([DQN(max_epi=300), DQN(max_epi=300)], n_episodes=300, save=False, print_results=False)"
+    out["trainer_default"] = r
+    r = call(lambda: [Models.PERD3QN(), Models.PERD3QN()], 300, width=30, height=30, max_agents=100, static_families=True)
+    r["call"] = "trainer([PERD3QN(), PERD3QN()], width=30, height=30, max_agents=100, static_families=True, n_episodes=300, save=False, print_results=False)  [BASELINE configs[0]]"
+    out["trainer_configs0"] = r
+    return out
+
+
+def c5_leg(args, rank, device, dist=None):
+    """BASELINE configs[4] next to the main line -- on EVERY rank: PPO + PERD3QN mixed brains, static_families=False (the mixed-kind
     multi-tick kernel, k_run<512, fixed, kKindAll>; PPO.py:101-106,164-169, PERD3QN.py:198-210, environment.py:521-547,728-739), the
-    same synthetic worlds and refill rule, 256 worlds per GPU.  ~60 ms of GPU time: 1000 untimed ticks, then one 1000-tick launch
-    between HIP events and a wall clock."""
+    same synthetic worlds and refill rule, 256 worlds per GPU at global replica ids rank * 256 ... (2048 replicas on 8
+    GPUs).  ~60 ms of GPU time per rank: 1000 untimed ticks, then one 1000-tick launch between HIP events and a wall clock, the ranks
+    released together by a barrier.  With a process group the figures are whole-job -- every rank's agent-steps over the SLOWEST rank's
+    wall time, reduced by the same one-collective row gather as the main line -- with the per-rank table beside them; `roofline` is
+    rank 0's kernel (HIP events on its launch stream)."""
     import argparse
     a5 = argparse.Namespace(**dict(vars(args), workload="c5"))
     dw = make_worlds(a5, rank, device)
@@ -240,6 +364,8 @@ def c5_leg(args, rank, device):
     torch.cuda.synchronize()
     dw.acted_total.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
     e0.record(); dw.run(n, 70, 100); e1.record()
     torch.cuda.synchronize()
@@ -247,33 +373,74 @@ def c5_leg(args, rank, device):
     dw.check_error_flag()
     steps = int(dw.acted_total.item())
     t_k = e0.elapsed_time(e1) * 1e-3
+    # whole job: [agent-steps, kernel seconds, world_base] of every rank + the slowest rank's wall time, ONE collective
+    row = torch.tensor([float(steps), t_k, float(dw.world_base)], dtype=torch.float64, device=device)
+    tot, wall_max, table = reduce_counters(row, wall, dist)
+    table = table.numpy()
+    steps_all = float(tot[0].item())
     wl = WORKLOADS["c5"]
     flop = float(np.mean([POLICY_FLOP_PER_AGENT[k] for k in wl["brains"]]))
     by = TICK_BYTES_PER_AGENT_STEP + POLICY_BYTES_PER_AGENT
-    return {"workload": wl["name"], "value": round(steps / wall, 1), "unit": "agent-steps/s", "ticks": n, "us_per_tick": round(wall / n * 1e6, 2),
-            "kernel_us_per_tick": round(t_k / n * 1e6, 2), "agent_steps_per_tick": round(steps / n, 1),
-            "roofline": {"kernel": "k_run<512, fixed, kKindAll> (rl_run, mixed brain kinds)", "bound": "hbm", "achieved": round(steps * by / t_k / 1e9, 2),
+    n_ranks = len(table)
+    return {"workload": wl["name"], "value": round(steps_all / wall_max, 1), "unit": "agent-steps/s", "ranks": n_ranks,
+            "worlds_total": args.worlds * n_ranks, "agent_steps": int(round(steps_all)), "ticks": n,
+            "us_per_tick": round(wall_max / n * 1e6, 2), "kernel_us_per_tick": round(float(table[:, 1].max()) / n * 1e6, 2),
+            "agent_steps_per_tick": round(steps_all / n, 1),
+            "per_rank": {"world_base": [int(x) for x in table[:, 2]], "agent_steps": [int(x) for x in table[:, 0]],
+                         "value": [round(float(a / w), 1) for a, w in zip(table[:, 0], table[:, 3])],
+                         "us_per_tick": [round(float(w) / n * 1e6, 2) for w in table[:, 3]],
+                         "kernel_us_per_tick": [round(float(k) / n * 1e6, 2) for k in table[:, 1]]},
+            "value_min_rank": round(float((table[:, 0] / table[:, 3]).min()), 1), "value_max_rank": round(float((table[:, 0] / table[:, 3]).max()), 1),
+            "roofline": {"kernel": "k_run<512, fixed, kKindAll> (rl_run, mixed brain kinds)", "rank": 0, "bound": "hbm", "achieved": round(steps * by / t_k / 1e9, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(steps * by / t_k / 1e9 / HBM_PEAK_GBS, 5), "bytes_per_agent_step": by,
                          "flop_per_agent": flop, "mfma_tflops": round(steps * flop / t_k / 1e12, 2),
                          "mfma_frac": round(steps * flop / t_k / 1e12 / MFMA_F32_EQUIV_PEAK_TFLOPS, 5),
-                         "how": "HIP events on the launch stream around ONE launch of %d ticks, queued behind %d untimed ticks" % (n, n)},
-            "timed": "wall clock around the launch + synchronize (value); inputs resident in HBM"}
+                         "how": "rank 0's launch: HIP events on the launch stream around ONE launch of %d ticks, queued behind %d untimed ticks" % (n, n)},
+            "timed": "wall clock around the launch + synchronize on every rank, released together by a barrier; value = all ranks' agent-steps / "
+                     "the slowest rank's wall time; inputs resident in HBM"}
 
 
-def respawn_under_torchrun(args):
-    """`python bench.py --gpus N` with N > 1 and no torchrun environment: run N ranks of this script, one per GPU."""
-    n_vis = torch.cuda.device_count()
-    if n_vis < args.gpus:
-        raise SystemExit("bench.py: --gpus %d but only %d GPUs are visible" % (args.gpus, n_vis))
+def torchrun_command(args, argv, n_visible):
+    """(cmd, env) of `python bench.py --gpus N` with N > 1 and no torchrun environment: N ranks of this script, one per GPU, through
+    torch.distributed.run on 127.0.0.1 with a free port -- the launch line the driver uses.  Refuses more ranks than visible GPUs
+    unless the ranks share one GPU (--share-gpu, gloo dry run)."""
+    if not args.share_gpu and n_visible < args.gpus:
+        raise SystemExit("bench.py: --gpus %d but only %d GPUs are visible" % (args.gpus, n_visible))
+    if args.share_gpu and n_visible < 1:
+        raise SystemExit("bench.py: --share-gpu needs one visible GPU, there is none")
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return cmd, env
+
+
+def respawn_under_torchrun(args):
+    cmd, env = torchrun_command(args, sys.argv[1:], torch.cuda.device_count())
+    if os.environ.get("RL_BENCH_PRINT_SPAWN"):   # (tests/test_bench_cpu.py: the launch line, without launching)
+        print(json.dumps({"cmd": cmd, "HSA_ENABLE_IPC_MODE_LEGACY": env["HSA_ENABLE_IPC_MODE_LEGACY"]}))
+        raise SystemExit(0)
     sys.stdout.flush()
     raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def check_rank_environment(args, n_visible):
+    """(world_size, rank, local_rank, device index) of this process, or SystemExit with the mismatch: WORLD_SIZE against --gpus, LOCAL_RANK
+    against the visible GPUs (every rank on cuda:0 with --share-gpu)."""
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world_size))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_gpu and args.dist_backend != "gloo":
+        raise SystemExit("bench.py: --share-gpu is the gloo dry run (RCCL refuses two ranks on one device): add --dist-backend gloo")
+    dev_index = 0 if args.share_gpu else local_rank
+    if dev_index >= n_visible:
+        raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPUs visible" % (local_rank, n_visible))
+    return world_size, rank, local_rank, dev_index
 
 
 def main():
@@ -294,15 +461,15 @@ def main():
     ap.add_argument("--no-api-trainer", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="skip the configs[4] per-GPU leg of the default (c4) line")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-single-world", action="store_true", help="skip the configs[1] / configs[2] single-world figures (N = 1 only)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend: nccl = RCCL over xGMI (the product); gloo = dry run of the N > 1 path (collectives hop through the host)")
+    ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank on cuda:0 (needs --dist-backend gloo)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args)
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_size != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world_size))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size, rank, local_rank, dev_index = check_rank_environment(args, torch.cuda.device_count())
     dist = None
     if world_size > 1 or os.environ.get("RL_FORCE_DIST"):
         import torch.distributed as dist
@@ -310,15 +477,18 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world_size))
-        if local_rank >= torch.cuda.device_count():
-            raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPUs visible" % (local_rank, torch.cuda.device_count()))
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
         if dist.get_world_size() != args.gpus:
-            raise SystemExit("bench.py: RCCL sees %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
-    rccl_ranks = dist.get_world_size() if dist is not None else 1
-    device = "cuda:%d" % local_rank
-    torch.cuda.set_device(local_rank)
+            raise SystemExit("bench.py: the process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
+    n_ranks = dist.get_world_size() if dist is not None else 1
+    backend = rl_dist.backend_of(dist) if dist is not None else None
+    rccl_ranks = n_ranks if backend in (None, "nccl") else 0   # the world size RCCL saw (1 without a process group; 0 = a gloo dry run)
+    device = "cuda:%d" % dev_index
+    torch.cuda.set_device(dev_index)
 
     if args.groups > 1:
         grp = StreamGroups(args, rank, device)
@@ -375,10 +545,10 @@ def main():
     # the only collective of the job: ONE RCCL all-gather of every rank's [agent-steps, refills, elapsed] row over xGMI
     # (reinlife_amd/distributed.py); executed whenever a process group exists, also with one rank
     counted = grp.counters() if grp else (float(dw.acted_total.item()), float(dw.refill_count.item()))
-    stats = torch.tensor(counted, dtype=torch.float64, device=device)
+    stats = torch.tensor(list(counted) + [float(dw.world_base)], dtype=torch.float64, device=device)   # (world_base: for the per-rank table only)
     stats, elapsed, rank_table = reduce_counters(stats, elapsed, dist)
-    total_agent_steps, refills = stats.tolist()
-    rank_rates = (rank_table[:, 0] / rank_table[:, 2]).tolist()   # each rank's own agent-steps/s over its own clock: stragglers show here
+    total_agent_steps, refills, _ = stats.tolist()
+    rank_rates = (rank_table[:, 0] / rank_table[:, -1]).tolist()   # each rank's own agent-steps/s over its own clock: stragglers show here
 
     # ---- per-kernel durations with HIP events on the launch stream (untimed extra steps) ------------------------------
     roofline, extra = None, {}
@@ -535,12 +705,25 @@ def main():
         api = api_trainer(args, device, dist, rank)
 
     c5 = None
-    if rank == 0 and args.workload == "c4" and args.groups == 1 and not args.no_c5:
-        c5 = c5_leg(args, rank, device)
+    if args.workload == "c4" and args.groups == 1 and not args.no_c5:   # every rank: configs[4] IS the weak-scaling configuration
+        c5 = c5_leg(args, rank, device, dist)
+
+    single = None
+    if rank == 0 and args.gpus == 1 and args.groups == 1 and not args.no_single_world:
+        single = single_world(args, device)
 
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
+
+    # every rank is done with its legs: how long each one waits here for the slowest (rank 0 carries the rank-0-only legs) is part of
+    # the line -- a rank stuck behind a leg the others skipped would show as seconds
+    barrier_waits = [0.0]
+    if dist is not None:
+        tb = time.perf_counter()
+        dist.barrier()
+        w = torch.tensor([time.perf_counter() - tb], dtype=torch.float64, device=device)
+        barrier_waits = [round(float(x), 4) for x in rl_dist.gather_rows(w, dist).reshape(-1).tolist()]
 
     if rank == 0:
         wl = WORKLOADS[args.workload]
@@ -551,8 +734,13 @@ def main():
             "n_gpus": args.gpus,
             "rccl_ranks": rccl_ranks,
             "rccl_collectives_executed": main_collectives,
+            "ranks": n_ranks,
+            "dist_backend": {None: None, "nccl": "nccl (RCCL)"}.get(backend, backend),
             "per_rank": {"value_min": round(min(rank_rates), 1), "value_max": round(max(rank_rates), 1),
-                         "elapsed_ms": [round(float(x) * 1e3, 3) for x in rank_table[:, 2].tolist()]},
+                         "elapsed_ms": [round(float(x) * 1e3, 3) for x in rank_table[:, -1].tolist()],
+                         "agent_steps": [int(x) for x in rank_table[:, 0].tolist()], "world_base": [int(x) for x in rank_table[:, 2].tolist()],
+                         "device": device if not args.share_gpu else "cuda:0 shared by every rank (dry run)",
+                         "final_barrier_wait_s": barrier_waits},
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
@@ -570,12 +758,12 @@ def main():
             "cpu_baseline": cpu,
             "api_trainer": api,
             "c5": c5,
+            "single_world": single,
         }
         out.update(extra)
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()
         dist.destroy_process_group()
 
 

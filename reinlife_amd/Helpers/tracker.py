@@ -45,9 +45,12 @@ class Tracker:
         self.worlds = worlds
         self.dist = dist
         self.collectives_executed = 0   # collectives issued so far: exactly one per closed interval when a process group exists
+        self.setup_collectives_executed = 0   # (+ the layout check at construction, below)
         self.fig = None
         if worlds is not None:
             worlds.enable_tracking(True)
+            if dist is not None and dist.is_initialized():
+                self._check_layout()
 
     @property
     def results(self):
@@ -87,29 +90,49 @@ class Tracker:
         if len(arrays) > 1:
             self.worlds.raise_on_error_flag(arrays[1])
 
+    def _check_layout(self):
+        """Set-up, once per Tracker under a process group: every rank must hold the SAME number of worlds (the interval collective is an
+        all-gather of equal rows) at world_base = rank x n_worlds (the pooled sums are taken in global replica order, which is what
+        makes them independent of the number of ranks).  One tiny all-gather of (world_base, n_worlds); a layout that would hang or
+        mis-order the interval collective is refused here, on every rank, with the table in the message."""
+        from ..distributed import gather_rows
+        w = self.worlds
+        mine = torch.tensor([float(getattr(w, "world_base", 0)), float(w.trk_sum.shape[0])], dtype=torch.float64)
+        table = gather_rows(mine, self.dist).cpu().numpy()
+        self.setup_collectives_executed += 1
+        n = table[0, 1]
+        if not (table[:, 1] == n).all() or not (table[:, 0] == table[0, 0] + n * np.arange(len(table))).all():
+            raise ValueError("Tracker under a process group needs equal shards in rank order (world_base = first + rank * n_worlds); "
+                             "got (world_base, n_worlds) per rank: %s" % table.astype(np.int64).tolist())
+
     def _average_results(self):
         """The device half: queued, not waited for."""
         w = self.worlds
         rows = torch.cat([w.trk_sum.reshape(w.trk_sum.shape[0], -1), w.trk_cnt.reshape(w.trk_cnt.shape[0], -1).to(torch.float64),
                           w.trk_pop[:, 1:]], dim=1)   # one row per world of this rank: [sums | counts | population sums]
+        err = getattr(w, "err", None)
         if self.dist is not None and self.dist.is_initialized():   # (also at world size 1: the collective is the same code path)
             # ONE collective per closed interval.  The ranks' PER-WORLD rows are gathered (a few hundred bytes per world and interval)
             # and every rank then sums the job's worlds in global replica order with the same reduction a single-rank job uses: the
             # aggregates are bit-identical whatever the number of ranks (a sum of per-rank partial sums -- an all-reduce(SUM) -- would
-            # re-associate the float64 additions: equal to 1e-16 relative, not exactly)
-            backend = getattr(self.dist, "get_backend", lambda: "")()
-            if rows.is_cuda and str(backend) == "gloo":   # (a CPU-only backend under GPU worlds: the few hundred bytes go through the host)
-                rows = rows.cpu()
-            flat = torch.empty(self.dist.get_world_size() * rows.numel(), dtype=torch.float64, device=rows.device)
-            self.dist.all_gather_into_tensor(flat, rows.reshape(-1).contiguous())
+            # re-associate the float64 additions: equal to 1e-16 relative, not exactly).  The rank's device error flag rides in the same
+            # row, so a corrupted world on ANY rank stops EVERY rank at this interval (no rank is left waiting in the next collective).
+            from ..distributed import gather_rows
+            ncol = rows.shape[1]
+            payload = rows.reshape(-1) if err is None else torch.cat([rows.reshape(-1), err.to(torch.float64)])
+            table = gather_rows(payload, self.dist)   # (under a CPU-only backend the few hundred bytes go through the host)
             self.collectives_executed += 1
-            rows = flat.view(-1, rows.shape[1])
+            if err is not None:
+                errs = table[:, -err.numel():]
+                err = errs[(errs[:, 0] != 0).to(torch.int32).argmax()].to(torch.int32)   # the first rank's flag that is set, else zeros
+                table = table[:, :-err.numel()]
+            rows = table.reshape(-1, ncol)
         tot = rows.sum(0)
         shape = tuple(w.trk_sum.shape[1:])
         if hasattr(w, "readback") and tot.device.type == torch.device(w.device).type:   # (not after a hop through a CPU-only collective)
-            self._pending = (w.readback([tot, w.err]), shape)
-        else:
-            self._pending = (_Here([tot.cpu().numpy()]), shape)
+            self._pending = (w.readback([tot, err]), shape)
+        else:   # sums that are on the host already; the error flag comes along (one small read-back when it is still on the device)
+            self._pending = (_Here([tot.cpu().numpy()] + ([err.cpu().numpy()] if err is not None else [])), shape)
         w.reset_tracking()
 
     def _append(self, tot, shape):

@@ -1,7 +1,7 @@
 """trainer(): same signature, defaults and return value as ReinLife/Helpers/trainer.py:7-107.
 
 The loop is the reference's (get_action -> step -> learn -> update_env, trainer.py:85-99) with get_action batched on the
-GPU through env.act().  A single world (rng="reference", the default for n_worlds == 1) makes every random draw of the
+GPU through env.act().  A single world (rng="reference", the default for n_worlds == 1 outside a multi-rank job) makes every random draw of the
 loop exactly as the reference does, so the same seeds give the same run; replicated worlds draw in-kernel.
 
 INFERENCE ONLY: training=True (the reference's default) keeps the loop, the epsilon schedules and the Tracker, but the brains
@@ -26,8 +26,8 @@ def trainer(brains, n_episodes=10_000, width=30, height=30, visualize_results=Fa
     Several GPUs: start one process per GPU (torchrun) and initialise torch.distributed (backend "nccl" = RCCL) before the
     call -- or pass the process-group module as `dist`.  Every rank then owns `n_worlds` replicas (global ids rank * n_worlds ...: the
     worlds are the same whatever the number of ranks), runs on cuda:LOCAL_RANK unless `device` says otherwise, and the Tracker's
-    per-interval statistics (tracker.py:107-121) are pooled over ALL ranks' worlds by one all-reduce per closed interval -- the only
-    collective of the job; every rank returns the same `env.tracker.results`."""
+    per-interval statistics (tracker.py:107-121) are pooled over ALL ranks' worlds by one all-gather of the ranks' per-world sums per closed interval --
+    the only collective of the loop; every rank returns the same `env.tracker.results`."""
     env = Environment(width=width, height=height, max_agents=max_agents, brains=brains, grid_size=24,
                       static_families=static_families, update_interval=update_interval, print_results=print_results,
                       interactive_results=visualize_results, google_colab=google_colab, training=training,

@@ -145,15 +145,22 @@ class Environment:
         # Replica sharding: under an initialised torch.distributed process group (passed as `dist`, or found) this
         # process is ONE rank of a job whose replicas are `n_worlds` per rank -- global replica ids rank * n_worlds .. + n_worlds - 1
         # key the Philox streams (results do not depend on the number of ranks), the device defaults to cuda:LOCAL_RANK, and the
-        # Tracker sums its per-interval statistics over all ranks with ONE all-reduce per closed interval.  No other collective.
+        # Tracker pools its per-interval statistics over all ranks with ONE all-gather per closed interval (+ one layout check when it is built).
         self.dist, self.rank, self.world_size = resolve_dist(dist)
         self.world_base = int(world_base) if world_base is not None else self.rank * n_worlds
         if device is None:
             device = "cuda:%d" % (int(os.environ.get("LOCAL_RANK", "0")) if self.dist is not None else 0)
         self.device = device
-        self.rng = rng or ("reference" if n_worlds == 1 else "philox")
+        # rng="reference" means "this process's one world consumes the process-global generators like the reference does": that cannot
+        # be a shard of a replicated job (every rank would build the same world from the same seeds and the Tracker would pool
+        # duplicates), so under a process group of several ranks, or at a non-zero world_base, the default is the keyed Philox streams
+        sharded = self.world_size > 1 or self.world_base != 0
+        self.rng = rng or ("reference" if (n_worlds == 1 and not sharded) else "philox")
         if self.rng not in ("reference", "philox") or (self.rng == "reference" and n_worlds != 1):
             raise ValueError("rng must be 'reference' (single world only) or 'philox'")
+        if self.rng == "reference" and sharded:
+            raise ValueError("rng='reference' draws from the process-global generators and ignores world_base: it cannot be one shard of "
+                             "a replicated job (world_size %d, world_base %d) -- use rng='philox'" % (self.world_size, self.world_base))
         # SURVEY.md 8d's synthetic benchmark worlds through this API (keyword-only extras, rng="philox"): reset() fills every world with
         # `synthetic_agents` agents at random cells (gene / brain uniform over the brains) instead of one agent per brain, and a world
         # whose population drops below `refill_below` after update_env is re-generated (what bench.py times: 100 / 70)

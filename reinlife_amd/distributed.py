@@ -13,6 +13,26 @@ def shard(n_worlds_total, rank, world_size):
     return first, count
 
 
+def backend_of(dist):
+    """Name of the process group's backend ("nccl" = RCCL on ROCm, "gloo", ...); "" for a stand-in without get_backend."""
+    try:
+        return str(dist.get_backend())
+    except Exception:  # noqa: BLE001
+        return ""
+
+
+def gather_rows(row, dist):
+    """ONE all-gather of a flat float64 tensor per rank -> [world_size, row.numel()], identical on every rank.  Under a CPU-only
+    backend (gloo) with device tensors the few hundred bytes hop through the host (the 2-rank dry runs that share one GPU:
+    tests/test_hip_round5.py; the result then stays on the host); under nccl (= RCCL) the gather runs on the device over xGMI."""
+    row = row.reshape(-1).contiguous()
+    if row.is_cuda and backend_of(dist) == "gloo":
+        row = row.cpu()
+    flat = torch.empty(dist.get_world_size() * row.numel(), dtype=row.dtype, device=row.device)
+    dist.all_gather_into_tensor(flat, row)   # (flat output: the shape every backend accepts)
+    return flat.view(dist.get_world_size(), row.numel())
+
+
 def reduce_counters(counters, elapsed_s, dist=None):
     """counters: 1-D float64 tensor of additive metrics; returns (summed counters, max elapsed, per-rank table) over all ranks.
 
@@ -24,9 +44,7 @@ def reduce_counters(counters, elapsed_s, dist=None):
     if dist is not None and dist.is_initialized():
         global collectives_executed
         collectives_executed += 1
-        flat = torch.empty(dist.get_world_size() * row.numel(), dtype=torch.float64, device=row.device)
-        dist.all_gather_into_tensor(flat, row)   # (flat output: the shape every backend accepts)
-        table = flat.view(dist.get_world_size(), row.numel())
+        table = gather_rows(row, dist)
     else:
         table = row[None, :].clone()
     return table[:, :-1].sum(0), float(table[:, -1].max().item()), table.cpu()

@@ -54,6 +54,7 @@ class DeviceWorlds:
         self.R, self.W, self.H, self.C = n_worlds, width, height, width * height
         self.cap = slot_cap or _lib.slot_cap_for(max_agents)
         self.max_agents, self.n_brains = max_agents, n_brains
+        self.world_base = int(world_base)   # global replica id of world 0 of this handle (keys the Philox streams)
         self.cfg = _lib.Config(width, height, max_agents, n_brains, self.cap, n_worlds, int(static_families),
                                int(limit_reproduction), int(incentivize_killing), world_base, seed)
         self.handle = C.c_void_p()
@@ -317,14 +318,15 @@ class DeviceWorlds:
     def run_supported(self):
         return self._brains is not None and bool(self.lib.rl_run_supported(self.handle, self._brains, self.n_brains))
 
-    def run(self, n_ticks, threshold=-1, n_agents=0, eps_schedule=None, trk_skip=0):
+    def run(self, n_ticks, threshold=-1, n_agents=0, eps_schedule=None, trk_skip=0, want_q=False):
         """n_ticks x (act() + tick_refill(threshold, n_agents)) -- or + tick() when threshold < 0 -- in ONE launch when the
         configuration allows it (rl_run_ex: every world stays in LDS between ticks; the Tracker accumulators are maintained in
         the launch when tracking is on), else the same loop over the two launches.  Either way the buffers afterwards hold the
         last tick's outputs.
         eps_schedule: optional [n_ticks, n_brains] float32 (host array or device tensor) -- the brains' exploration rate in every
         tick (the reference's brains decay epsilon per episode); None = the rates given to set_brains().
-        trk_skip: the Tracker's running sums leave out the first trk_skip ticks (episode 0, tracker.py:279-282)."""
+        trk_skip: the Tracker's running sums leave out the first trk_skip ticks (episode 0, tracker.py:279-282).
+        want_q: the policy's outputs of the LAST tick (Q values / PPO probabilities) are left in self.out_q (rl_run_opts.policy_out)."""
         if self._brains is None:
             raise _lib.ReinLifeHipError("set_brains() was not called")
         if n_ticks <= 0:
@@ -353,7 +355,7 @@ class DeviceWorlds:
             for t in range(n_ticks):
                 if eps_host is not None:
                     self._set_epsilons(eps_host[t].tolist())
-                self.act(want_q=self.replays is not None and self._capture_prob)
+                self.act(want_q=want_q or (self.replays is not None and self._capture_prob))
                 if threshold >= 0:
                     self.tick_refill(threshold, n_agents)
                 else:
@@ -373,7 +375,7 @@ class DeviceWorlds:
         # (a short schedule rides in the kernel arguments -- rl_run_opts.eps_schedule_on_host: the launch waits for no upload)
         eps_arg = C.c_void_p(eps_host.ctypes.data) if inline else _ptr(eps_schedule)
         opts = _lib.RunOpts(threshold, n_agents, _ptr(self.refill_count), eps_arg, trk_skip, 1 if inline else 0,
-                            C.cast(self._replay_arr, C.c_void_p) if cap else None, _ptr(self.out_q) if (cap and self._capture_prob) else None)
+                            C.cast(self._replay_arr, C.c_void_p) if cap else None, _ptr(self.out_q) if (want_q or (cap and self._capture_prob)) else None)
         self._trk_dirty = self._trk_dirty or self.tracking
         _lib.check(self.lib.rl_run_ex(self.handle, self._brains, self.n_brains, n_ticks, _ptr(self.actions), C.byref(self._step_out),
                                       self._run_pair, self._cur, _ptr(self.src2), C.byref(opts), self._stream()), "rl_run_ex")

@@ -161,3 +161,80 @@ def test_environment_world_base_and_device_resolution_without_a_process_group(mo
         st = np.random.get_state()[1].copy()
         env.reset()
         assert np.array_equal(st, np.random.get_state()[1])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 5: what a sharded job refuses, and how a device error on ONE rank reaches EVERY rank
+# ---------------------------------------------------------------------------------------------------------------------
+class FlaggedWorlds(OracleBackedWorlds):
+    """The stand-in with a device error flag (DeviceWorlds.err / raise_on_error_flag)."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.err = torch.zeros(4, dtype=torch.int32)
+
+    @staticmethod
+    def raise_on_error_flag(e):
+        from reinlife_amd import _lib
+        if e[0] != 0:
+            raise _lib.ReinLifeHipError("device error flag: code %d world %d detail (%d, %d)" % tuple(int(x) for x in e))
+
+
+def _edge_worker(rank, world_size, port, q):
+    import warnings
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    envmod, Models = _patch()
+    envmod.DeviceWorlds = FlaggedWorlds
+    from reinlife_amd import _lib
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # (1) the trainer()/tester() default n_worlds=1 under a multi-rank job: keyed Philox streams, one distinct replica per rank
+        env = envmod.Environment(brains=[Models.PERD3QN(), Models.PPO()])
+        out["default"] = (env.rng, env.world_base, env.worlds.world_base, env.tracker.setup_collectives_executed)
+        try:   # (every rank raises before the Tracker's collective: nobody is left waiting)
+            envmod.Environment(brains=[Models.PERD3QN()], rng="reference")
+            out["reference"] = "accepted"
+        except ValueError as e:
+            out["reference"] = str(e)
+        # (2) unequal shards: refused on EVERY rank at construction, not a hang in the first interval's collective
+        try:
+            envmod.Environment(brains=[Models.PERD3QN()], n_worlds=2 + rank)
+            out["unequal"] = "accepted"
+        except ValueError as e:
+            out["unequal"] = str(e)
+        # (3) a device error on rank 1 only: both ranks raise when the interval that carried it is resolved
+        env = envmod.Environment(brains=[Models.PERD3QN(), Models.D3QN()], n_worlds=2, update_interval=5, print_results=False, seed=3)
+        env.reset()
+        env.run(0, 5)            # episodes 0..4: no interval closes
+        if rank == 1:
+            env.worlds.err[:] = torch.tensor([7, 1, 2, 3], dtype=torch.int32)
+        try:
+            env.run(5, 6)        # episode 5 closes interval 1; its flag travels with the gathered rows
+            out["flag"] = "no error"
+        except _lib.ReinLifeHipError as e:
+            out["flag"] = str(e)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_sharded_job_refuses_what_it_cannot_shard_and_shares_its_error_flag():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_edge_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(2):
+        out = res[rank]
+        assert out["default"] == ("philox", rank, rank, 1)
+        assert "cannot be one shard" in out["reference"]
+        assert "equal shards" in out["unequal"] and "[[0, 2], [3, 3]]" in out["unequal"]
+        assert out["flag"] == "device error flag: code 7 world 1 detail (2, 3)"   # rank 1's flag, on both ranks

@@ -308,7 +308,7 @@ def _bench(extra_env, *args):
 
 def test_bench_rccl_path_at_world_size_one_reduces_the_same_counters():
     """RL_FORCE_DIST=1: bench.py initialises the nccl (= RCCL) process group with one rank and sends its counters through the
-    same all-reduce the 8-GPU run uses.  The reduced counters must equal the plain single-process run's (the worlds are
+    same all-gather the 8-GPU run uses.  The reduced counters must equal the plain single-process run's (the worlds are
     deterministic in (seed, global replica id))."""
     import socket
     with socket.socket() as sk:

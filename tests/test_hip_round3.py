@@ -207,17 +207,28 @@ def _bench_worlds(seed=20260928):
 
 def test_benched_size_multi_tick_launch_tracks_the_oracle_for_300_ticks():
     """The instantiation bench.py times (k_run<512, fixed> on 256 workgroups) against the oracle fed the chosen actions: 300 launches
-    of one tick; integer state every tick, both observation passes and every per-agent output every 10 ticks."""
+    of one tick; integer state every tick, both observation passes and every per-agent output every 10 ticks.  Round 5: the POLICY half
+    at that size too (tests/policy_check.py) -- every 10th tick the chosen actions of all ~22k agents against the selection rule on an
+    f32 forward of the ORACLE's rows, and every other 10th tick a launch that also writes its Q values (policy_out): Q within 1e-5,
+    actions exactly the rule on them."""
+    import bench
     from oracle import oracle as orc
+    from policy_check import PolicyCheck
     dw = _bench_worlds()
     ow = orc.OracleWorlds(n_worlds=256, seed=20260928, width=30, height=30, max_agents=100, n_brains=2, static_families=True)
     ow.reset_synthetic(100)
     assert dw.run_supported()
+    pc = PolicyCheck(["PERD3QN", "PERD3QN"], [bench.brain_weights("PERD3QN", 100 + k) for k in range(2)], [0.0, 0.0])
     steps = 0
     for t in range(300):
         n0 = ow.s["n_agents"].copy()
-        dw.run(1, 70, 100)
+        with_q, with_a = t % 10 == 4, t % 10 == 9
+        if with_q or with_a:
+            pc.before(ow)
+        dw.run(1, 70, 100, want_q=with_q)
         acts = dw.actions.cpu().numpy()
+        if with_q or with_a:
+            pc.after(acts, dw.out_q.cpu().numpy() if with_q else None, "tick %d" % t)
         ow.step(acts)
         full = t % 10 == 9
         if full:
@@ -236,6 +247,7 @@ def test_benched_size_multi_tick_launch_tracks_the_oracle_for_300_ticks():
             _cmp_state(dw, ow, "tick %d" % t)
             _cmp_rows(dw.obs_state().cpu().numpy(), ow.obs2, ow.s["n_agents"], "tick %d obs2" % t)
     assert steps > 6_000_000 and int(dw.acted_total.item()) == steps and int(dw.refill_count.item()) > 500
+    assert pc.rows > 1_200_000 and pc.q_rows > 600_000 and pc.max_dq < 1e-5
 
 
 def test_benched_size_one_launch_of_300_ticks_equals_300_launches_of_one():

@@ -42,14 +42,24 @@ def _against_the_oracle(workload, train):
     nb = len(wl["brains"])
     ow = orc.OracleWorlds(n_worlds=256, seed=SEED, width=30, height=30, max_agents=100, n_brains=nb, static_families=wl["static_families"])
     ow.reset_synthetic(100)
+    # round 5: the policy half at this size too (tests/policy_check.py) -- greedy brains of the TRAIN 0 launch only (an exploring
+    # schedule changes per tick; its selection rule is covered at 16 worlds in test_hip_round2.py)
+    import bench
+    from policy_check import PolicyCheck
+    pc = None if train else PolicyCheck(wl["brains"], [bench.brain_weights(n, 100 + k) for k, n in enumerate(wl["brains"])], [0.0] * nb)
     steps = 0
     for t in range(TICKS):
         n0 = ow.s["n_agents"].copy()
+        with_q, with_a = pc is not None and t % 10 == 4, pc is not None and t % 10 == 9
+        if with_q or with_a:
+            pc.before(ow)
         if train:
             dw.run(1, 70, 100, eps_schedule=_schedule(nb, t, 1), trk_skip=1 if t == 0 else 0)
         else:
-            dw.run(1, 70, 100)
+            dw.run(1, 70, 100, want_q=with_q)
         acts = dw.actions.cpu().numpy()
+        if with_q or with_a:
+            pc.after(acts, dw.out_q.cpu().numpy() if with_q else None, "tick %d" % t)
         if train and t == 0:
             keep = (ow.trk_sum.copy(), ow.trk_cnt.copy(), ow.trk_pop.copy())
         ow.step(acts)
@@ -78,6 +88,8 @@ def _against_the_oracle(workload, train):
                     assert np.array_equal(getattr(dw, name).cpu().numpy(), getattr(ow, name), equal_nan=True), (name, t)
                 assert np.array_equal(dw.trk_pop.cpu().numpy()[:, 1:], ow.trk_pop[:, 1:]), ("trk_pop", t)
     assert steps > 4_000_000 and int(dw.acted_total.item()) == steps and int(dw.refill_count.item()) > 300
+    if pc is not None:
+        assert pc.rows > 800_000 and pc.q_rows > 400_000 and pc.max_dq < 1e-5 and pc.ppo_mismatches <= 3
     return dw, ow
 
 

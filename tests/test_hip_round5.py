@@ -1,0 +1,77 @@
+"""GPU, round 5: bench.py's N > 1 path EXECUTED -- two torchrun ranks sharing the one GPU of the box (`--dist-backend gloo --share-gpu`:
+every rank on cuda:0, the collectives hop through the host and gloo), so that `python bench.py --gpus 8` on an 8-GPU node differs from
+what ran here only in backend="nccl" and the device index.  Checked: ONE JSON line, the ranks and their world_base, whole-job sums equal
+to a 1-rank run holding all the worlds (the worlds are keyed by global replica id), the Tracker pooled through trainer() on every rank,
+configs[4] (`c5`) on every rank and reduced, nobody waiting at the final barrier; and the single-world figures of the default line.
+Two ranks on one GPU cannot show a speed-up: structure is asserted, not speed (Helpers/trainer.py:79-83 of the reference)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--steps", "30", "--warmup", "5", "--burnin", "40", "--no-cpu-baseline"]
+
+
+def _bench(*args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RL_WORLD_BLOCK", "RL_WORLD_GENERIC", "RL_FORCE_DIST")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *COMMON, *args], env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "expected ONE JSON line, got %d" % len(lines)
+    assert out.stdout.strip().splitlines()[-1] == lines[0]      # ... and it is the last thing on stdout
+    return json.loads(lines[0])
+
+
+def test_two_rank_dry_run_of_the_multi_gpu_bench_path():
+    two = _bench("--gpus", "2", "--dist-backend", "gloo", "--share-gpu", "--worlds", "64")
+    one = _bench("--gpus", "1", "--worlds", "128", "--no-single-world")
+    # what ran: two ranks, stated as a gloo dry run -- never to be mistaken for RCCL evidence
+    assert two["n_gpus"] == 2 and two["ranks"] == 2 and two["dist_backend"] == "gloo" and two["rccl_ranks"] == 0
+    assert one["ranks"] == 1 and one["dist_backend"] is None and one["rccl_ranks"] == 1
+    assert two["scaling"] == "weak" and two["config"]["worlds_per_gpu"] == 64 and two["config"]["worlds_total"] == 128
+    assert "x2" in two["config"]["parallelism"]
+    # the shards: global replica ids 0.. and 64.., every rank's counters in the one collective, whole job = their sum = the 1-rank job
+    pr = two["per_rank"]
+    assert pr["world_base"] == [0, 64] and len(pr["agent_steps"]) == len(pr["elapsed_ms"]) == 2
+    assert sum(pr["agent_steps"]) == two["config"]["agent_steps"] == one["config"]["agent_steps"] > 30 * 128 * 60
+    assert min(pr["agent_steps"]) > 30 * 64 * 60
+    assert two["config"]["world_refills"] == one["config"]["world_refills"]
+    assert two["rccl_collectives_executed"] == 1 and one["rccl_collectives_executed"] == 0      # the metric's reduction: ONE collective
+    assert abs(two["value"] - two["config"]["agent_steps"] / (two["ms_per_step"] * 1e-3 * 30)) < 1e-3 * two["value"]
+    assert max(pr["elapsed_ms"]) * 1e-3 <= two["ms_per_step"] * 1e-3 * 30 + 1e-6 and pr["value_min"] <= pr["value_max"]
+    # nobody is left waiting behind a leg only rank 0 runs
+    assert len(pr["final_barrier_wait_s"]) == 2 and max(pr["final_barrier_wait_s"]) < 5.0
+    # the dominant kernel's roofline stays in a multi-rank line (rank 0's kernel)
+    assert two["roofline"] is not None and two["roofline"]["bound"] == "hbm" and 0 < two["roofline"]["frac"] < 1
+    assert two["cpu_baseline"] is None and two["single_world"] is None          # N = 1 only (the contract)
+    # trainer() on every rank under the process group: rank -> world_base, the Tracker pooled with one collective per closed interval,
+    # and the pooled statistics are EXACTLY the 1-rank job's (bit-identical: per-world rows summed in global replica order)
+    ta, tb = one["api_trainer"], two["api_trainer"]
+    assert tb["ranks"] == 2 and ta["ranks"] == 1 and tb["tracker_rccl_collectives"] == 8 and ta["tracker_rccl_collectives"] == 0
+    assert tb["tracker_intervals_closed"] == ta["tracker_intervals_closed"] == 4
+    assert tb["tracker_last_interval"] == ta["tracker_last_interval"]
+    # configs[4] on every rank, reduced like the main line
+    c2, c1 = two["c5"], one["c5"]
+    assert c2["ranks"] == 2 and c1["ranks"] == 1 and c2["worlds_total"] == 128
+    assert c2["per_rank"]["world_base"] == [0, 64] and c1["per_rank"]["world_base"] == [0]
+    assert sum(c2["per_rank"]["agent_steps"]) == c2["agent_steps"] == c1["agent_steps"] > 1000 * 128 * 60
+    assert len(c2["per_rank"]["us_per_tick"]) == 2 and c2["us_per_tick"] == max(c2["per_rank"]["us_per_tick"])
+    assert c2["value_min_rank"] <= c2["value_max_rank"] and c2["roofline"]["rank"] == 0 and 0 < c2["roofline"]["mfma_frac"] < 1
+    assert abs(c2["value"] - c2["agent_steps"] / (c2["us_per_tick"] * 1e-6 * 1000)) < 2e-3 * c2["value"]
+
+
+def test_single_world_figures_of_the_default_line():
+    """BASELINE configs[1] / configs[2] and the literal drop-in defaults as throughput figures (VERDICT r04 missing #3)."""
+    line = _bench("--gpus", "1", "--worlds", "64", "--no-api-trainer", "--no-c5", "--no-kernel-timing")
+    sw = line["single_world"]
+    assert sw["c2"]["step_only"]["value"] > 0 and sw["c2"]["host_loop"]["value"] > 0 and 60 < sw["c2"]["mean_agents"] <= 100
+    assert sw["c3"]["value"] > 0 and sw["c3"]["two_launch"]["value"] > 0 and 60 < sw["c3"]["mean_agents"] <= 100
+    for key in ("trainer_default", "trainer_configs0"):
+        r = sw[key]
+        assert r["rng"] == "reference" and r["n_worlds"] == 1 and r["episodes"] == 301 and r["value"] > 0 and r["mean_agents"] > 0
+    assert "configs[0]" in sw["trainer_configs0"]["call"] and "DQN(max_epi=300)" in sw["trainer_default"]["call"]
+    assert sw["reference_cpu_survey_time"]["C3 100 agents, DQN forward + step"] == 7100
