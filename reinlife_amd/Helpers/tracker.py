@@ -97,7 +97,7 @@ class Tracker:
         mis-order the interval collective is refused here, on every rank, with the table in the message."""
         from ..distributed import gather_rows
         w = self.worlds
-        mine = torch.tensor([float(getattr(w, "world_base", 0)), float(w.trk_sum.shape[0])], dtype=torch.float64)
+        mine = torch.tensor([float(getattr(w, "world_base", 0)), float(w.trk_sum.shape[0])], dtype=torch.float64, device=w.trk_sum.device)
         table = gather_rows(mine, self.dist).cpu().numpy()
         self.setup_collectives_executed += 1
         n = table[0, 1]

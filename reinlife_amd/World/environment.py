@@ -24,19 +24,48 @@ from ..worlds import DeviceWorlds
 from .utils import Actions, EntityTypes
 
 
+_A_FIELDS = tuple(n for n in _lib.STATE_FIELDS if n.startswith("a_"))
+
+
 class _WorldMirror:
     """Host copy of ONE world's agent list and per-agent outputs, in env.agents order.  Built on first use after a step() /
-    update_env() / run() (Environment._mat): a loop that never looks at env.agents never pays for it."""
+    update_env() / run() (Environment._mat): a loop that never looks at env.agents never pays for it.  The small arrays come with
+    the state snapshot; the observation rows (Agent.state / state_prime: 612 B per agent) are fetched only when somebody reads them."""
 
-    def __init__(self, world):
-        self.world = world
+    def __init__(self, env, world, phase):
+        self.env, self.world, self.phase = env, world, phase
+        self.stamp = env._stamp     # the device state this mirror describes (Environment._refresh moves on)
+        self.n = 0
         self.host = None            # {"a_i": ..., ...}
-        self.state = None           # [n,153] float64: Agent.state
-        self.state_prime = None     # [n,153] or None (between update_env and the next step)
-        self.reward = self.done = None
+        self._state = None          # [n,153] float64: Agent.state
+        self._state_prime = None    # [n,153] or None (between update_env and the next step)
+        self.reward = self.done = self.src1 = None
         self.actions = None         # [cap] int8
+        self.q = None               # [cap,8] float32: the policy's outputs for this tick (Environment.act, rng="reference")
         self.dirty = False          # actions were set through AgentView.action and are not on the device yet
         self.views = None           # the AgentView list handed out by agents_of()
+
+    def _rows(self, t):
+        if self.stamp != self.env._stamp:
+            raise RuntimeError("this AgentView describes an earlier tick: Agent.state / state_prime must be read before the next "
+                               "step() / update_env() / run() (take env.agents again)")
+        return t.cpu().numpy().astype(np.float64)
+
+    @property
+    def state(self):
+        if self._state is None:
+            w, n = self.env.worlds, self.n
+            if self.phase == "step":   # Agent.state is still the observation the policy read, in the pre-step order
+                self._state = self._rows(w.obs_state()[self.world])[self.src1[:n].astype(np.int64)]
+            else:
+                self._state = self._rows(w.obs_state()[self.world, :n])
+        return self._state
+
+    @property
+    def state_prime(self):
+        if self._state_prime is None and self.phase == "step":
+            self._state_prime = self._rows(self.env.worlds.obs_state_prime()[self.world, :self.n])
+        return self._state_prime
 
 
 class AgentView:
@@ -99,11 +128,12 @@ class AgentView:
 
     def get_action(self, n_epi, out=None):  # entities.py:215-222
         b = self.brain
+        state = self.state if out is None else None   # (with the outputs at hand the brain does not look at the row: no fetch)
         if b.method == "PPO":
-            r = b.get_action(self.state, out=out)
+            r = b.get_action(state, out=out)
             self.action, self.prob = r if isinstance(r, tuple) else (r, None)
         else:
-            self.action = b.get_action(self.state, n_epi, out=out)
+            self.action = b.get_action(state, n_epi, out=out)
 
     def learn(self, **kwargs):
         """entities.py:194-208: the keyword set the reference hands to brain.learn, per brain method (caller kwargs such as
@@ -185,6 +215,8 @@ class Environment:
                                static_families=static_families, brains=brains, worlds=self.worlds if training else None,
                                dist=self.dist)
         self._mirrors = {}          # world -> _WorldMirror, built on demand (_mat): env.agents is world 0's
+        self._stamp = 0             # counts the changes of the device state (_refresh)
+        self._n_empty = None        # rng="reference": empty cells after this tick's _add_food, as far as the host's draws say
         self._grid = self._max_gene = None
         self._phase = "update"
         self._acted = False         # act() ran since the last step() / update_env(): worlds.actions holds the policy's choice
@@ -283,15 +315,22 @@ class Environment:
         reference's order (the forward pass draws nothing, so batching it changes no draw).
         rng="philox": forward pass, epsilon-greedy / categorical selection and the draws all happen in the kernel."""
         if self.rng == "reference":
-            idx = self._host["a_brain"].astype(np.int64)
-            outs = [None] * len(self.agents)
-            for b in np.unique(idx):
-                rows = np.nonzero(idx == b)[0]
-                res = self.brains[int(b)].forward_batch(self._state_host[rows], self.device).cpu()
-                for r, o in zip(rows, res):
-                    outs[r] = o
-            for agent, o in zip(self.agents, outs):
-                agent.get_action(n_epi, out=o)
+            # ONE policy launch for all agents (rl_policy_act: per-brain row lists built on the device, every brain kind side by side),
+            # queued before the host has looked at anything; its outputs travel with the state snapshot (one copy, one wait).  The
+            # kernel's own action choice is overwritten below: the brains' rules run on the host, in list order, on these outputs.
+            self._bind_brains()
+            self.worlds.act(want_q=True)
+            self._acted = True
+            m = self._mat(0)
+            if m.q is None:   # (the mirror was built before this call: somebody read env.agents first)
+                m.q = self.worlds.out_q[0].cpu().numpy()
+            q, qt = m.q, None
+            for k, agent in enumerate(m.views):
+                if agent.brain.method == "PPO":   # (Categorical(prob).sample() wants a tensor; argmax rules take the numpy row)
+                    qt = torch.from_numpy(q) if qt is None else qt
+                    agent.get_action(n_epi, out=qt[k])
+                else:
+                    agent.get_action(n_epi, out=q[k])
             return
         for b in self.brains:
             b.update_epsilon(n_epi)
@@ -306,17 +345,28 @@ class Environment:
         """environment.py:160-186"""
         dirty = [m for m in self._mirrors.values() if m.dirty]
         if dirty:
-            full = self.worlds.actions.cpu().numpy()
+            if self.n_worlds == 1:   # (the mirror holds the whole row: nothing to read back)
+                full = dirty[0].actions[None]
+            else:
+                full = self.worlds.actions.cpu().numpy()
+                for m in dirty:
+                    full[m.world] = m.actions
             for m in dirty:
-                full[m.world] = m.actions
                 m.dirty = False
             self.worlds.set_actions(full)
         if self.rng == "reference":
-            nf, npo, ns, ne = self.worlds.step_split()[0].tolist()
-            self.worlds.step_food(self.worlds.make_tape([self._draw_add_food(nf, npo, ns, ne)]))
+            # the draws of _add_food need the grid after movement: first half, ONE snapshot (the counts AND the post-step agent list --
+            # update_env's draws are made from it without another look at the device), host draws, second half
+            self.worlds.step_split()
+            snap = self._snapshot()
+            nf, npo, ns, ne = (int(x) for x in snap["pre_counts"][0])
+            tape, self._n_empty = self._draw_add_food(nf, npo, ns, ne)
+            self.worlds.step_food(self.worlds.make_tape([tape]))
+            self._refresh(after="step")
+            self._mirrors[0] = self._build_mirror(0, snap)   # (its cell_type predates the food: env.grid fetches its own)
         else:
             self.worlds.step()
-        self._refresh(after="step")
+            self._refresh(after="step")
 
     def update_env(self, n_epi=0):
         """environment.py:188-215"""
@@ -357,14 +407,15 @@ class Environment:
                 k[t] = np.random.randint(0, n_empty)
                 u[t] = np.random.random()
                 n_empty -= u[t] < p
-        return {"food_k": k, "food_u": u, "repro_u": [], "birth_k": [], "produce_u": 0.0, "produce_choice": 0}
+        return {"food_k": k, "food_u": u, "repro_u": [], "birth_k": [], "produce_u": 0.0, "produce_choice": 0}, n_empty
 
     def _draw_update(self):
         """_reproduce / _produce (environment.py:488-547) over the post-step agent list (host mirror)."""
         import random
         h = self._host
         n1 = len(h["a_age"])
-        n_empty = int((self.grid == _lib.EMPTY).sum())
+        # (empty cells after _add_food: known from step()'s own draws; a caller who changed the world in between reads the grid)
+        n_empty = self._n_empty if self._n_empty is not None else int((self.grid == _lib.EMPTY).sum())
         repro_u, birth_k = [], []
         produce_u, choice, produced = 0.0, 0, False
 
@@ -471,28 +522,48 @@ class Environment:
         torch.cuda.synchronize(self.worlds.device)
         self.worlds.check_error_flag()
 
+    def _snapshot(self):
+        """The device state on the host behind everything queued so far: ONE copy and ONE wait for a small handle (DeviceWorlds.snapshot);
+        the error flag comes with it."""
+        snap = self.worlds.snapshot()
+        self.worlds.raise_on_error_flag(snap["err"])
+        self._ticks_since_check = 0
+        return snap
+
+    def _build_mirror(self, world, snap):
+        m = _WorldMirror(self, world, self._phase)
+        n = m.n = int(snap["n_agents"][world])
+        if world == 0 and "max_gene" in snap:
+            self._max_gene = int(snap["max_gene"][0])
+        m.host = {k: snap[k][world, :n] for k in _A_FIELDS}
+        if self._phase == "step":
+            m.src1, m.reward, m.done = snap["src1"][world], snap["reward"][world, :n], snap["done"][world, :n]
+        if self._phase == "update" and self._acted:   # act() has run: what the policy chose for this tick (and what it computed)
+            m.actions = snap["actions"][world].copy()
+            m.q = snap["out_q"][world]
+        else:                                          # Agent.action: the action last taken (-1 for newborns)
+            m.actions = np.concatenate([m.host["a_action"], np.full(self.worlds.cap - n, -1, np.int8)])
+        self._mirrors[world] = m   # (before the views: AgentView looks its mirror up)
+        m.views = [AgentView(self, k, m) for k in range(n)]
+        return m
+
     def _mat(self, world):
         """The host mirror of one world, built from the device state on first use."""
         m = self._mirrors.get(world)
         if m is None:
             w = self.worlds
-            self._sync()
-            m = _WorldMirror(world)
-            n = int(w.s["n_agents"][world].item())
-            m.host = {k: w.s[k][world, :n].cpu().numpy() for k in w.s if k.startswith("a_")}
-            if self._phase == "step":   # Agent.state is still the observation the policy read, in the pre-step order
-                src = w.src1[world, :n].cpu().numpy().astype(np.int64)
-                m.state = w.obs_state()[world].cpu().numpy().astype(np.float64)[src]
-                m.state_prime = w.obs_state_prime()[world, :n].cpu().numpy().astype(np.float64)
-                m.reward = w.reward[world, :n].cpu().numpy()
-                m.done = w.done[world, :n].cpu().numpy()
-            else:
-                m.state = w.obs_state()[world, :n].cpu().numpy().astype(np.float64)
-            if not (self._phase == "update" and self._acted):   # Agent.action: the action last taken (-1 for newborns) ...
-                m.actions = np.concatenate([m.host["a_action"], np.full(w.cap - n, -1, np.int8)])
-            self._mirrors[world] = m   # (before the views: AgentView looks its mirror up)
-            m.views = [AgentView(self, k, m) for k in range(n)]
-        if m.actions is None:          # ... or, once act() has run, what the policy chose for this tick
+            if hasattr(w, "snapshot") and w._arena.numel() <= w.SNAPSHOT_MAX_BYTES:
+                m = self._build_mirror(world, self._snapshot())
+            else:   # a big handle: this world's rows only
+                self._sync()
+                n = int(w.s["n_agents"][world].item())
+                snap = {k: w.s[k][world:world + 1, :n].cpu().numpy() for k in w.s if k.startswith("a_")}
+                snap["n_agents"] = np.array([n])
+                for k in ("src1", "reward", "done", "actions", "out_q"):
+                    snap[k] = getattr(w, k)[world:world + 1].cpu().numpy()
+                snap = {k: _Shift(v, world) for k, v in snap.items()}   # (a plain dict: keys() / [] like a snapshot)
+                m = self._build_mirror(world, snap)
+        if m.actions is None:          # act() ran after this mirror was built: what the policy chose for this tick
             m.actions = self.worlds.actions[world].cpu().numpy().copy()
         return m
 
@@ -502,6 +573,23 @@ class Environment:
         self._acted = False
         self._mirrors = {}
         self._grid = self._max_gene = None
+        self._stamp += 1
+        if after != "step":
+            self._n_empty = None
+
+
+class _Shift:
+    """A one-world slice that answers to the world's index in the full array (big handles: Environment._mat)."""
+
+    def __init__(self, a, world):
+        self.a, self.world = a, world
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):
+            assert key[0] == self.world
+            return self.a[(0,) + key[1:]]
+        assert key == self.world
+        return self.a[0]
 
 
 def resolve_dist(dist=None):

@@ -27,6 +27,33 @@ _STATE_SPEC = [  # name, torch dtype, shape suffix
 _EPS_RING = {}
 
 
+_NP = {torch.uint8: np.uint8, torch.int8: np.int8, torch.int16: np.int16, torch.int32: np.int32, torch.float32: np.float32,
+       torch.float64: np.float64}
+
+
+_raw_stream = torch._C._cuda_getCurrentRawStream
+
+
+class _Snapshot:
+    """DeviceWorlds.snapshot(): name -> numpy array over one host copy of the state arena; the typed views are made on first use."""
+
+    def __init__(self, buf, layout):
+        self._buf, self._layout, self._views = buf, layout, {}
+
+    def __getitem__(self, name):
+        v = self._views.get(name)
+        if v is None:
+            o, nb, dt, shape = self._layout[name]
+            v = self._views[name] = self._buf[o:o + nb].view(_NP[dt]).reshape(shape)
+        return v
+
+    def __contains__(self, name):
+        return name in self._layout
+
+    def keys(self):
+        return self._layout.keys()
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -51,6 +78,7 @@ class DeviceWorlds:
                                         "(there is no CPU fallback)")
         self.lib = _lib.lib()
         self.device = torch.device(device)
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.R, self.W, self.H, self.C = n_worlds, width, height, width * height
         self.cap = slot_cap or _lib.slot_cap_for(max_agents)
         self.max_agents, self.n_brains = max_agents, n_brains
@@ -61,27 +89,38 @@ class DeviceWorlds:
         _lib.check(self.lib.rl_create(C.byref(self.cfg), C.byref(self.handle)), "rl_create")
         dims = {"C": (self.C,), "cap": (self.cap,), "best": (_lib.N_BEST,), "": ()}
         with torch.cuda.device(self.device):
-            self.s = {n: torch.zeros((self.R,) + dims[suf], dtype=dt, device=self.device) for n, dt, suf in _STATE_SPEC}
+            R, cap = self.R, self.cap
+            # The world state and every small per-tick output live in ONE allocation (`_arena`, each array 256-byte aligned inside it), so
+            # that a host which has to look at a world every tick -- Environment(rng="reference"): the reference's generator draws are
+            # made on the host -- fetches all of it with ONE copy (snapshot()) instead of one small copy per array.  The kernels see
+            # plain pointers, as before.
+            spec = [(n, dt, (R,) + dims[suf]) for n, dt, suf in _STATE_SPEC]
+            spec += [("actions", torch.int8, (R, cap)), ("n_acted", torch.int32, (R,)), ("reward", torch.float32, (R, cap)),
+                     ("done", torch.uint8, (R, cap)), ("src1", torch.int16, (R, cap)), ("src2", torch.int16, (R, cap)),
+                     ("n_post", torch.int32, (R,)), ("pre_counts", torch.int32, (R, 4)), ("err", torch.int32, (4,)),
+                     ("out_q", torch.float32, (R, cap, 8))]
+            self._layout, off = {}, 0
+            for name, dt, shape in spec:
+                nbytes = int(np.prod(shape)) * torch.empty(0, dtype=dt).element_size()
+                self._layout[name] = (off, nbytes, dt, shape)
+                off += (nbytes + 255) // 256 * 256
+            self._arena = torch.zeros(off, dtype=torch.uint8, device=self.device)
+            self._arena_host = None
+            carve = {name: self._arena[o:o + nb].view(dt).view(shape) for name, (o, nb, dt, shape) in self._layout.items()}
+            self.s = {n: carve[n] for n, _, _ in _STATE_SPEC}
             self.s["best_uid"].fill_(-1)
             self.s["max_gene"].fill_(n_brains)
-            R, cap = self.R, self.cap
-            self.actions = torch.zeros((R, cap), dtype=torch.int8, device=self.device)
-            self.n_acted = torch.zeros(R, dtype=torch.int32, device=self.device)
-            self.reward = torch.zeros((R, cap), dtype=torch.float32, device=self.device)
-            self.done = torch.zeros((R, cap), dtype=torch.uint8, device=self.device)
-            self.src1 = torch.full((R, cap), -1, dtype=torch.int16, device=self.device)
+            self.actions, self.n_acted, self.reward, self.done = carve["actions"], carve["n_acted"], carve["reward"], carve["done"]
+            self.src1, self.src2 = carve["src1"].fill_(-1), carve["src2"].fill_(-1)
+            self.n_post, self.pre_counts, self.err, self.out_q = carve["n_post"], carve["pre_counts"], carve["err"], carve["out_q"]
             # +1 row of padding keeps 16-byte row reads of the policy kernel inside the allocation
             self.obs1 = torch.zeros((R * cap + 1, _lib.OBS_DIM), dtype=torch.float32, device=self.device)
-            self.src2 = torch.full((R, cap), -1, dtype=torch.int16, device=self.device)
             # Agent.state lives in a ping-pong pair: a tick writes the new observations into the other buffer, so the
             # observations the policy read for that tick stay available for transition capture
             self._obs2 = [torch.zeros((R * cap + 1, _lib.OBS_DIM), dtype=torch.float32, device=self.device) for _ in range(2)]
             self._cur = 0
-            self.n_post = torch.zeros(R, dtype=torch.int32, device=self.device)
             self.age1 = torch.zeros((R, cap), dtype=torch.int32, device=self.device)
             self.brain1 = torch.zeros((R, cap), dtype=torch.int32, device=self.device)
-            self.out_q = torch.zeros((R, cap, 8), dtype=torch.float32, device=self.device)
-            self.err = torch.zeros(4, dtype=torch.int32, device=self.device)
             self.refill_count = torch.zeros(1, dtype=torch.int32, device=self.device)
             self.acted_total = torch.zeros(1, dtype=torch.int64, device=self.device)
             self.G = n_brains if static_families else 1
@@ -117,7 +156,16 @@ class DeviceWorlds:
 
     # -- helpers ------------------------------------------------------------------------------------------------
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # (the raw handle of torch's current stream on this device: ~0.3 us, where torch.cuda.current_stream() builds a Stream object
+        # in ~5 us -- eight launches per tick of a host-driven loop)
+        return C.c_void_p(_raw_stream(self._dev_index))
+
+    def _cur_stream(self):
+        """torch's current stream on this device as a Stream object (for Event.record), rebuilt only when the raw handle has changed."""
+        raw = _raw_stream(self._dev_index)
+        if getattr(self, "_cs_raw", None) != raw:
+            self._cs_raw, self._cs = raw, torch.cuda.current_stream(self.device)
+        return self._cs
 
     def obs_state(self):
         """[R, cap, 153] view of Agent.state (post-update observation)."""
@@ -158,6 +206,25 @@ class DeviceWorlds:
             done.record(self._side)
         return _Readback(host, done)
 
+    SNAPSHOT_MAX_BYTES = 1 << 20
+
+    def snapshot(self):
+        """Host copy of the whole state arena (every rl_state array, actions, n_acted, reward, done, src1 / src2, step_split's counts, the
+        error flag, the policy outputs) behind everything queued on the current stream: ONE device-to-host copy and ONE wait, whatever
+        the number of arrays -> {name: numpy array}.  For hosts that look at their worlds every tick (a single world driven by the
+        reference's generators); refused for big handles, whose callers read single worlds (world())."""
+        nbytes = self._arena.numel()
+        if nbytes > self.SNAPSHOT_MAX_BYTES:
+            raise _lib.ReinLifeHipError("snapshot(): %d bytes of state; read single worlds of a handle this large with world()" % nbytes)
+        if self._arena_host is None:
+            self._arena_host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+            self._arena_np = self._arena_host.numpy()
+            self._arena_done = torch.cuda.Event()
+        self._arena_host.copy_(self._arena, non_blocking=True)
+        self._arena_done.record(self._cur_stream())
+        self._arena_done.synchronize()
+        return _Snapshot(self._arena_np.copy(), self._layout)   # (a copy: the pinned buffer is reused by the next snapshot)
+
     # -- host <-> device state (parity I/O) ----------------------------------------------------------------------
     def load_world(self, w, snap):
         n = len(snap["i"])
@@ -186,22 +253,53 @@ class DeviceWorlds:
         return d
 
     def make_tape(self, tapes):
-        """tapes: one dict per world (food_k, food_u, repro_u, birth_k, produce_u, produce_choice) -> device Tape."""
+        """tapes: one dict per world (food_k, food_u, repro_u, birth_k, produce_u, produce_choice) -> device Tape.  The six arrays are
+        carved out of one pinned host buffer and one device buffer: ONE host-to-device copy per tape (a host that draws every tick
+        uploads two tapes per tick).  The device buffer is rewritten in stream order (behind the launch that read the previous tape);
+        the pinned buffers form a ring of four, each reused only once its last upload has executed."""
         R, cap = self.R, self.cap
-        host = {"food_k": np.zeros((R, _lib.FOOD_TRIES), np.int32), "food_u": np.zeros((R, _lib.FOOD_TRIES), np.float64),
-                "repro_u": np.zeros((R, cap), np.float64), "birth_k": np.zeros((R, cap + 1), np.int32),
-                "produce_u": np.zeros(R, np.float64), "produce_choice": np.zeros(R, np.int32)}
+        if getattr(self, "_tape_ring", None) is None:
+            spec = [("food_k", np.int32, (R, _lib.FOOD_TRIES)), ("food_u", np.float64, (R, _lib.FOOD_TRIES)), ("repro_u", np.float64, (R, cap)),
+                    ("birth_k", np.int32, (R, cap + 1)), ("produce_u", np.float64, (R,)), ("produce_choice", np.int32, (R,))]
+            lay, off = {}, 0
+            for name, dt, shape in spec:
+                nb = int(np.prod(shape)) * np.dtype(dt).itemsize
+                lay[name] = (off, nb, dt, shape)
+                off += (nb + 255) // 256 * 256
+            self._tape_layout, self._tape_bytes = lay, off
+            self._tape_dev = torch.zeros(off, dtype=torch.uint8, device=self.device)
+            self._tape_ring = []
+            for _ in range(4):
+                pin = torch.zeros(off, dtype=torch.uint8).pin_memory()
+                buf = pin.numpy()
+                self._tape_ring.append([pin, None, {n: buf[o:o + nb].view(dt).reshape(shape) for n, (o, nb, dt, shape) in lay.items()}])
+            self._tape_next = 0
+            base = self._tape_dev.data_ptr()
+            self._tape_struct = _lib.Tape(*[C.c_void_p(base + lay[n][0]) for n in _lib.TAPE_FIELDS])
+        slot = self._tape_ring[self._tape_next % 4]
+        self._tape_next += 1
+        if slot[1] is not None:
+            slot[1].synchronize()
+        host = slot[2]
         for w, t in enumerate(tapes):
             host["food_k"][w] = t["food_k"]
             host["food_u"][w] = t["food_u"]
             m = min(cap, len(t["repro_u"]))
             host["repro_u"][w, :m] = t["repro_u"][:m]
+            host["repro_u"][w, m:] = 0
             m = min(cap + 1, len(t["birth_k"]))
             host["birth_k"][w, :m] = t["birth_k"][:m]
+            host["birth_k"][w, m:] = 0
             host["produce_u"][w] = t["produce_u"]
             host["produce_choice"][w] = t["produce_choice"]
-        self._tape_keep = {k: torch.as_tensor(v, device=self.device) for k, v in host.items()}
-        return _lib.Tape(*[_ptr(self._tape_keep[n]) for n in _lib.TAPE_FIELDS])
+        for name in ("food_k", "food_u", "repro_u", "birth_k", "produce_u", "produce_choice"):   # (worlds beyond the list: zeros, as before)
+            if len(tapes) < R:
+                host[name][len(tapes):] = 0
+        self._tape_dev.copy_(slot[0], non_blocking=True)
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        slot[1].record(self._cur_stream())
+        return self._tape_struct
 
     # -- the path -----------------------------------------------------------------------------------------------
     @property
@@ -263,10 +361,26 @@ class DeviceWorlds:
             self._trk_dirty = False
 
     def set_actions(self, actions):
-        a = torch.as_tensor(np.ascontiguousarray(actions, dtype=np.int8) if not torch.is_tensor(actions) else actions,
-                            device=self.device).to(torch.int8)
-        assert tuple(a.shape) == (self.R, self.cap)
-        self.actions.copy_(a)
+        if torch.is_tensor(actions):
+            a = actions.to(device=self.device, dtype=torch.int8)
+            assert tuple(a.shape) == (self.R, self.cap)
+            self.actions.copy_(a)
+            return
+        # a host array: through a pinned staging buffer (two, alternating; each reused only once its last upload has executed)
+        if getattr(self, "_act_ring", None) is None:
+            self._act_ring = [[torch.zeros((self.R, self.cap), dtype=torch.int8).pin_memory(), None] for _ in range(2)]
+            self._act_next = 0
+        slot = self._act_ring[self._act_next & 1]
+        self._act_next += 1
+        if slot[1] is not None:
+            slot[1].synchronize()
+        a = np.asarray(actions)
+        assert a.shape == (self.R, self.cap)
+        slot[0].numpy()[...] = a      # (casts to int8 like the former as_tensor(...).to(int8))
+        self.actions.copy_(slot[0], non_blocking=True)
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        slot[1].record(self._cur_stream())
 
     def step(self, actions=None, tape=None):
         if actions is not None:
@@ -280,8 +394,6 @@ class DeviceWorlds:
         """First half of a split step; returns the device tensor [R,4] (food, poison, super food, empty cells after movement)."""
         if actions is not None:
             self.set_actions(actions)
-        if not hasattr(self, "pre_counts"):
-            self.pre_counts = torch.zeros((self.R, 4), dtype=torch.int32, device=self.device)
         self._trk_dirty = self._trk_dirty or self.tracking
         _lib.check(self.lib.rl_step_split(self.handle, _ptr(self.actions), C.byref(self._step_out), _ptr(self.pre_counts),
                                           self._stream()), "rl_step_split")
