@@ -400,6 +400,21 @@ def c5_leg(args, rank, device, dist=None):
                      "the slowest rank's wall time; inputs resident in HBM"}
 
 
+def tuning_halves(args):
+    """tools/run_halves.py --json in a subprocess that loads lib/libreinlife_hip_tune.so (RL_TUNE=1 python reinlife_amd/build.py); an
+    {"error": ...} when that library is not built for the current sources -- the benchmark never builds or loads it itself."""
+    env = dict(os.environ, RL_TUNE="1")
+    env.pop("REINLIFE_HIP_LIB", None)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_halves.py"), "--json", "--no-build", "--worlds", str(args.worlds),
+                              "--workload", args.workload, "--seed", str(args.seed)], env=env, capture_output=True, text=True, timeout=300)
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": "tools/run_halves.py failed: %r" % (e,)}
+
+
 def torchrun_command(args, argv, n_visible):
     """(cmd, env) of `python bench.py --gpus N` with N > 1 and no torchrun environment: N ranks of this script, one per GPU, through
     torch.distributed.run on 127.0.0.1 with a free port -- the launch line the driver uses.  Refuses more ranks than visible GPUs
@@ -554,26 +569,20 @@ def main():
     roofline, extra = None, {}
     fused_roof = None
     if rank == 0 and not args.no_kernel_timing and fused:
-        # the multi-tick launch, HIP events around launches of N ticks; then its two halves alone (rl_debug_set_run_mask: the library
-        # skips one half of every tick -- results are then wrong, the work of the remaining half is the same)
-        def timed_run(n, debug=None):
+        # the multi-tick launch, HIP events around a launch of N ticks
+        def timed_run(n):
             # launches back to back in stream order, the last one between the events: the ones before it bring the chip to its
             # working clocks (a launch that follows a host round trip starts on a chip that has begun to clock down, and behind a
             # 0.5 ms launch it still is at its idle clocks: tools/launch_cost.py, tools/window_probe.py), and nothing but the
             # kernel lies between the events
             if n < 1000:
                 dw.run(1000, 70, 100)
-            if debug:
-                _lib.lib().rl_debug_set_run_mask(int(debug))   # explicit measurement switch of THIS process (never an environment variable)
-            try:
-                dw.run(n, 70, 100)
-                before = dw.acted_total.clone()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); dw.run(n, 70, 100); e1.record()
-                torch.cuda.synchronize()
-                return e0.elapsed_time(e1) * 1e-3 / n, (int(dw.acted_total.item()) - int(before.item())) / n
-            finally:
-                _lib.lib().rl_debug_set_run_mask(0)
+            dw.run(n, 70, 100)
+            before = dw.acted_total.clone()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); dw.run(n, 70, 100); e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / n, (int(dw.acted_total.item()) - int(before.item())) / n
         # the dominant kernel over the TIMED REGION: HIP events around its launches there (recorded on the launch stream); for a short
         # region, around a replay of its launch (same number of ticks) queued directly behind a warm launch, so that the events see
         # the kernel and not the host's launch latency in front of it
@@ -608,29 +617,24 @@ def main():
                                                 "current_kernel_src_sha16": now}
             except Exception:  # noqa: BLE001
                 pass
-        dw_state = {k: v.clone() for k, v in dw.s.items()}   # the half-runs leave wrong worlds behind: restore afterwards
-        obs_keep = [o.clone() for o in dw._obs2]
-        t_tick_half, n_tick_half = timed_run(200, "1")
-        for k, v in dw_state.items():
-            dw.s[k].copy_(v)
-        for o, keep in zip(dw._obs2, obs_keep):
-            o.copy_(keep)
-        t_pol_half, _ = timed_run(200, "2")
-        for k, v in dw_state.items():
-            dw.s[k].copy_(v)
-        for o, keep in zip(dw._obs2, obs_keep):
-            o.copy_(keep)
-        fused_roof["tick_half"] = {"us_per_tick": round(t_tick_half * 1e6, 2), "hbm_GBs": round(n_tick_half * TICK_BYTES_PER_AGENT_STEP / t_tick_half / 1e9, 1),
-                                   "hbm_frac": round(n_tick_half * TICK_BYTES_PER_AGENT_STEP / t_tick_half / 1e9 / HBM_PEAK_GBS, 4),
-                                   "how": "launches with the policy half skipped (rl_debug_set_run_mask(1))"}
-        # the policy half inside a full tick = the tick minus the tick half alone (the policy alone, with the tick half skipped, reads its
-        # rows from memory instead of the LDS mirror the tick half fills, and is slower than in place)
-        t_ref, _ = timed_run(200)   # (a steady 200-tick launch: the timed region's own figure carries a short launch's fixed cost)
-        t_pol_in = max(t_ref - t_tick_half, 1e-9)
-        fused_roof["policy_half"] = {"us_per_tick": round(t_pol_in * 1e6, 2), "mfma_tflops": round(per_tick * flop / t_pol_in / 1e12, 1),
-                                     "mfma_frac": round(per_tick * flop / t_pol_in / 1e12 / MFMA_F32_EQUIV_PEAK_TFLOPS, 4),
-                                     "alone_us_per_tick": round(t_pol_half * 1e6, 2),
-                                     "how": "per-tick time of a 200-tick launch - tick_half.us_per_tick; alone_us_per_tick = launches with the tick half skipped (rl_debug_set_run_mask(2): rows from memory, not from the LDS mirror)"}
+        # the launch's two halves alone: measured by the TUNING library in a process of its own (tools/run_halves.py: the switch that
+        # skips half of every tick -- results WRONG by design -- is not in the product library this process has loaded)
+        halves = tuning_halves(args)
+        if "error" in halves:
+            fused_roof["halves"] = halves["error"]
+        else:
+            t_tick_half, n_tick_half = halves["tick_half_us"] * 1e-6, halves["tick_half_agent_steps_per_tick"]
+            t_pol_in = max(halves["full_us"] * 1e-6 - t_tick_half, 1e-9)
+            pt = halves["agent_steps_per_tick"]
+            fused_roof["tick_half"] = {"us_per_tick": round(t_tick_half * 1e6, 2), "hbm_GBs": round(n_tick_half * TICK_BYTES_PER_AGENT_STEP / t_tick_half / 1e9, 1),
+                                       "hbm_frac": round(n_tick_half * TICK_BYTES_PER_AGENT_STEP / t_tick_half / 1e9 / HBM_PEAK_GBS, 4),
+                                       "how": "tools/run_halves.py on %s: launches with the policy half skipped (run mask 1)" % halves["library"]}
+            # the policy half inside a full tick = the tick minus the tick half alone (the policy alone, with the tick half skipped, reads its
+            # rows from memory instead of the LDS mirror the tick half fills, and is slower than in place)
+            fused_roof["policy_half"] = {"us_per_tick": round(t_pol_in * 1e6, 2), "mfma_tflops": round(pt * flop / t_pol_in / 1e12, 1),
+                                         "mfma_frac": round(pt * flop / t_pol_in / 1e12 / MFMA_F32_EQUIV_PEAK_TFLOPS, 4),
+                                         "alone_us_per_tick": round(halves["policy_alone_us"], 2),
+                                         "how": "per-tick time of a %d-tick launch of the same library (%.2f us) - tick_half.us_per_tick; alone_us_per_tick = launches with the tick half skipped (run mask 2: rows from memory, not from the LDS mirror)" % (halves["ticks"], halves["full_us"])}
     if rank == 0 and not args.no_kernel_timing:
         # (with --groups G the probe runs group 0 alone: its launches cover worlds/G worlds each)
         # back-to-back launches, no host sync inside the probe (a launch from an idle stream costs ~8 us extra): the event

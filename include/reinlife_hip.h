@@ -33,6 +33,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libreinlife_hip.so is built with -fvisibility=hidden: the declarations between this push and the pop at the end of the file ARE its
+ * export list (tests/test_abi_cpu.py compares the library's dynamic symbol table with them). */
+#pragma GCC visibility push(default)
 
 #define RL_OBS_DIM 153   /* Environment.observation_space, environment.py:119 */
 #define RL_N_ACTIONS 8   /* Environment.action_space, environment.py:118; World/utils.py:4-17 */
@@ -272,17 +275,16 @@ int rl_policy_act(rl_world* h, const rl_brain* brains, int n_brains, const float
 
 /* ---- options -------------------------------------------------------------------------------------------------- */
 /* Tuning / test switches (nothing like them in the reference).  Process-level values start from the environment, read ONCE
- * (RL_WORLD_BLOCK, RL_WORLD_GENERIC, RL_POLICY_VARIANT, RL_POLICY_PER_KIND, RL_RUN_ALWAYS), and change only through rl_set_option;
+ * (RL_WORLD_BLOCK, RL_WORLD_GENERIC, RL_POLICY_VARIANT, RL_RUN_ALWAYS), and change only through rl_set_option;
  * rl_create copies them into the handle, so a handle's kernels never change under it and no launch reads the environment.
  *   "world_block"      "0" (by world count) | "256" | "512" | "1024": workgroup size of the world kernels and of rl_run
  *   "world_generic"    "1": the generic world code also for the default 30x30 / 100-agent shape
  *   "policy_variant"   "auto" (default: the tiles of rl_run's policy half -- ONE arithmetic on every path: `pair`, or `dense` for
- *                      dueling brains from 1,536 tiles on, bit-identical to each other) | "pair" | "dense" | "wave" | "nsplit" (the
- *                      4-wave tile of earlier rounds: equal to the others to ~1e-7, not bit for bit; measurements only)
- *   "policy_per_kind"  "1": with "nsplit", one launch per brain kind instead of the mixed-kind launch
+ *                      dueling brains from 1,536 tiles on, bit-identical to each other) | "pair" | "dense" | "wave" (one wave per
+ *                      tile, dueling kinds; the same bits).  Every variant computes the same Q values bit for bit.
  *   "run_always"       "1": callers that choose between rl_run and the two-launch loop by world count take rl_run
  * value NULL restores what the environment says.  rl_get_option: the handle's snapshot (h != NULL) or the process level (h == NULL);
- * policy_variant as 0 auto, 1 nsplit, 2 wave, 3 dense, 4 pair; -1 for an unknown name. */
+ * policy_variant as 0 auto, 2 wave, 3 dense, 4 pair; -1 for an unknown name. */
 int rl_set_option(const char* name, const char* value);
 int rl_get_option(const rl_world* h, const char* name);
 
@@ -290,6 +292,7 @@ int rl_get_option(const rl_world* h, const char* name);
 void rl_philox(uint64_t seed, uint32_t epoch, uint32_t world, uint32_t tick, uint32_t site, uint32_t index,
                uint32_t out[4]);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

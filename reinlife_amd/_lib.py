@@ -108,15 +108,19 @@ class ReinLifeHipError(RuntimeError):
 
 
 def lib():
-    """Load (building it first if the sources are newer / it is absent) the HIP library.  Never falls back."""
+    """Load the HIP library, building it first when it is absent OR stale: build() compares the content digest stamped beside every
+    object and the library (*.srchash) with the sources' and recompiles what differs -- a library older than its sources (an ABI change
+    since it was built) is never loaded silently.  REINLIFE_HIP_LIB names another build instead (tuning: A/B libraries, the tuning
+    library with the measurement switches); it is loaded as it is.  Never falls back to anything that is not the HIP library."""
     global _lib
     if _lib is None:
-        path = os.environ.get("REINLIFE_HIP_LIB") or _build.LIB_PATH  # override: A/B of alternative builds (tuning)
-        if not os.path.exists(path) or os.environ.get("REINLIFE_REBUILD"):
+        path = os.environ.get("REINLIFE_HIP_LIB")
+        if not path:
+            path = _build.LIB_PATH
             try:
-                _build.build()
+                _build.build(force=bool(os.environ.get("REINLIFE_REBUILD")))   # (a few file digests when everything is current)
             except Exception as e:  # noqa: BLE001
-                raise ReinLifeHipError("libreinlife_hip.so is missing and could not be built with hipcc: %s" % e)
+                raise ReinLifeHipError("libreinlife_hip.so is missing or older than its sources and could not be built with hipcc: %s" % e)
         handle = C.CDLL(path)
         for name, res, args in ABI:
             fn = getattr(handle, name)

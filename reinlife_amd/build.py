@@ -7,13 +7,21 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 PROFILE = bool(os.environ.get("RL_PHASE_PROFILE"))  # tuning build with in-kernel phase stamps
+# The TUNING library (RL_TUNE=1 -> lib/libreinlife_hip_tune.so): the product's kernels plus the measurement switches the product does not
+# carry -- rl_debug_set_run_mask (one half of every tick skipped: bench.py's tick_half / policy_half figures, tools/) and k_run<1024>
+# (DESIGN.md 5.10).  Results under a mask are WRONG by design; nothing in the product path loads this library.
+TUNE = bool(os.environ.get("RL_TUNE"))
 # A/B builds (tuning): RL_LIB_TAG=x RL_EXTRA_HIPCC_FLAGS=-D... -> lib/libreinlife_hip_x.so next to the product; load it with REINLIFE_HIP_LIB
-TAG = "_prof" if PROFILE else ("_" + os.environ["RL_LIB_TAG"] if os.environ.get("RL_LIB_TAG") else "")
+TAG = "_prof" if PROFILE else "_tune" if TUNE else ("_" + os.environ["RL_LIB_TAG"] if os.environ.get("RL_LIB_TAG") else "")
+TUNE_LIB_PATH = os.path.join(LIB_DIR, "libreinlife_hip_tune.so")
 LIB_PATH = os.path.join(LIB_DIR, "libreinlife_hip%s.so" % TAG)
 SOURCES = ["rl_world.hip", "rl_run.hip", "rl_policy.hip", "rl_capi.hip"]
 HEADERS = ["rl_common.h", "rl_policy_dev.h", "rl_world_dev.h", os.path.join("..", "..", "include", "reinlife_hip.h")]
 # -ffp-contract=off: the world kernels' float64 reward / fitness arithmetic must round exactly like the CPU path
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# -fvisibility=hidden: the export list is include/reinlife_hip.h (its declarations sit inside a visibility push(default))
+# --offload-compress: the gfx950 code objects are stored zstd-compressed in the fat binary (2.8 MB -> 0.7 MB; the runtime inflates them once, at load)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "--offload-compress", "-Wall",
+         "-Wno-unused-function"]
 FLAGS += os.environ.get("RL_EXTRA_HIPCC_FLAGS", "").split()
 
 
@@ -57,7 +65,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(LIB_DIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
-    flags = FLAGS + (["-DRL_PHASE_PROFILE"] if PROFILE else [])
+    flags = FLAGS + (["-DRL_PHASE_PROFILE", "-DRL_TUNING", "-DRL_RUN_1024", "-DRL_RUN_256"] if PROFILE else ["-DRL_TUNING", "-DRL_RUN_1024", "-DRL_RUN_256"] if TUNE else [])
     objs, digests, jobs = [], [], []
     for src in SOURCES:   # the translation units compile side by side (rl_world.hip alone takes over a minute)
         sp = os.path.join(CSRC, src)
@@ -81,7 +89,8 @@ def build(force=False, verbose=False):
         raise failed
     lib_want = _digest([], " ".join(digests))
     if force or jobs or not _stamp_ok(LIB_PATH, lib_want):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        vs = os.path.join(CSRC, "exports.map")   # global: rl_*; everything else (libstdc++ template instances, toolchain markers) local
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + vs, "-o", LIB_PATH] + objs
         if verbose:
             print(" ".join(cmd))
         if os.path.exists(LIB_PATH + ".srchash"):

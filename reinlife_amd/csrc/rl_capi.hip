@@ -34,7 +34,6 @@ static thread_local char g_err[512] = "";
 static int parse_variant(const char* v)
 {
     if (!v || !*v || !strcmp(v, "auto")) return RL_PV_AUTO;
-    if (!strcmp(v, "nsplit")) return RL_PV_NSPLIT;
     if (!strcmp(v, "wave")) return RL_PV_WAVE;
     if (!strcmp(v, "dense")) return RL_PV_DENSE;
     if (!strcmp(v, "pair")) return RL_PV_PAIR;
@@ -53,7 +52,6 @@ static rl_options options_from_env()
     o.world_generic = getenv("RL_WORLD_GENERIC") ? 1 : 0;
     const int v = parse_variant(getenv("RL_POLICY_VARIANT"));
     o.policy_variant = v < 0 ? RL_PV_AUTO : v;
-    o.policy_per_kind = getenv("RL_POLICY_PER_KIND") ? 1 : 0;
     o.run_always = getenv("RL_RUN_ALWAYS") ? 1 : 0;
     return o;
 }
@@ -105,10 +103,9 @@ int rl_set_option(const char* name, const char* value)
     } else if (!strcmp(name, "world_generic")) o.world_generic = value ? (atoi(value) != 0) : env.world_generic;
     else if (!strcmp(name, "policy_variant")) {
         const int v = value ? parse_variant(value) : env.policy_variant;
-        if (v < 0) { rl_set_error("rl_set_option: policy_variant must be auto, pair, dense, wave or nsplit"); return RL_E_INVALID; }
+        if (v < 0) { rl_set_error("rl_set_option: policy_variant must be auto, pair, dense or wave"); return RL_E_INVALID; }
         o.policy_variant = v;
-    } else if (!strcmp(name, "policy_per_kind")) o.policy_per_kind = value ? (atoi(value) != 0) : env.policy_per_kind;
-    else if (!strcmp(name, "run_always")) o.run_always = value ? (atoi(value) != 0) : env.run_always;
+    } else if (!strcmp(name, "run_always")) o.run_always = value ? (atoi(value) != 0) : env.run_always;
     else { rl_set_error("rl_set_option: unknown option '%s'", name); return RL_E_INVALID; }
     return RL_OK;
 }
@@ -120,7 +117,6 @@ int rl_get_option(const rl_world* h, const char* name)
     if (!strcmp(name, "world_block")) return o.world_block;
     if (!strcmp(name, "world_generic")) return o.world_generic;
     if (!strcmp(name, "policy_variant")) return o.policy_variant;
-    if (!strcmp(name, "policy_per_kind")) return o.policy_per_kind;
     if (!strcmp(name, "run_always")) return o.run_always;
     return -1;
 }
@@ -133,11 +129,17 @@ int rl_create(const rl_config* cfg, rl_world** out)
     if (!cfg || !out) { rl_set_error("rl_create: null argument"); return RL_E_INVALID; }
     *out = nullptr;
     if (cfg->width < 3 || cfg->height < 3 || cfg->width > 255 || cfg->height > 255) {  // Grid asserts >= 3 (grid.py:23-24)
-        rl_set_error("rl_create: width/height must be in [3,255] (got %dx%d)", cfg->width, cfg->height);
+        rl_set_error("rl_create: width/height must be in [3,255] (got %dx%d): the reference's Grid needs >= 3 (grid.py:23-24) and has no upper bound; "
+                     "this library keeps a world in ONE workgroup's LDS with 8-bit coordinates", cfg->width, cfg->height);
         return RL_E_INVALID;
     }
     const int cells = cfg->width * cfg->height;
-    if (cells > RL_MAX_CELLS) { rl_set_error("rl_create: %d cells > %d supported", cells, RL_MAX_CELLS); return RL_E_UNSUPPORTED; }
+    if (cells > RL_MAX_CELLS) {
+        rl_set_error("rl_create: %dx%d = %d cells, this library supports width*height <= %d (a world lives in one workgroup's 160 KB of LDS); "
+                     "the reference's Grid(width, height) is unbounded (grid.py:22-33) -- a LIMIT of this build, not a rule of the reference",
+                     cfg->width, cfg->height, cells, RL_MAX_CELLS);
+        return RL_E_UNSUPPORTED;
+    }
     if (cfg->n_brains < 1 || cfg->n_brains > RL_MAX_BRAINS) { rl_set_error("rl_create: n_brains must be in [1,%d]", RL_MAX_BRAINS); return RL_E_INVALID; }
     if (cfg->n_worlds < 1 || cfg->n_worlds >= (1 << 19)) { rl_set_error("rl_create: n_worlds must be in [1, 2^19)"); return RL_E_INVALID; }
     if (cfg->max_agents < 1) { rl_set_error("rl_create: max_agents must be >= 1"); return RL_E_INVALID; }

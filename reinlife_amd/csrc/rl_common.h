@@ -6,14 +6,13 @@
 #include "../../include/reinlife_hip.h"
 
 // Tuning / test switches.  Process-level defaults are read from the environment ONCE (first use: RL_WORLD_BLOCK, RL_WORLD_GENERIC,
-// RL_POLICY_VARIANT, RL_POLICY_PER_KIND, RL_RUN_ALWAYS) and changed only by rl_set_option(); rl_create() snapshots them into the handle,
+// RL_POLICY_VARIANT, RL_RUN_ALWAYS) and changed only by rl_set_option(); rl_create() snapshots them into the handle,
 // so no launch ever calls getenv and a handle's kernels do not change under it.  The handle-less rl_policy_forward reads the process level.
-enum { RL_PV_AUTO = 0, RL_PV_NSPLIT, RL_PV_WAVE, RL_PV_DENSE, RL_PV_PAIR };
+enum { RL_PV_AUTO = 0, RL_PV_WAVE = 2, RL_PV_DENSE, RL_PV_PAIR };   // (1 was the 4-wave "nsplit" tile of rounds 1-2, removed in round 5)
 struct rl_options {
     int world_block;      // 0 = by world count; 256 / 512 / 1024 = workgroup size of the world kernels and of rl_run
     int world_generic;    // 1 = the generic (not shape-specialised) world code also for the default 30x30 / 100-agent shape
     int policy_variant;   // RL_PV_*: which stand-alone policy kernel (auto: the tiles of rl_run's policy half, one arithmetic everywhere)
-    int policy_per_kind;  // 1 = (nsplit only) one launch per brain kind instead of the mixed-kind launch
     int run_always;       // 1 = DeviceWorlds.run() takes the multi-tick launch at any world count (host side reads it through rl_get_option)
 };
 const rl_options& rl_options_current();

@@ -58,66 +58,6 @@ struct PolicyArgs {
 #endif
 };
 
-// One launch serves every brain of one kind: the tile space is the concatenation of the brains' 32-row tiles; one
-// 4-wave workgroup per tile (policy_tile, rl_policy_dev.h).
-template <int KIND, bool DEEP>
-__global__ __launch_bounds__(256, (KIND == RL_PPO ? 2 : (DEEP ? 3 : 4))) void k_policy(const PolicyArgs A)
-{
-    __shared__ __attribute__((aligned(16))) f32x4 lds_h[policy_lds_units(KIND)];
-    __shared__ __attribute__((aligned(16))) float lds_aux[kAuxFloats];  // row scales
-    __shared__ float lds_part[4][32][9];                        // per-wave head partials
-    const int lane = threadIdx.x & 63, j = lane & 31, v = threadIdx.x >> 6;
-    {   // one batch of scalar loads touches every 64-byte line of the argument block (the brain table is read entry by
-        // entry below: each first touch of a line would be a scalar-cache miss on the way to the row list)
-        auto ka = __builtin_amdgcn_kernarg_segment_ptr();
-        int t0, t1, t2, t3, t4, t5;
-        asm volatile("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\t"
-                     "s_load_dword %3, %6, 0xc0\n\ts_load_dword %4, %6, 0x100\n\ts_load_dword %5, %6, 0x140\n\ts_waitcnt lgkmcnt(0)"
-                     : "=s"(t0), "=s"(t1), "=s"(t2), "=s"(t3), "=s"(t4), "=s"(t5) : "s"(ka) : "memory");
-        static_assert(sizeof(PolicyArgs) >= 0x140 + 4 && sizeof(PolicyArgs) <= 0x180, "the warm-up loads must cover the argument block");
-    }
-#ifdef RL_PHASE_PROFILE
-    if (A.prof && (int)blockIdx.x == A.prof_block && blockIdx.y == 0 && threadIdx.x == 0) A.prof[100] = (long long)clock64();
-#endif
-    // grid = (tiles a brain can have at most, brains of this launch): the brain and the tile follow from the block index,
-    // so the row-list entry is requested together with the brain's row count instead of after it (one dependent round
-    // trip less at the head of every workgroup).  Entries beyond the count are stale or zero row ids: still valid rows.
-    typedef const int __attribute__((address_space(4))) cint;
-    {
-        const int bi = blockIdx.y, tile = blockIdx.x;
-        const BrainSlot B = A.b[bi];
-        const int li = tile * 32 + j;
-        // list entries are (world << 12) | slot (rl_common.h): world and slot without a division, row = world * cap + slot
-        const int entry = B.rowlist ? B.rowlist[li] : 0;
-        const int e_w = rl_list_world(entry), e_k = rl_list_slot(entry);
-        const int64_t listed = B.rowlist ? (int64_t)e_w * A.cap + e_k : (int64_t)li;
-        const int n = B.count_ptr ? ((cint*)B.count_ptr)[0] : (int)A.n_rows;
-        if (tile * 32 >= n) return;
-        TileIO io;
-        io.packed = (gfloat*)B.packed;
-        io.obs = A.obs;
-        io.valid = li < n;
-        io.row = (io.valid || B.rowlist) ? listed : (int64_t)tile * 32;  // dense mode: rows past the end do not exist
-        io.eps = B.eps; io.out = A.out; io.actions = A.actions; io.seed = A.seed;
-        io.key_world = io.key_tick = io.key_epoch = io.key_index = 0;
-        io.lds_actions_off = -1; io.lds_slot = 0; io.x_lds_off = -1; io.c_lds_off = -1;
-        // the draw's Philox key needs the world's tick / epoch: fetch them now, not in the epilogue's dependent chain
-        if (A.actions && v == 0 && lane < 32) {  // rl_policy_act always passes row lists
-            io.key_world = (uint32_t)(A.world_base + e_w); io.key_index = (uint32_t)e_k;
-            io.key_tick = (uint32_t)A.tick[e_w]; io.key_epoch = (uint32_t)A.epoch[e_w];
-        }
-#ifdef RL_PHASE_PROFILE
-        io.prof = (A.prof && (int)blockIdx.x == A.prof_block && blockIdx.y == 0) ? A.prof : nullptr;
-        if (io.prof && threadIdx.x == 0) io.prof[101] = (long long)clock64();
-#endif
-#ifdef RL_ABL_TILE  // tuning experiment: front end only
-        if (io.actions && io.valid && v == 0 && lane < 32) io.actions[io.row] = (int8_t)(io.key_tick & 7);
-#else
-        policy_tile<KIND, DEEP>(io, lds_h, lds_aux, lds_part, lane, v);
-#endif
-    }
-}
-
 // One wave per tile (policy_tile1, the dueling kinds): a 64-thread workgroup per (tile, brain), no LDS, no barrier.
 template <int KIND>
 __global__ __launch_bounds__(64, 2) void k_policy1(const PolicyArgs A)
@@ -296,71 +236,6 @@ __global__ __launch_bounds__(128 * kPairTiles) void k_policy_pair(const PolicyAr
         if (kind == RL_DQN) pair_finish<RL_DQN>(io, lane, part, &pl);
         else if (kind == RL_PPO) pair_finish<RL_PPO>(io, lane, part, &pl);
         else tile1_finish<RL_PERD3QN>(io, lane, part.head, pl.val[j], part.draw, *(const f32x4*)(lds_c + 768 + 8 + 4 * (lane >> 5)));
-    }
-}
-
-// Brains of DIFFERENT kinds in one launch (mixed populations, BASELINE configs[4]): one launch per kind ran them back to
-// back (PPO 16 us + PERD3QN 13.5 us for the two halves of 680 tiles); here every workgroup picks its brain's tile code at run
-// time, so the kinds overlap on the chip.  Register budget and LDS are the widest kind's (PPO: 2 waves per SIMD).
-__global__ __launch_bounds__(256, 2) void k_policy_mixed(const PolicyArgs A)
-{
-    __shared__ __attribute__((aligned(16))) f32x4 lds_h[policy_lds_units(RL_PPO)];
-    __shared__ __attribute__((aligned(16))) float lds_aux[kAuxFloats];  // row scales
-    __shared__ float lds_part[4][32][9];                        // per-wave head partials
-    const int lane = threadIdx.x & 63, j = lane & 31, v = threadIdx.x >> 6;
-    {   // one batch of scalar loads touches every 64-byte line of the argument block (the brain table is read entry by
-        // entry below: each first touch of a line would be a scalar-cache miss on the way to the row list)
-        auto ka = __builtin_amdgcn_kernarg_segment_ptr();
-        int t0, t1, t2, t3, t4, t5;
-        asm volatile("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\t"
-                     "s_load_dword %3, %6, 0xc0\n\ts_load_dword %4, %6, 0x100\n\ts_load_dword %5, %6, 0x140\n\ts_waitcnt lgkmcnt(0)"
-                     : "=s"(t0), "=s"(t1), "=s"(t2), "=s"(t3), "=s"(t4), "=s"(t5) : "s"(ka) : "memory");
-        static_assert(sizeof(PolicyArgs) >= 0x140 + 4 && sizeof(PolicyArgs) <= 0x180, "the warm-up loads must cover the argument block");
-    }
-#ifdef RL_PHASE_PROFILE
-    if (A.prof && (int)blockIdx.x == A.prof_block && blockIdx.y == 0 && threadIdx.x == 0) A.prof[100] = (long long)clock64();
-#endif
-    // grid = (tiles a brain can have at most, brains of this launch): the brain and the tile follow from the block index,
-    // so the row-list entry is requested together with the brain's row count instead of after it (one dependent round
-    // trip less at the head of every workgroup).  Entries beyond the count are stale or zero row ids: still valid rows.
-    typedef const int __attribute__((address_space(4))) cint;
-    {
-        const int bi = blockIdx.y, tile = blockIdx.x;
-        const BrainSlot B = A.b[bi];
-        const int li = tile * 32 + j;
-        // list entries are (world << 12) | slot (rl_common.h): world and slot without a division, row = world * cap + slot
-        const int entry = B.rowlist ? B.rowlist[li] : 0;
-        const int e_w = rl_list_world(entry), e_k = rl_list_slot(entry);
-        const int64_t listed = B.rowlist ? (int64_t)e_w * A.cap + e_k : (int64_t)li;
-        const int n = B.count_ptr ? ((cint*)B.count_ptr)[0] : (int)A.n_rows;
-        if (tile * 32 >= n) return;
-        TileIO io;
-        io.packed = (gfloat*)B.packed;
-        io.obs = A.obs;
-        io.valid = li < n;
-        io.row = (io.valid || B.rowlist) ? listed : (int64_t)tile * 32;  // dense mode: rows past the end do not exist
-        io.eps = B.eps; io.out = A.out; io.actions = A.actions; io.seed = A.seed;
-        io.key_world = io.key_tick = io.key_epoch = io.key_index = 0;
-        io.lds_actions_off = -1; io.lds_slot = 0; io.x_lds_off = -1; io.c_lds_off = -1;
-        // the draw's Philox key needs the world's tick / epoch: fetch them now, not in the epilogue's dependent chain
-        if (A.actions && v == 0 && lane < 32) {  // rl_policy_act always passes row lists
-            io.key_world = (uint32_t)(A.world_base + e_w); io.key_index = (uint32_t)e_k;
-            io.key_tick = (uint32_t)A.tick[e_w]; io.key_epoch = (uint32_t)A.epoch[e_w];
-        }
-#ifdef RL_PHASE_PROFILE
-        io.prof = (A.prof && (int)blockIdx.x == A.prof_block && blockIdx.y == 0) ? A.prof : nullptr;
-        if (io.prof && threadIdx.x == 0) io.prof[101] = (long long)clock64();
-#endif
-#ifdef RL_ABL_TILE  // tuning experiment: front end only
-        if (io.actions && io.valid && v == 0 && lane < 32) io.actions[io.row] = (int8_t)(io.key_tick & 7);
-#else
-        switch (B.kind) {  // uniform per workgroup
-            case RL_DQN: policy_tile<RL_DQN, true>(io, lds_h, lds_aux, lds_part, lane, v); break;
-            case RL_D3QN: policy_tile<RL_D3QN, true>(io, lds_h, lds_aux, lds_part, lane, v); break;
-            case RL_PERD3QN: policy_tile<RL_PERD3QN, true>(io, lds_h, lds_aux, lds_part, lane, v); break;
-            default: policy_tile<RL_PPO, false>(io, lds_h, lds_aux, lds_part, lane, v); break;
-        }
-#endif
     }
 }
 
@@ -564,8 +439,7 @@ static int policy_grid(int64_t max_rows)  // tiles one brain can have: one 4-wav
 //           the dueling kinds; the default from 1,536 tiles on (2,048 / 4,096 / 10,880 tiles: 32.4 / 60.9 / 148 us against 38.6 / 72.7 /
 //           188 for the 4-wave tile)
 //   wave    k_policy1: one wave per tile, no LDS (dueling kinds; the same bits again) -- measurement only
-//   nsplit  k_policy / k_policy_mixed: the 4-wave N-split tile of rounds 1-2 (main + cross accumulators: agrees with the others to ~1e-7,
-//           NOT bit for bit) -- kept for measurements and for k_run<1024>, never chosen automatically
+// (The 4-wave N-split tile of rounds 1-2 -- "nsplit", ~1e-7 away from these -- was removed in round 5: it was nobody's arithmetic any more.)
 // The variant comes from the handle's option snapshot (rl_set_option / RL_POLICY_VARIANT at rl_create), not from getenv at the launch.
 static bool kind_is_dueling(int kind) { return kind == RL_D3QN || kind == RL_PERD3QN; }
 static int resolve_variant(int variant, bool all_dueling, int64_t expected_rows)
@@ -580,13 +454,13 @@ static int launch_check(const char* what)
     if (e != hipSuccess) { rl_set_error("%s launch failed: %s", what, hipGetErrorString(e)); return RL_E_LAUNCH; }
     return RL_OK;
 }
-// One launch for the brains in `a` (<= kMaxBrainsPerLaunch); `variant` already resolved; nsplit: all brains of `kind`.
+// One launch for the brains in `a` (<= kMaxBrainsPerLaunch); `variant` already resolved.
 static int launch_policy(int variant, int kind, const PolicyArgs& a, int64_t max_rows, int64_t expected_rows, hipStream_t st)
 {
     // grid = (tiles a brain can have at most, brains): the bound is several times the real tile count (a brain COULD own every
     // agent), but the ~2,500 empty workgroups cost < 1 us (a dense launch of the same 680 tiles without them: 17.6 vs 18.4 us).
     // Brain-fastest order (all real tiles dispatched first) is SLOWER: 21.6 vs 18.4 us.
-    const dim3 grid(policy_grid(max_rows), a.nb), block(256);
+    const dim3 grid(policy_grid(max_rows), a.nb);
     if (variant == RL_PV_PAIR) {
         int ex_bytes = kPairStageBytes;   // per tile: the staged rows (20.5 KB), then the exchange buffer of the widest kind (16 KB; PPO: 32 KB)
         for (int b = 0; b < a.nb; ++b) ex_bytes = ex_bytes > pair_ex_bytes(a.b[b].kind) ? ex_bytes : pair_ex_bytes(a.b[b].kind);
@@ -614,18 +488,8 @@ static int launch_policy(int variant, int kind, const PolicyArgs& a, int64_t max
         hipLaunchKernelGGL((k_policy1<RL_PERD3QN>), grid, dim3(64), 0, st, a);
         return launch_check("policy kernel (wave)");
     }
-    const bool deep = expected_rows / 32 <= 6 * 256;  // fewer than ~6 tiles per CU: latency-bound, deeper weight rings
-#define RL_LAUNCH(K) do { if (deep) hipLaunchKernelGGL((k_policy<K, true>), grid, block, 0, st, a); \
-                          else hipLaunchKernelGGL((k_policy<K, false>), grid, block, 0, st, a); } while (0)
-    switch (kind) {
-        case RL_DQN: RL_LAUNCH(RL_DQN); break;
-        case RL_D3QN: RL_LAUNCH(RL_D3QN); break;
-        case RL_PERD3QN: RL_LAUNCH(RL_PERD3QN); break;
-        case RL_PPO: hipLaunchKernelGGL((k_policy<RL_PPO, false>), grid, block, 0, st, a); break;
-        default: rl_set_error("unknown brain kind %d", kind); return RL_E_INVALID;
-    }
-#undef RL_LAUNCH
-    return launch_check("policy kernel (nsplit)");
+    rl_set_error("policy launch: unknown variant %d", variant);
+    return RL_E_INVALID;
 }
 
 int rl_policy_forward_impl(int kind, const float* packed, const float* obs, int64_t n_rows, float* out, hipStream_t st)
@@ -684,49 +548,19 @@ int rl_policy_act_impl(rl_world* h, const rl_brain* brains, int n_brains, const 
         s.kind = brains[b].kind;
         return s;
     };
-    // (D3QN and PERD3QN are ONE network -- D3QN.py:149-165, PERD3QN.py:186-202 -- and one kernel: a population of both is not "mixed")
-    auto canon = [](int k) { return k == RL_D3QN ? RL_PERD3QN : k; };
-    unsigned kinds = 0;
-    for (int b = 0; b < n_brains; ++b) {
+    for (int b = 0; b < n_brains; ++b)
         if (brains[b].kind < RL_DQN || brains[b].kind > RL_PPO) { rl_set_error("unknown brain kind %d", brains[b].kind); return RL_E_INVALID; }
-        kinds |= 1u << canon(brains[b].kind);
-    }
     bool all_dueling = true;
     for (int b = 0; b < n_brains; ++b) all_dueling = all_dueling && kind_is_dueling(brains[b].kind);
     const int variant = resolve_variant(h->opt.policy_variant, all_dueling, expected);
-    if (variant != RL_PV_NSPLIT) {
-        // one arithmetic (see launch_policy): the tiles of rl_run's policy half, brains of any kinds side by side in a launch
-        PolicyArgs a = base_args();
-        for (int b = 0; b < n_brains; ++b) {
-            a.b[a.nb++] = slot_of(b);
-            if (a.nb == kMaxBrainsPerLaunch || b + 1 == n_brains) {
-                if (int rc = launch_policy(variant, RL_PERD3QN, a, bound, expected, st)) return rc;
-                a.nb = 0;
-            }
+    // one arithmetic (see launch_policy): the tiles of rl_run's policy half, brains of any kinds side by side in a launch
+    PolicyArgs a = base_args();
+    for (int b = 0; b < n_brains; ++b) {
+        a.b[a.nb++] = slot_of(b);
+        if (a.nb == kMaxBrainsPerLaunch || b + 1 == n_brains) {
+            if (int rc = launch_policy(variant, RL_PERD3QN, a, bound, expected, st)) return rc;
+            a.nb = 0;
         }
-        return RL_OK;
-    }
-    // ---- nsplit (explicit option): the 4-wave tile of rounds 1-2
-    if ((kinds & (kinds - 1)) != 0 && n_brains <= kMaxBrainsPerLaunch && !h->opt.policy_per_kind) {
-        // several kinds: ONE launch, the tile code picked per workgroup (k_policy_mixed)
-        PolicyArgs a = base_args();
-        for (int b = 0; b < n_brains; ++b) a.b[a.nb++] = slot_of(b);
-        const dim3 grid(policy_grid(bound), a.nb), block(256);
-        hipLaunchKernelGGL(k_policy_mixed, grid, block, 0, st, a);
-        return launch_check("policy kernel (nsplit, mixed kinds)");
-    }
-    for (int kind = RL_DQN; kind <= RL_PPO; ++kind) {
-        if (kind == RL_D3QN) continue;   // (served by the PERD3QN pass)
-        PolicyArgs a = base_args();
-        for (int b = 0; b < n_brains; ++b) {
-            if (canon(brains[b].kind) != kind) continue;
-            a.b[a.nb++] = slot_of(b);
-            if (a.nb == kMaxBrainsPerLaunch) {
-                if (int rc = launch_policy(RL_PV_NSPLIT, kind, a, bound, expected, st)) return rc;
-                a.nb = 0;
-            }
-        }
-        if (a.nb) if (int rc = launch_policy(RL_PV_NSPLIT, kind, a, bound, expected, st)) return rc;
     }
     return RL_OK;
 }

@@ -114,14 +114,6 @@ __device__ inline f32x16 mfma16(const f32x4& a, const f32x4& b, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// the three partial products of one K-chunk (a / b: planes hi, lo): hi.hi into `main`, the cross terms into `cross`
-__device__ inline void mfma3(const f32x4 (&a)[kPlanes], const f32x4 (&b)[kPlanes], f32x16& main, f32x16& cross)
-{
-    cross = mfma16(a[0], b[1], cross);  // hi.lo
-    main = mfma16(a[0], b[0], main);    // hi.hi
-    cross = mfma16(a[1], b[0], cross);  // lo.hi
-}
-
 // Two values and their row's power-of-two scale -> packed f16 pairs: hi = f16(x * s) (round to nearest even), lo = f16(x * s - hi)
 // with x * s - hi evaluated exactly (one fused multiply-add in f32).  Four v_fma_mix instructions per pair -- the mixed-precision
 // FMA reads f32 and f16 sources and writes an f16 half directly; the earlier sequence (2 multiplies, cvt_pkrtz, 2 cvt back, 2
@@ -146,84 +138,6 @@ __device__ inline void split8(const float (&x)[8], float sc, f32x4& hi, f32x4& l
     for (int q = 0; q < 4; ++q) split_pair(x[2 * q], x[2 * q + 1], sc, h[q], l[q]);
     hi = f32x4{__builtin_bit_cast(float, h[0]), __builtin_bit_cast(float, h[1]), __builtin_bit_cast(float, h[2]), __builtin_bit_cast(float, h[3])};
     lo = f32x4{__builtin_bit_cast(float, l[0]), __builtin_bit_cast(float, l[1]), __builtin_bit_cast(float, l[2]), __builtin_bit_cast(float, l[3])};
-}
-
-// maximum of a non-negative float over the 64 lanes (DPP: no LDS traffic), returned in every lane
-__device__ inline float wave_max_nonneg(float v)
-{
-    int i = __builtin_bit_cast(int, v);  // non-negative floats order like their bit patterns
-    i = max(i, __builtin_amdgcn_update_dpp(0, i, 0x111, 0xF, 0xF, true));  // row_shr:1
-    i = max(i, __builtin_amdgcn_update_dpp(0, i, 0x112, 0xF, 0xF, true));  // row_shr:2
-    i = max(i, __builtin_amdgcn_update_dpp(0, i, 0x114, 0xF, 0xF, true));  // row_shr:4
-    i = max(i, __builtin_amdgcn_update_dpp(0, i, 0x118, 0xF, 0xF, true));  // row_shr:8
-    i = max(i, __builtin_amdgcn_update_dpp(0, i, 0x142, 0xA, 0xF, true));  // row_bcast:15
-    i = max(i, __builtin_amdgcn_update_dpp(0, i, 0x143, 0xC, 0xF, true));  // row_bcast:31
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 63));
-}
-
-// Observation tile in LDS, scaled, split and already in B-operand order: plane p (hi, lo) holds, for K-chunk c and lane
-// (row j = lane&31, half kh = lane>>5), the 8 f16 of x[j][16c + 8kh + 0..7] (zero beyond k = 152) as one 16-byte unit
-// at p*kXPlane + (2c + kh)*33 + j.  Groups are 33 (not 32) units apart so that the staging writes of one row (40 lanes,
-// one 8-byte half unit each) spread over the banks.
-constexpr int kXGroup = 33;
-constexpr int kXPlane = 2 * kInChunks * kXGroup;
-constexpr int kXsUnits = kPlanes * kXPlane;
-
-// Stage the 32 rows of a tile: wave v loads rows 8v..8v+7, ONE coalesced 612-byte read per row (lane m reads floats
-// 4m..4m+3), instead of every wave gathering 16 bytes per lane from 32 different rows for each K-step (64 cache lines
-// per load instruction, four times over).  Every row gets its power-of-two scale here (row maximum by DPP); 1 / scale
-// goes to row_unscale[row] for the input layer's epilogue.
-// `row_of_lane`: observation row id of tile row (lane & 31).
-// COHERENT: the rows were written earlier in the SAME launch (the multi-tick kernel of rl_world.hip): read them with sc1
-// (served by L2, never by a line this CU's vector L1 kept from an older pass over the same buffer).
-template <bool COHERENT, typename WHILE_IN_FLIGHT>
-__device__ inline void stage_x(f32x4* __restrict__ xs, float* __restrict__ row_unscale, const float* __restrict__ obs,
-                               int64_t row_of_lane, int lane, int v, WHILE_IN_FLIGHT&& while_in_flight)
-{
-    const int lo = (int)(row_of_lane & 0xffffffff), hi = (int)(row_of_lane >> 32);
-    f32x2* x2 = (f32x2*)xs;
-    const int unit0 = (lane >> 1) * kXGroup + 8 * v, half = lane & 1;  // lane m: floats 4m..4m+3 = half (m&1) of group m>>1
-    const int off = lane < 38 ? 4 * lane : 149;  // every lane loads (lanes >= 38 read floats 149..152, inside the row): not
-                                                 // predicated -- a predicated load drags its first use, and a wait, up to itself
-    f32x4 val[8];  // all eight rows of this wave in flight: one round trip
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        const int jj = 8 * v + rr;
-        const int64_t r = ((int64_t)__builtin_amdgcn_readlane(hi, jj) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, jj);
-#ifdef RL_ABL_X  // tuning experiment: no observation reads (results are WRONG)
-        val[rr] = f32x4{(float)r, 1.0f, 2.0f, 3.0f};
-#else
-        if (COHERENT) {
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)obs, 0, 0x7fffffff, 0x00027000);
-            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(r * (RL_OBS_DIM * 4)) + off * 4, 0, 16 /* sc1 */);
-            val[rr] = __builtin_bit_cast(f32x4, raw);
-        } else
-            val[rr] = *(const f32x4u*)(obs + r * RL_OBS_DIM + off);
-#endif
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    while_in_flight();  // independent work for the HBM round trip of the rows (the action draw)
-    __builtin_amdgcn_sched_barrier(0);
-
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        f32x4 t = val[rr];
-        if (lane == 38) t = f32x4{t.w, 0.0f, 0.0f, 0.0f};  // k = 152, then padding
-        else if (lane > 38) t = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        const float mx = wave_max_nonneg(fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w))));
-        float sc, un;
-        row_scale(mx, sc, un);
-        if (lane == 0) row_unscale[8 * v + rr] = un;
-        if (lane < 40) {
-            unsigned h0, l0, h1, l1;
-            split_pair(t.x, t.y, sc, h0, l0);
-            split_pair(t.z, t.w, sc, h1, l1);
-            const int u = (unit0 + rr) * 2 + half;
-            x2[u] = f32x2{__builtin_bit_cast(float, h0), __builtin_bit_cast(float, h1)};
-            x2[kXPlane * 2 + u] = f32x2{__builtin_bit_cast(float, l0), __builtin_bit_cast(float, l1)};
-        }
-    }
 }
 
 // The packed weights are STEP-major: [K-chunk][output tile][plane][lane][8 f16], so the fragments of one chunk are
@@ -287,43 +201,6 @@ struct EpiConsts {
 
 
 
-// K loop of one layer: B fragments from LDS planes `bsrc` (unit stride `bstep` per chunk, plane stride `bplane`), A
-// fragments from the ring.  Leaves acc[t] = sum hi.hi + hi.lo + lo.hi, still in the scaled domain.
-template <int NS, int TOUT, int NT, int TSTRIDE, int D>
-__device__ inline void k_loop(WRing<TOUT, NT, TSTRIDE, D>& w, const f32x4* __restrict__ bsrc, int bplane, int bstep, f32x16 (&acc)[NT],
-                              EpiConsts* epi = nullptr, gfloat* __restrict__ epi_consts = nullptr, int epi_t2 = 0, int epi_half = 0)
-{
-    f32x16 cross[NT];  // second accumulator chain: also keeps consecutive MFMAs of one wave independent
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.0f; cross[t][r] = 0.0f; }
-    f32x4 b[2][kPlanes];
-#pragma unroll
-    for (int pl = 0; pl < kPlanes; ++pl) b[0][pl] = bsrc[pl * bplane];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        f32x4 ac[NT][kPlanes], bc[kPlanes];
-#pragma unroll
-        for (int pl = 0; pl < kPlanes; ++pl) bc[pl] = b[s & 1][pl];
-        w.template next<NS>(s, ac);
-        if (s + 1 < NS) {
-#pragma unroll
-            for (int pl = 0; pl < kPlanes; ++pl) b[(s + 1) & 1][pl] = bsrc[pl * bplane + (s + 1) * bstep];
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) mfma3(ac[t], bc, acc[t], cross[t]);
-        // the layer's epilogue constants are requested four steps before the end: by then the ring has stopped asking for
-        // chunks and its registers are draining (asked for before the loop they cost spills; at their use site an L2 trip)
-        if (epi && s == (NS > 4 ? NS - 4 : 0)) epi->start(epi_consts, epi_t2, epi_half);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] += cross[t][r];
-}
-
 // layer epilogue of one output tile: back to the unscaled domain, bias, optional ReLU.
 // consts = the layer's epilogue block (behind its fragments): tile t2, half h -> [unscale 16 | bias 16] in register order.
 // The 32 constants are REQUESTED before the layer's K loop (EpiConsts::start) and only consumed here: read at their use
@@ -356,72 +233,6 @@ __device__ inline float reg_max(const f32x16& h)
     return m;
 }
 
-// Publish this wave's activation tile `t` to the workgroup, scaled by the row's factor and split: plane p unit
-// (t*2 + c)*64 + lane = registers 8c..8c+7, i.e. exactly the B-operand fragment of K-chunk (t, c) of the next layer.
-__device__ inline void publish_tile(f32x4* lds, int plane_units, int t, int lane, const f32x16& h, float sc)
-{
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        float x[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = h[8 * c + e];
-        f32x4 hi, lo;
-        split8(x, sc, hi, lo);
-        const int u = (t * 2 + c) * 64 + lane;
-        lds[u] = hi;
-        lds[plane_units + u] = lo;
-    }
-}
-
-// Narrow heads (8 / 1 outputs) also run on the matrix pipe: the head's weight rows are the A operand (outputs padded
-// to 32 rows with zeros), the B operand is this wave's own activation registers (a lane's registers 8c..8c+7 are its
-// B fragment of chunk c -- no exchange needed), 6 MFMAs per 32 input features.
-// Result: out[r], r = 0..3 = this wave's partial sum of output 4*(lane>>5) + r for row lane&31 (unscaled, no bias).
-template <int NT, int TSTRIDE>
-struct HeadW {
-    f32x4 a[NT][2][kPlanes];
-    f32x4 un;  // unscale of outputs 4h..4h+3
-    __device__ inline void start(gfloat* __restrict__ hw, int tin, int lane, int t0)
-    {
-        gf32x4* p = (gf32x4*)hw + lane;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int pl = 0; pl < kPlanes; ++pl) a[t][c][pl] = p[(((t0 + t * TSTRIDE) * 2 + c) * kPlanes + pl) * 64];
-        un = ((gf32x4*)(hw + head_consts_off(tin)))[lane >> 5];
-    }
-};
-
-template <int NT, int TSTRIDE>
-__device__ inline void head_mfma(const HeadW<NT, TSTRIDE>& w, const f32x16 (&hin)[NT], float (&out)[4])
-{
-    // the row scale over this wave's features: both k-halves of a row (lanes j and j + 32) must use the same factor
-    float m = reg_max(hin[0]);
-#pragma unroll
-    for (int t = 1; t < NT; ++t) m = fmaxf(m, reg_max(hin[t]));
-    m = fmaxf(m, __shfl_xor(m, 32));
-    float sc, un;
-    row_scale(m, sc, un);
-    f32x16 acc, cross;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; cross[r] = 0.0f; }
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            float x[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = hin[t][8 * c + e];
-            f32x4 b[kPlanes];
-            split8(x, sc, b[0], b[1]);
-            mfma3(w.a[t][c], b, acc, cross);
-        }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) out[r] = (acc[r] + cross[r]) * (w.un[r] * un);
-}
-
 struct TileIO {
     gfloat* packed;        // the brain's packed weights
     const float* obs;      // observation rows (153 floats each)
@@ -447,222 +258,10 @@ struct TileIO {
 #define RL_PMARK(i) do { } while (0)
 #endif
 
-constexpr __host__ __device__ int policy_lds_units(int kind)  // f32x4 units of lds_h one tile needs
-{
-    return (kPlanes * (kind == RL_PPO ? 8 : 4) * 2 * 64 > kXsUnits) ? kPlanes * (kind == RL_PPO ? 8 : 4) * 2 * 64 : kXsUnits;
-}
-constexpr int kAuxFloats = 32 + 32 * 8;  // lds_aux: 1 / scale of the 32 observation rows, then per row 8 partial maxima
-
-// Row scale of a hidden activation tile set: every wave leaves the maximum of its 16 registers per lane in
-// aux[32 + row * 8 + (wave * 2 + half)] BEFORE the workgroup barrier that precedes publishing; afterwards every lane reads
-// the 8 partial maxima of its row.
-__device__ inline void row_max_put(float* aux, int j, int slot, float m) { aux[32 + j * 8 + slot] = m; }
-__device__ inline float row_max_get(const float* aux, int j)
-{
-    const f32x4 a = *(const f32x4*)(aux + 32 + j * 8), b = *(const f32x4*)(aux + 32 + j * 8 + 4);
-    return fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
-}
-
-// One 32-row tile by 4 waves.  Every layer's weight ring and head fragments are requested BEFORE the wait that precedes
-// the layer (observation staging, the LDS exchange, the previous head).
-// DEEP: the variant for launches of a few tiles per CU (256 worlds): five K-chunks of weights in flight per wave (latency),
-// 3 waves per SIMD; otherwise three chunks and 4 waves per SIMD (throughput).  Measured: 18.4 vs 19.8 us at 256 worlds,
-// 217 vs 201 us at 4096.
-template <int KIND, bool DEEP, bool COHERENT = false>
-__device__ inline void policy_tile(const TileIO& io, f32x4* __restrict__ lds_h, float* __restrict__ lds_aux,
-                                   float (*__restrict__ lds_part)[32][9], int lane, int v)
-{
-    constexpr int HID_TILES = KIND == RL_PPO ? 8 : 4;
-    constexpr int PS = HID_TILES * 2 * 64;  // units per plane of the published activations
-    const int h = lane >> 5, j = lane & 31;
-    f32x4 duel_ba0 = {0.0f, 0.0f, 0.0f, 0.0f}, duel_ba1 = {0.0f, 0.0f, 0.0f, 0.0f};
-    float duel_bv = 0.0f;
-    // the action draw of tile row j depends only on the row's key: wave 0 computes it while the observation rows are in flight
-    // (inside stage_x, between the loads and their first use)
-    // (not in the 128-register dueling variant: 13 more live registers spill there)
-    constexpr bool EARLY = DEEP || KIND == RL_DQN || KIND == RL_PPO;
-    rl_u4 draw = {0u, 0u, 0u, 0u};
-    auto early_draw = [&]() {
-        if (EARLY && v == 0 && io.actions) draw = rl_philox4x32(io.seed, io.key_epoch, io.key_world, io.key_tick, RL_SITE_ACT, io.key_index);
-    };
-    const Layout L = layout_of(KIND);
-    gfloat* __restrict__ packed = io.packed;
-    const int xb = h * kXGroup + j;  // this lane's unit of chunk 0 in the observation planes
-    if (KIND == RL_DQN) {
-        f32x16 h1[1], h2[1];
-        WRing<4, 1, 1, 3> w1;
-        WRing<2, 1, 1, 3> w2;
-        HeadW<1, 1> wh;
-        float q4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        w1.start(packed + L.l1, lane, v);
-        stage_x<COHERENT>(lds_h, lds_aux, io.obs, io.row, lane, v, early_draw);
-        lds_barrier();
-        k_loop<kInChunks>(w1, lds_h + xb, kXPlane, 2 * kXGroup, h1);
-        if (v < 2) { w2.start(packed + L.l2a, lane, v); wh.start(packed + L.ha, 2, lane, v); }
-        epilogue_tile<true>(h1[0], packed + L.l1 + frag_floats(kInChunks, 4), v, h, lds_aux[j]);
-        row_max_put(lds_aux, j, v * 2 + h, reg_max(h1[0]));
-        lds_barrier();  // every wave is done with the observation tile: its LDS becomes the activation exchange
-        float sc1, un1;
-        row_scale(row_max_get(lds_aux, j), sc1, un1);
-        publish_tile(lds_h, PS, v, lane, h1[0], sc1);
-        lds_barrier();
-        if (v < 2) {  // the second hidden layer has 2 output tiles: waves 0 and 1
-            k_loop<8>(w2, lds_h + lane, PS, 64, h2);
-            epilogue_tile<true>(h2[0], packed + L.l2a + frag_floats(8, 2), v, h, un1);
-            head_mfma(wh, h2, q4);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lds_part[v][j][4 * h + r] = q4[r];
-    } else if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
-        f32x16 h1[1], h2[1];
-        float adv[4], val[4];
-        WRing<4, 1, 1, DEEP ? 5 : 3> w1, w2;
-        HeadW<1, 1> wh;
-        EpiConsts e1, e2;
-        RL_PMARK(22);
-        w1.start(packed + L.l1, lane, v);
-        if (EARLY && v == 0) {  // wave 0 finishes the tile: its head biases are asked for now, not after the last barrier
-            const gf32x4* ba = (const gf32x4*)(packed + L.ha + head_consts_off(4) + 8);
-            duel_ba0 = ba[0]; duel_ba1 = ba[1];
-            duel_bv = packed[L.hb + head_consts_off(4) + 8];
-        }
-        stage_x<COHERENT>(lds_h, lds_aux, io.obs, io.row, lane, v, early_draw);
-        RL_PMARK(23);
-        lds_barrier();
-        RL_PMARK(10);
-        k_loop<kInChunks>(w1, lds_h + xb, kXPlane, 2 * kXGroup, h1, DEEP ? &e1 : nullptr, packed + L.l1 + frag_floats(kInChunks, 4), v, h);
-        RL_PMARK(2);
-        w2.start(packed + L.l2a, lane, v);
-        wh.start(packed + L.ha, 4, lane, v);
-        // relu(feature) feeds both branches (PERD3QN.py:200-201)
-        // (the DEEP variant has the registers to ask for the epilogue constants inside the K loop; the 128-register variant
-        // reads them here)
-        if (!DEEP) e1.start(packed + L.l1 + frag_floats(kInChunks, 4), v, h);
-        epilogue_tile<true>(h1[0], e1, lds_aux[j]);
-        row_max_put(lds_aux, j, v * 2 + h, reg_max(h1[0]));
-        lds_barrier();
-        float sc1, un1;
-        row_scale(row_max_get(lds_aux, j), sc1, un1);
-        publish_tile(lds_h, PS, v, lane, h1[0], sc1);
-        lds_barrier();
-        RL_PMARK(3);
-        k_loop<8>(w2, lds_h + lane, PS, 64, h2, DEEP ? &e2 : nullptr, packed + L.l2a + frag_floats(8, 4), v, h);
-        RL_PMARK(4);
-        w1.start(packed + L.l2b, lane, v);  // the value branch's first chunks arrive while the advantage head runs
-        if (!DEEP) e2.start(packed + L.l2a + frag_floats(8, 4), v, h);
-        epilogue_tile<true>(h2[0], e2, un1);
-        head_mfma(wh, h2, adv);
-        wh.start(packed + L.hb, 4, lane, v);
-        RL_PMARK(5);
-        k_loop<8>(w1, lds_h + lane, PS, 64, h2, DEEP ? &e1 : nullptr, packed + L.l2b + frag_floats(8, 4), v, h);
-        RL_PMARK(6);
-        if (!DEEP) e1.start(packed + L.l2b + frag_floats(8, 4), v, h);
-        epilogue_tile<true>(h2[0], e1, un1);
-        head_mfma(wh, h2, val);
-        RL_PMARK(7);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lds_part[v][j][4 * h + r] = adv[r];
-        if (h == 0) lds_part[v][j][8] = val[0];
-    } else {
-        f32x16 h1[2], h2[2];
-        float q4[4];
-        WRing<8, 2, 4, 3> w1, w2;
-        HeadW<2, 4> wh;
-        w1.start(packed + L.l1, lane, v);   // tiles v and v+4
-        stage_x<COHERENT>(lds_h, lds_aux, io.obs, io.row, lane, v, early_draw);
-        lds_barrier();
-        k_loop<kInChunks>(w1, lds_h + xb, kXPlane, 2 * kXGroup, h1);
-        w2.start(packed + L.l2a, lane, v);
-        epilogue_tile<true>(h1[0], packed + L.l1 + frag_floats(kInChunks, 8), v, h, lds_aux[j]);
-        epilogue_tile<true>(h1[1], packed + L.l1 + frag_floats(kInChunks, 8), v + 4, h, lds_aux[j]);
-        row_max_put(lds_aux, j, v * 2 + h, fmaxf(reg_max(h1[0]), reg_max(h1[1])));
-        lds_barrier();
-        float sc1, un1;
-        row_scale(row_max_get(lds_aux, j), sc1, un1);
-        publish_tile(lds_h, PS, v, lane, h1[0], sc1);
-        publish_tile(lds_h, PS, v + 4, lane, h1[1], sc1);
-        lds_barrier();
-        wh.start(packed + L.ha, 8, lane, v);
-        k_loop<16>(w2, lds_h + lane, PS, 64, h2);
-        epilogue_tile<true>(h2[0], packed + L.l2a + frag_floats(16, 8), v, h, un1);
-        epilogue_tile<true>(h2[1], packed + L.l2a + frag_floats(16, 8), v + 4, h, un1);
-        head_mfma(wh, h2, q4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lds_part[v][j][4 * h + r] = q4[r];
-    }
-    lds_barrier();
-    RL_PMARK(8);
-    if (v == 0 && h == 0) {
-        float q[8];
-        float sum9[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i)
-            sum9[i] = (i < 8 || KIND == RL_D3QN || KIND == RL_PERD3QN)
-                          ? ((lds_part[0][j][i] + lds_part[1][j][i]) + lds_part[2][j][i]) + lds_part[3][j][i] : 0.0f;
-        if (KIND == RL_D3QN || KIND == RL_PERD3QN) {
-            if (!EARLY) {
-                const gf32x4* bp = (const gf32x4*)(packed + L.ha + head_consts_off(4) + 8);
-                duel_ba0 = bp[0]; duel_ba1 = bp[1];
-                duel_bv = packed[L.hb + head_consts_off(4) + 8];
-            }
-            const float ba[8] = {duel_ba0.x, duel_ba0.y, duel_ba0.z, duel_ba0.w, duel_ba1.x, duel_ba1.y, duel_ba1.z, duel_ba1.w};
-            const float bv = duel_bv;
-            float adv[8], mean = 0.0f;  // advantage.mean() of the [1,8] tensor == per-row mean when batched
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { adv[i] = sum9[i] + ba[i]; mean += adv[i]; }
-            mean *= 0.125f;
-            const float val = sum9[8] + bv;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) q[i] = adv[i] + val - mean;
-        } else {
-            gfloat* bq = packed + L.ha + head_consts_off(KIND == RL_DQN ? 2 : 8) + 8;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) q[i] = sum9[i] + bq[i];
-            if (KIND == RL_PPO) {
-                float m = q[0], sm = 0.0f;  // softmax over the 8 logits (PPO.py:105)
-#pragma unroll
-                for (int i = 1; i < 8; ++i) m = fmaxf(m, q[i]);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { q[i] = expf(q[i] - m); sm += q[i]; }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) q[i] = q[i] / sm;
-            }
-        }
-        if (io.valid) {
-            if (io.out) {
-                f32x4* o = (f32x4*)(io.out + io.row * 8);
-                o[0] = f32x4{q[0], q[1], q[2], q[3]};
-                o[1] = f32x4{q[4], q[5], q[6], q[7]};
-            }
-            if (io.actions) {
-                const rl_u4 r = EARLY ? draw : rl_philox4x32(io.seed, io.key_epoch, io.key_world, io.key_tick, RL_SITE_ACT, io.key_index);
-                const float u = (float)rl_u24(r.x);
-                int a = 0;
-                if (KIND == RL_PPO) {  // Categorical(prob).sample() as inverse CDF
-                    float cum = 0.0f; a = 7; bool found = false;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { cum += q[i]; if (!found && u < cum) { a = i; found = true; } }
-                } else if (u < io.eps) a = (int)(r.y >> 29);
-                else {
-#pragma unroll
-                    for (int i = 1; i < 8; ++i) if (q[i] > q[a]) a = i;  // first maximum
-                }
-                io.actions[io.row] = (int8_t)a;
-                if (io.lds_actions_off >= 0) {
-                    extern __shared__ __attribute__((aligned(16))) char rl_dyn_lds[];
-                    ((signed char*)rl_dyn_lds)[io.lds_actions_off + io.lds_slot] = (signed char)a;
-                }
-            }
-        }
-    }
-    RL_PMARK(9);
-    lds_barrier();  // lds_h / lds_part are reused by the next tile
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // One WAVE per 32-row tile (the dueling kinds: D3QN / PERD3QN).
 //
-// The 4-wave tile above spends ~25 instructions per MFMA: every wave stages, scales and splits rows, publishes and re-reads
+// The 4-wave tile of rounds 1-2 (removed in round 5) spent ~25 instructions per MFMA: every wave stages, scales and splits rows, publishes and re-reads
 // activations through LDS, crosses five workgroup barriers and keeps a weight ring for its quarter of the features -- 9,400
 // instructions per tile, and the launch is bound by instruction issue (SQ counters: profiles/r02a_policy_tick_sq_counters.txt).
 // Here ONE wave owns all four output tiles of every layer, so that

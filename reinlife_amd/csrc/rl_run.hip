@@ -2,11 +2,17 @@
 #include "rl_world_dev.h"
 
 // Measurement switch of the multi-tick launch (bench.py's per-half timings, tools/): 1 = skip the policy half, 2 = skip the tick half,
-// 4 / 8 / 16 = at most 2 / 1 / 3 policy tiles, 32 = no staggered start.  Results are then WRONG, so this is an explicit call of the
-// measuring process -- never an environment variable a production run could inherit -- and rl_run says so in rl_last_error().
+// 4 / 8 / 16 = at most 2 / 1 / 3 policy tiles, 32 = no staggered start.  Results are then WRONG, so it exists in the TUNING builds only
+// (-DRL_TUNING: lib/libreinlife_hip_tune.so, and the stamped _prof build): the product library neither exports the switch nor compiles
+// the branches (RL_RUN_DBG is the constant 0 there).
+#ifdef RL_TUNING
 static int g_run_debug = 0;
-extern "C" void rl_debug_set_run_mask(int mask) { g_run_debug = mask; }
-extern "C" int rl_debug_get_run_mask(void) { return g_run_debug; }
+extern "C" __attribute__((visibility("default"))) void rl_debug_set_run_mask(int mask) { g_run_debug = mask; }
+extern "C" __attribute__((visibility("default"))) int rl_debug_get_run_mask(void) { return g_run_debug; }
+#define RL_RUN_DBG(ka) (*(const int __attribute__((address_space(4)))*)&(ka)->ra.debug)
+#else
+#define RL_RUN_DBG(ka) 0
+#endif
 
 namespace {
 
@@ -346,7 +352,7 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
     // (the per-brain row lists were built by wave 0 while the other waves wrote the previous tick's Agent.state rows: policy_lists_wave0)
     int ntiles = __builtin_amdgcn_readfirstlane(ps.meta[0]);
     {   // measurement only (run mask & 4 / & 8): run at most 2 / 1 tiles (results WRONG)
-        const int dbg = *(const int __attribute__((address_space(4)))*)&ka->ra.debug;
+        const int dbg = RL_RUN_DBG(ka);
         if (dbg & 4) ntiles = min(ntiles, 2);
         if (dbg & 8) ntiles = min(ntiles, 1);
         if (dbg & 16) ntiles = min(ntiles, 3);
@@ -961,7 +967,7 @@ __global__ __launch_bounds__(T) void k_run(const RunParams rp)
     RunParamsC* ka = (RunParamsC*)__builtin_amdgcn_kernarg_segment_ptr();
     typedef const int __attribute__((address_space(4))) cint;
     const int n_ticks = *(cint*)&ka->ra.n_ticks;
-    const int dbg = *(cint*)&ka->ra.debug;
+    const int dbg = RL_RUN_DBG(ka);
     // Workgroups that start in exact lockstep stay in lockstep for tens of ticks (every world does the same work at the same moment:
     // 256 CUs ask L2 for the same weight lines, then all write their observation rows), and such ticks are ~3 us slower than those of
     // drifted-apart worlds: kernel time of a 20-tick launch 545 -> 518 us with the starts spread over 3.75 us (16 steps of 0.25 us; 0.5 / 1 us
@@ -1053,6 +1059,16 @@ int rl_world_run_supported(const rl_world* h, const rl_brain* brains, int n_brai
     if (kind < 0) return 0;
     const int T = run_block(h);
     if (h->cfg.slot_cap > T) return 0;
+#ifndef RL_RUN_1024
+    // k_run<1024> (sixteen waves per world, four-wave policy tiles: policy_quad) is bit-identical to the 512-thread kernel and 4.4 us per
+    // tick slower: it is compiled into the tuning builds only (-DRL_RUN_1024); callers fall back to the two-launch loop
+    if (T == 1024) { rl_set_error("rl_run: 1024-thread workgroups are a tuning-build instantiation (-DRL_RUN_1024), not in this library"); return 0; }
+#endif
+#ifndef RL_RUN_256
+    // k_run<256> (several worlds per CU) loses to the two-launch loop wherever it would be chosen (6.5e8 against 9.7e8 agent-steps/s at 1,024
+    // worlds): tuning builds only (-DRL_RUN_256)
+    if (T == 256) { rl_set_error("rl_run: 256-thread workgroups are a tuning-build instantiation (-DRL_RUN_256), not in this library"); return 0; }
+#endif
     if (kind == kKindAll) {
         // the mixed-kind kernel exists for 512-thread workgroups; the tiles' exchange buffers (32 KB for a PPO tile) lie in the mirror
         if (T != 512) return 0;
@@ -1093,8 +1109,10 @@ int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n
     } else { ra.eps_sched = eps_sched; ra.eps_inline_on = 0; }
     ra.capture = replays != nullptr; ra.policy_out = policy_out;
     if (replays) for (int b = 0; b < n_brains; ++b) ra.rp[b] = replays[b];
+#ifdef RL_TUNING
     ra.debug = g_run_debug;
     if (g_run_debug) rl_set_error("rl_run: measurement mask %d is set (rl_debug_set_run_mask): the results of this launch are not valid", g_run_debug);
+#endif
     const int T = run_block(h);
     const int kind = run_kind_of(brains, n_brains);
     rp.p.PS = kind == kKindAll ? host_plane_stride<kKindAll>(h, T) : host_plane_stride<RL_PERD3QN>(h, T);
@@ -1110,22 +1128,31 @@ int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n
 #endif
 #else
 #define RL_RUN_PICK3(TT, FX, KD) RL_RUN_PICK(TT, FX, KD, 0) RL_RUN_PICK(TT, FX, KD, 1) RL_RUN_PICK(TT, FX, KD, 2)
-    RL_RUN_PICK3(1024, true, RL_PERD3QN) RL_RUN_PICK3(1024, false, RL_PERD3QN) RL_RUN_PICK3(512, true, RL_PERD3QN) RL_RUN_PICK3(512, false, RL_PERD3QN)
+#ifdef RL_RUN_1024
+    RL_RUN_PICK3(1024, true, RL_PERD3QN) RL_RUN_PICK3(1024, false, RL_PERD3QN)
+#endif
+    RL_RUN_PICK3(512, true, RL_PERD3QN) RL_RUN_PICK3(512, false, RL_PERD3QN)
+#ifdef RL_RUN_256
     RL_RUN_PICK3(256, true, RL_PERD3QN) RL_RUN_PICK3(256, false, RL_PERD3QN)
+#endif
     RL_RUN_PICK3(512, true, kKindAll) RL_RUN_PICK3(512, false, kKindAll)
 #undef RL_RUN_PICK3
 #endif
 #undef RL_RUN_PICK
     if (!fn) { rl_set_error("rl_run: no kernel instantiation for T=%d fixed=%d kind=%d train=%d in this build", T, (int)fixed, kind, train); return RL_E_UNSUPPORTED; }
     if (bytes > 64 * 1024) {   // opt in to the large dynamic-LDS window: once per (kernel, device, size) -- the attribute belongs to the device's copy of the kernel
-        static const void* granted_fn[64];
-        static size_t granted_bytes[64];
+        // (a process may alternate several instantiations -- bench.py's TRAIN 0 line and trainer()'s TRAIN 1: each keeps its grant)
+        struct Grant { const void* fn; size_t bytes; };
+        static Grant granted[64][8];
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-        if (granted_fn[dev] != fn || granted_bytes[dev] < bytes) {
+        Grant* g = nullptr;
+        for (int i = 0; i < 8 && !g; ++i) if (granted[dev][i].fn == fn || granted[dev][i].fn == nullptr) g = &granted[dev][i];
+        if (!g) { g = &granted[dev][0]; g->fn = nullptr; g->bytes = 0; }   // (more than eight instantiations in one process: reuse a slot)
+        if (g->fn != fn || g->bytes < bytes) {
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             if (e != hipSuccess) { rl_set_error("hipFuncSetAttribute(%zu bytes of LDS) failed: %s", bytes, hipGetErrorString(e)); return RL_E_LAUNCH; }
-            granted_fn[dev] = fn; granted_bytes[dev] = bytes;
+            g->fn = fn; g->bytes = bytes;
         }
     }
     void* kargs[] = {(void*)&rp};

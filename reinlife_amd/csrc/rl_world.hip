@@ -3,8 +3,10 @@
 // multi-tick kernel (k_run) in rl_run.hip.
 #include "rl_world_dev.h"
 
-int g_rl_ablate = 0;  // tuning only
-extern "C" void rl_debug_set_ablate(int mask) { g_rl_ablate = mask; }
+#ifdef RL_PHASE_PROFILE   /* the stamped tuning build only: sections of the tick can be skipped (results WRONG) */
+int g_rl_ablate = 0;
+extern "C" __attribute__((visibility("default"))) void rl_debug_set_ablate(int mask) { g_rl_ablate = mask; }
+#endif
 
 namespace {
 

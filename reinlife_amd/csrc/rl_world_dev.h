@@ -48,7 +48,9 @@ __device__ inline int rl_lane_fresh()
 
 int rl_world_prepare_bytes(size_t bytes);
 size_t rl_world_smem_bytes(int cpad, int cap, int hash, int plane_stride, int height);
+#ifdef RL_PHASE_PROFILE
 extern int g_rl_ablate;   // tuning only (rl_debug_set_ablate, rl_world.hip)
+#endif
 
 namespace {
 
@@ -1779,7 +1781,9 @@ inline KParams make_params(const rl_world* h)
     p.refill_threshold = -1;
     p.prof = h->prof; p.prof_world = h->prof_world;
     p.lists = nullptr; p.lists_counts = nullptr; p.lists_counts_zero = nullptr; p.list_stride = 0;
+#ifdef RL_PHASE_PROFILE
     p.ablate = g_rl_ablate;
+#endif
     return p;
 }
 

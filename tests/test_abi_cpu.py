@@ -23,7 +23,26 @@ def test_library_exports_every_declared_symbol():
     assert declared == {n for n, _, _ in _lib.ABI}, "ctypes ABI table out of sync with the header"
 
 
-def test_create_validates_like_the_reference():
+def test_the_library_exports_the_header_and_nothing_else():
+    """The product library is built with -fvisibility=hidden + a version script: its dynamic symbol table is EXACTLY the functions
+    include/reinlife_hip.h declares -- no measurement switch (rl_debug_*: tuning builds only), no C++ internals."""
+    import subprocess
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "reinlife_hip.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(rl_[a-z_0-9]+)\s*\(", hdr))
+    _lib.lib()
+    from reinlife_amd import build
+    nm = "/opt/rocm/lib/llvm/bin/llvm-nm" if os.path.exists("/opt/rocm/lib/llvm/bin/llvm-nm") else "nm"
+    out = subprocess.run([nm, "-D", "--defined-only", build.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
+    src = "".join(open(os.path.join(ROOT, "reinlife_amd", "csrc", f)).read() for f in ("rl_run.hip", "rl_world.hip"))
+    # the switches exist under RL_TUNING / RL_PHASE_PROFILE only
+    assert "#ifdef RL_TUNING\nstatic int g_run_debug" in src and "#ifdef RL_PHASE_PROFILE   /* the stamped tuning build only" in src
+
+
+def test_create_validates_its_configuration_and_states_its_own_limits():
+    """width / height >= 3 is the reference's rule (Grid asserts it, grid.py:23-24).  The upper bounds are THIS build's: a world lives in
+    one workgroup's LDS (width * height <= 4096 cells, a side <= 255), where the reference's Grid is unbounded -- rl_last_error() says so."""
     lib = _lib.lib()
     h = C.c_void_p()
     ok = _lib.Config(30, 30, 100, 2, 256, 1, 1, 0, 1, 0, 0)
@@ -39,6 +58,8 @@ def test_create_validates_like_the_reference():
             setattr(cfg, k, v)
         assert lib.rl_create(C.byref(cfg), C.byref(h)) < 0, bad     # Grid asserts width/height >= 3 (grid.py:23-24)
         assert lib.rl_last_error()
+        if bad == dict(width=100, height=100):
+            assert b"LIMIT of this build" in lib.rl_last_error() and b"unbounded" in lib.rl_last_error()
 
 
 def test_create_accepts_the_world_shapes_the_lds_budget_allows():
@@ -183,24 +204,24 @@ def test_options_are_process_level_snapshotted_by_handles_and_never_read_from_th
     get = lambda h, n: lib.rl_get_option(h, n.encode())  # noqa: E731
     try:
         assert get(None, "policy_variant") == 0 and get(None, "world_block") == 0      # auto: ONE arithmetic, block by world count
-        _lib.set_option("policy_variant", "nsplit"); _lib.set_option("world_block", 512)
+        _lib.set_option("policy_variant", "wave"); _lib.set_option("world_block", 512)
         monkeypatch.setenv("RL_WORLD_BLOCK", "256")                                     # later changes of the environment: not seen ...
         cfg = _lib.Config(30, 30, 100, 2, 256, 4, 1, 0, 1, 0, 7)
         h = C.c_void_p()
         assert lib.rl_create(C.byref(cfg), C.byref(h)) == 0
-        assert (get(h, "policy_variant"), get(h, "world_block"), get(h, "world_generic"), get(h, "run_always")) == (1, 512, 0, 0)
+        assert (get(h, "policy_variant"), get(h, "world_block"), get(h, "world_generic"), get(h, "run_always")) == (2, 512, 0, 0)
         _lib.set_option("policy_variant", "pair"); _lib.set_option("world_block", 1024); _lib.set_option("run_always", 1)
-        assert (get(h, "policy_variant"), get(h, "world_block"), get(h, "run_always")) == (1, 512, 0)   # the handle keeps its snapshot
+        assert (get(h, "policy_variant"), get(h, "world_block"), get(h, "run_always")) == (2, 512, 0)   # the handle keeps its snapshot
         assert (get(None, "policy_variant"), get(None, "world_block"), get(None, "run_always")) == (4, 1024, 1)
         lib.rl_destroy(h)
         _lib.set_option("world_block", None)                                            # ... until somebody asks for the environment's value
         assert get(None, "world_block") == 256
-        for name, value in (("policy_variant", "fast"), ("world_block", "300"), ("no_such_option", "1")):
+        for name, value in (("policy_variant", "fast"), ("policy_variant", "nsplit"), ("world_block", "300"), ("policy_per_kind", "1"), ("no_such_option", "1")):   # ("nsplit" / policy_per_kind: the 4-wave tile of rounds 1-2 is gone)
             assert lib.rl_set_option(name.encode(), value.encode()) != 0 and lib.rl_last_error()
         assert get(None, "no_such_option") == -1
     finally:
         monkeypatch.delenv("RL_WORLD_BLOCK", raising=False)
-        for name in ("policy_variant", "world_block", "world_generic", "policy_per_kind", "run_always"):
+        for name in ("policy_variant", "world_block", "world_generic", "run_always"):
             _lib.set_option(name, None)
     assert get(None, "policy_variant") == 0 and get(None, "world_block") == 0
     src = os.path.join(ROOT, "reinlife_amd", "csrc")

@@ -389,6 +389,16 @@ def _run_pair(R, static, seed, block=None):
     return out, wts, names, eps, cfg
 
 
+def _need_run(dw, block=None):
+    """The multi-tick launch must cover this handle -- except at a FORCED workgroup size of 256 / 1024 threads: k_run<256> and k_run<1024>
+    are slower than what the product runs in their place and live in the tuning build only (RL_TUNE=1 python reinlife_amd/build.py;
+    REINLIFE_HIP_LIB=reinlife_amd/lib/libreinlife_hip_tune.so runs these cases), DESIGN.md 5.10."""
+    if dw.run_supported():
+        return
+    assert block in (256, 1024), "rl_run should cover this configuration"
+    pytest.skip("k_run<%d> is a tuning-build instantiation (not in the product library)" % block)
+
+
 def _same_device_state(a, b, tag):
     n = a.s["n_agents"].cpu().numpy()
     assert np.array_equal(n, b.s["n_agents"].cpu().numpy()), tag
@@ -413,7 +423,7 @@ def test_multi_tick_launch_equals_the_two_launch_loop(static, block, hip_option)
     # then the two paths must agree bit for bit (with its default 4-wave tile they agree to ~1e-7 in Q, like any two float32
     # summation orders)
     (fused, loop), *_ = _run_pair(20, static, 555)
-    assert fused.run_supported()
+    _need_run(fused, block)
     done = 0
     for chunk in (1, 2, 7, 30, 1, 30, 30):
         fused.run(chunk, 70, 100)
@@ -505,7 +515,7 @@ def test_multi_tick_launch_other_shapes_and_the_sequential_update(width, height,
         pair.append(dw)
     fused, loop = pair
     if not fused.run_supported():
-        pytest.skip("slot_cap above this workgroup size")
+        pytest.skip("slot_cap above this workgroup size" if not block or fused.cap > block else "k_run<%d> is a tuning-build instantiation" % block)
     ow = orc.OracleWorlds(n_worlds=R, seed=99, **cfg)
     ow.reset_synthetic(n_new)
     for t in range(45):
@@ -609,7 +619,7 @@ def test_multi_tick_launch_brain_counts_and_crowded_worlds(n_brains, max_agents,
         dw.reset_synthetic(n_new)
         pair.append(dw)
     fused, loop = pair
-    assert fused.run_supported()
+    _need_run(fused)
     most = 0
     for chunk in (1, 6, 25, 40):
         fused.run(chunk, thr, n_new)

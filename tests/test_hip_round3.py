@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-from test_hip_round2 import _cmp_rows, _cmp_state, _run_pair, _same_device_state, _weights  # noqa: E402
+from test_hip_round2 import _cmp_rows, _cmp_state, _need_run, _run_pair, _same_device_state, _weights  # noqa: E402
 
 
 def _same_tracker(a, b, tag):
@@ -34,7 +34,7 @@ def test_training_launch_equals_the_two_launch_loop(static, block, hip_option):
     (fused, loop), *_ = _run_pair(14, static, 4242)
     for dw in (fused, loop):
         dw.enable_tracking(True)
-    assert fused.run_supported()
+    _need_run(fused, block)
     rng = np.random.RandomState(7)
     done = 0
     for chunk in (1, 3, 20, 37, 1, 20):
@@ -474,7 +474,7 @@ def test_capture_inside_the_multi_tick_launch(names, eps, static, block, hip_opt
     (fused, loop), wts, cfg = _kind_pair(names, eps, 9, static, 31)
     for dw in (fused, loop):
         dw.enable_capture(capacity=40_000, with_prob=True)
-    assert fused.run_supported()
+    _need_run(fused, block)
     seen = [0] * len(names)
     for chunk in (1, 1, 3, 12):
         fused.run(chunk, 70, 100)

@@ -20,13 +20,14 @@ from test_hip_round3 import _same_tracker  # noqa: E402
 SEED, TICKS = 20260928, 200
 
 
-def _worlds(workload, tracking=False):
+def _worlds(workload, tracking=False, block=None):
     sys.path.insert(0, ROOT)
     import bench
+    from test_hip_round2 import _need_run
     dw = bench.make_worlds(argparse.Namespace(worlds=256, workload=workload, seed=SEED), 0, "cuda:0")
     if tracking:
         dw.enable_tracking(True)
-    assert dw.run_supported()
+    _need_run(dw, block)
     return dw, bench.WORKLOADS[workload]
 
 
@@ -151,7 +152,7 @@ def test_sixteen_wave_workgroups_equal_eight_wave_workgroups_at_the_benched_size
     for train in (False, True):
         a, wl = _worlds("c4", tracking=train)
         hip_option("world_block", 1024)
-        b, _ = _worlds("c4", tracking=train)
+        b, _ = _worlds("c4", tracking=train, block=1024)
         hip_option("world_block", None)
         kw = dict(eps_schedule=_schedule(2, 0, 120), trk_skip=1) if train else {}
         a.run(120, 70, 100, **kw); b.run(120, 70, 100, **kw)
@@ -182,7 +183,8 @@ def test_sixteen_wave_workgroups_with_more_than_four_tiles(hip_option):
         dw.reset_synthetic(120)
         pair.append(dw)
     fused, loop = pair
-    assert fused.run_supported()
+    from test_hip_round2 import _need_run
+    _need_run(fused, 1024)
     for t in range(40):
         fused.run(1, 90, 120)
         loop.act(); loop.tick_refill(90, 120)

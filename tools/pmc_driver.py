@@ -1,6 +1,7 @@
 """Workload run under rocprofv3 --pmc: a calibration copy of known size, then a few bench steps."""
 import argparse
 import os
+os.environ.setdefault("RL_TUNE", "1")   # the tuning library (libreinlife_hip_tune.so) carries rl_debug_set_run_mask; the product does not
 import sys
 
 import torch

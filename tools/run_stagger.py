@@ -1,6 +1,7 @@
 """Kernel time (HIP events) of rl_run launches of 1 .. 500 ticks with and without the staggered workgroup starts (rl_debug_set_run_mask & 32 switches
 them off; tuning; GPU)."""
 import os, sys, time
+os.environ.setdefault("RL_TUNE", "1")   # the tuning library (libreinlife_hip_tune.so) carries rl_debug_set_run_mask; the product does not
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 args = __import__("argparse").Namespace(worlds=256, workload="c4", seed=1)

@@ -1,5 +1,6 @@
 """rl_run per-tick time with the policy limited to 1 / 2 / 3 tiles per world (rl_debug_set_run_mask bits 8 / 4 / 16; tuning only; GPU)."""
 import os, sys, time
+os.environ.setdefault("RL_TUNE", "1")   # the tuning library (libreinlife_hip_tune.so) carries rl_debug_set_run_mask; the product does not
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench

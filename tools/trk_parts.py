@@ -1,5 +1,6 @@
 """Which part of the Tracker pass costs what in the TRAIN launch (tuning build with measurement masks; results of masked launches are wrong)."""
 import os, sys, time
+os.environ.setdefault("RL_TUNE", "1")   # the tuning library (libreinlife_hip_tune.so) carries rl_debug_set_run_mask; the product does not
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench
 from reinlife_amd import _lib
