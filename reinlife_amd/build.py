@@ -16,6 +16,9 @@ TAG = "_prof" if PROFILE else "_tune" if TUNE else ("_" + os.environ["RL_LIB_TAG
 TUNE_LIB_PATH = os.path.join(LIB_DIR, "libreinlife_hip_tune.so")
 LIB_PATH = os.path.join(LIB_DIR, "libreinlife_hip%s.so" % TAG)
 SOURCES = ["rl_world.hip", "rl_run.hip", "rl_policy.hip", "rl_capi.hip"]
+# (object suffix, extra flags) per source: rl_run.hip is compiled as TWO units side by side (RL_RUN_UNIT, see the file) -- one compiler for all
+# of k_run's instantiations is what a forced build waits for
+UNITS = {"rl_run.hip": [("", ["-DRL_RUN_UNIT=0"]), ("_all", ["-DRL_RUN_UNIT=1"])]}
 HEADERS = ["rl_common.h", "rl_policy_dev.h", "rl_world_dev.h", os.path.join("..", "..", "include", "reinlife_hip.h")]
 # -ffp-contract=off: the world kernels' float64 reward / fitness arithmetic must round exactly like the CPU path
 # -fvisibility=hidden: the export list is include/reinlife_hip.h (its declarations sit inside a visibility push(default))
@@ -61,24 +64,38 @@ def _write_stamp(target, digest):
         fh.write(digest + "\n")
 
 
+def variant_flags():
+    """The compile flags of the variant this process builds / loads (product, RL_TUNE, RL_PHASE_PROFILE)."""
+    return FLAGS + (["-DRL_PHASE_PROFILE", "-DRL_TUNING", "-DRL_RUN_1024", "-DRL_RUN_256"] if PROFILE else ["-DRL_TUNING", "-DRL_RUN_1024", "-DRL_RUN_256"] if TUNE else [])
+
+
+def library_is_current():
+    """True when LIB_PATH exists and was built from the current sources with the current flags (the stamps build() writes)."""
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    flags = variant_flags()
+    digests = [_digest([os.path.join(CSRC, src)] + hdrs, " ".join(flags + extra)) for src in SOURCES for _, extra in UNITS.get(src, [("", [])])]
+    return _stamp_ok(LIB_PATH, _digest([], " ".join(digests)))
+
+
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(LIB_DIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
-    flags = FLAGS + (["-DRL_PHASE_PROFILE", "-DRL_TUNING", "-DRL_RUN_1024", "-DRL_RUN_256"] if PROFILE else ["-DRL_TUNING", "-DRL_RUN_1024", "-DRL_RUN_256"] if TUNE else [])
+    flags = variant_flags()
     objs, digests, jobs = [], [], []
-    for src in SOURCES:   # the translation units compile side by side (rl_world.hip alone takes over a minute)
+    for src in SOURCES:   # the translation units compile side by side (rl_world.hip alone takes over half a minute)
         sp = os.path.join(CSRC, src)
-        obj = os.path.join(LIB_DIR, src.replace(".hip", TAG + ".o"))
-        want = _digest([sp] + hdrs, " ".join(flags))   # (every unit includes every header)
-        objs.append(obj); digests.append(want)
-        if force or not _stamp_ok(obj, want):
-            cmd = [hipcc] + flags + ["-c", sp, "-o", obj]
-            if verbose:
-                print(" ".join(cmd))
-            if os.path.exists(obj + ".srchash"):
-                os.remove(obj + ".srchash")
-            jobs.append((cmd, subprocess.Popen(cmd), obj, want))
+        for suffix, extra in UNITS.get(src, [("", [])]):
+            obj = os.path.join(LIB_DIR, src.replace(".hip", suffix + TAG + ".o"))
+            want = _digest([sp] + hdrs, " ".join(flags + extra))   # (every unit includes every header)
+            objs.append(obj); digests.append(want)
+            if force or not _stamp_ok(obj, want):
+                cmd = [hipcc] + flags + extra + ["-c", sp, "-o", obj]
+                if verbose:
+                    print(" ".join(cmd))
+                if os.path.exists(obj + ".srchash"):
+                    os.remove(obj + ".srchash")
+                jobs.append((cmd, subprocess.Popen(cmd), obj, want))
     failed = None
     for cmd, job, obj, want in jobs:   # wait for EVERY compiler before reporting the first failure (no orphaned hipcc behind an exception)
         if job.wait() != 0:

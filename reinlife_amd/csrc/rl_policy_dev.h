@@ -589,6 +589,70 @@ __device__ inline void split_slice(int k, Raw&& raw, float sc, f32x4& hi, f32x4&
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// What an observation row IS (environment.py:362-370, 392-456), used by the input layer when the rows are known to be the world
+// kernels' own (template argument XM of policy_tile1s / policy_pair2, chosen per tile by k_run from the state it holds -- run_obs_flags,
+// rl_run.hip; the stand-alone launches take XM = 0, the general code):
+//   * the three 7x7 planes hold only -1, 0, 1/2, 1 -- except the health plane when cell (0,0) holds an agent (np.vectorize then infers
+//     float64 and the plane carries health / 200, environment.py:392-402; otherwise it is truncated to int64: -1, 0, 1);
+//   * features 147..152 are health / 200 (|.| < 2 while |health| < 400), 0/1, same / n <= 1, n / max_agents, 0/1 and ate_super_food = +-1.
+// Hence  RL_XF_SCALE: |health| < 400 for every agent and n < 2 max_agents  =>  every row's largest magnitude lies in [1, 2): the row
+//                     scale is 2^kScaleExp without looking at the row (no row-maximum pass);
+//        the `lo` half of the split of a K-chunk that only holds plane values is EXACTLY zero (a multiple of 1/2 times 2^10 is an f16):
+//        chunks 0-2 (features 0..47) and 7-8 (112..143) whenever RL_XF_SCALE holds, chunks 3-6 (48..111: the health plane) also when
+//        RL_XF_INT_HEALTH holds.  Their W_hi . x_lo products are exact zeros: the MFMAs are not issued and the halves not computed --
+//        the accumulators receive the same values in the same order, so the results are BIT-IDENTICAL to the general path (tests: every
+//        comparison of k_run with the stand-alone kernels, which take the general path).
+// XM is a COMPILE-TIME property of a tile instantiation (0 nothing known, 1 RL_XF_SCALE, 2 + RL_XF_INT_HEALTH) and the caller branches
+// between whole tiles: the same decisions as wave-uniform branches INSIDE one copy of the layer made the register allocator spill (65 -
+// 289 VGPRs: a conditional MFMA leaves two live versions of its sixteen-register accumulator) and the kernel 1.5 - 4 us slower.
+// ---------------------------------------------------------------------------------------------------------------
+enum { RL_XF_SCALE = 1, RL_XF_INT_HEALTH = 2 };
+template <int V> struct IntC { static constexpr int value = V; };
+// 0: the chunk's lo half may be anything (chunk 9: the six scalar features); 1: zero under RL_XF_SCALE; 2: zero under RL_XF_SCALE + RL_XF_INT_HEALTH
+__host__ __device__ constexpr int in_chunk_class(int c) { return (c <= 2 || c == 7 || c == 8) ? 1 : (c >= 3 && c <= 6) ? 2 : 0; }
+// One pass of the INPUT layer for output tiles 2 * HALF, + 1 of the ring, steps S .. 9: per chunk the two hi.lo MFMAs (not issued when the chunk's lo
+// half is known to be zero: XM >= the chunk's class), then hi.hi, hi.hi, lo.hi, lo.hi with shadow(step, k, slot) behind the
+// k-th of those four (slot = 4 * step + k).  The accumulation order per accumulator is k_pass's.
+template <int HALF, int XM, int S, typename Ring, typename Shadow>
+__device__ __forceinline__ void k_pass_inx_steps(Ring& w, const f32x4 (&B)[kInChunks][kPlanes], f32x16& a0, f32x16& a1, Shadow& shadow)
+{
+    constexpr int cls = in_chunk_class(S);
+    f32x4 ac[2][kPlanes];
+    w.take(HALF * kInChunks + S, ac);
+    if constexpr (!(cls != 0 && XM >= cls)) {
+        a0 = mfma16(ac[0][0], B[S][1], a0); __builtin_amdgcn_sched_barrier(0);   // hi.lo
+        a1 = mfma16(ac[1][0], B[S][1], a1); __builtin_amdgcn_sched_barrier(0);
+    }
+    a0 = mfma16(ac[0][0], B[S][0], a0); shadow(IntC<S>{}, IntC<0>{}, IntC<4 * S + 0>{}); __builtin_amdgcn_sched_barrier(0);   // hi.hi
+    a1 = mfma16(ac[1][0], B[S][0], a1); shadow(IntC<S>{}, IntC<1>{}, IntC<4 * S + 1>{}); __builtin_amdgcn_sched_barrier(0);
+    a0 = mfma16(ac[0][1], B[S][0], a0); shadow(IntC<S>{}, IntC<2>{}, IntC<4 * S + 2>{}); __builtin_amdgcn_sched_barrier(0);   // lo.hi
+    a1 = mfma16(ac[1][1], B[S][0], a1); shadow(IntC<S>{}, IntC<3>{}, IntC<4 * S + 3>{}); __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S + 1 < kInChunks) k_pass_inx_steps<HALF, XM, S + 1>(w, B, a0, a1, shadow);
+}
+template <int HALF, int XM, typename Ring, typename Shadow>
+__device__ __forceinline__ void k_pass_inx(Ring& w, const f32x4 (&B)[kInChunks][kPlanes], f32x16& a0, f32x16& a1, Shadow&& shadow)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; }
+    k_pass_inx_steps<HALF, XM, 0>(w, B, a0, a1, shadow);
+}
+// The split of input chunk C behind the four always-present MFMAs of the step before it: slot k does hi pair k; the lo pairs (0, 1 behind
+// slot 1; 2, 3 behind slot 3) only when the chunk's lo half is not known to be zero.  The instructions are split8's.
+template <int XM, int C, int K, typename Raw>
+__device__ __forceinline__ void in_split_slot(Raw&& raw, float sc, f32x4& hi, f32x4& lo)
+{
+    constexpr int cls = in_chunk_class(C);
+    { float v; split_hi(raw(2 * K), raw(2 * K + 1), sc, v); hi[K] = v; }
+    if constexpr (K == 1 || K == 3) {
+        if constexpr (!(cls != 0 && XM >= cls)) {
+            float v;
+            split_lo(raw(2 * K - 2), raw(2 * K - 1), sc, hi[K - 1], v); lo[K - 1] = v;
+            split_lo(raw(2 * K), raw(2 * K + 1), sc, hi[K], v); lo[K] = v;
+        }
+    }
+}
+
 // One pass of a layer: K loop over NS chunks for output tiles 2 * HALF, +1.  shadow(slot), slot = 0 .. 6 * NS - 1, follows MFMA `slot`.
 template <int NS, int HALF, typename Ring, typename Shadow>   // Ring: take(step, fragments) -- WRingH (registers) or WStageH (LDS stages)
 __device__ inline void k_pass(Ring& w, const f32x4 (&B)[NS][kPlanes], f32x16& a0, f32x16& a1, Shadow&& shadow)
@@ -681,7 +745,7 @@ struct Tile1Part {
     float head[4];
     rl_u4 draw;
 };
-template <int KIND, bool COHERENT, bool PAIR = false>
+template <int KIND, bool COHERENT, bool PAIR = false, int XM = 0>   // XM: what is known about the rows (in_chunk_class): 0 nothing, 1 RL_XF_SCALE, 2 + RL_XF_INT_HEALTH
 __device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, const PairLds* pair_lds = nullptr, Tile1Part* part = nullptr)
 {
     static_assert(KIND == RL_D3QN || KIND == RL_PERD3QN, "one-wave tile: dueling kinds");
@@ -724,32 +788,47 @@ __device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, c
     rl_u4 draw = {0u, 0u, 0u, 0u};
     if ((!PAIR || role == 0) && io.actions && io.eps > 0.0f) draw = rl_philox4x32(io.seed, io.key_epoch, io.key_world, io.key_tick, RL_SITE_ACT, io.key_index);
     if (h == 1) { X[kInChunks - 1][0] = f32x4{X[kInChunks - 1][0].w, 0.0f, 0.0f, 0.0f}; X[kInChunks - 1][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-    // the row's largest magnitude: four independent chains of max3(m, |a|, |b|) -- 40 instructions (the compiler's tree over fabsf / fmaxf
-    // is 92, and ONE chain of 40 is slower than that tree: a dependent VALU instruction costs a lone wave more than its issue slot)
-    float m4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int c = 0; c < kInChunks; ++c)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            max3_abs(m4[(2 * c + q) & 3], X[c][q].x, X[c][q].y);
-            max3_abs(m4[(2 * c + q + 2) & 3], X[c][q].z, X[c][q].w);
-        }
-    float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-    m = fmaxf(m, __shfl_xor(m, 32));
+    // the row's scale: known without looking when the rows are the world kernels' own (RL_XF_SCALE, see in_chunk_class) -- else from the row's
+    // largest magnitude: four independent chains of max3(m, |a|, |b|), 40 instructions (the compiler's tree over fabsf / fmaxf is 92, and
+    // ONE chain of 40 is slower than that tree: a dependent VALU instruction costs a lone wave more than its issue slot)
     float sc0, un0;
-    row_scale(m, sc0, un0);
+    if constexpr (XM >= 1) row_scale(1.0f, sc0, un0);
+    else {
+        float m4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < kInChunks; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                max3_abs(m4[(2 * c + q) & 3], X[c][q].x, X[c][q].y);
+                max3_abs(m4[(2 * c + q + 2) & 3], X[c][q].z, X[c][q].w);
+            }
+        float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        row_scale(m, sc0, un0);
+    }
     f32x4 B1[kInChunks][kPlanes];
     auto xraw = [&](int c, int e) { return X[c][e >> 2][e & 3]; };
-#pragma unroll
-    for (int k = 0; k < 6; ++k) split_slice<6>(k, [&](int e) { return xraw(0, e); }, sc0, B1[0][0], B1[0][1]);
-    RL_PMARK1(2);
     // ---- input layer
     f32x16 F[4];
     EpiStream ep;
-    k_pass<kInChunks, 0>(w1, B1, F[0], F[1], [&](int slot) {
-        const int c = slot / 6 + 1;
-        if (c < kInChunks) split_slice<6>(slot % 6, [&](int e) { return xraw(c, e); }, sc0, B1[c][0], B1[c][1]);
-    });
+    if constexpr (XM >= 1) {
+        auto x0 = [&](int e) { return xraw(0, e); };
+        in_split_slot<XM, 0, 0>(x0, sc0, B1[0][0], B1[0][1]); in_split_slot<XM, 0, 1>(x0, sc0, B1[0][0], B1[0][1]);
+        in_split_slot<XM, 0, 2>(x0, sc0, B1[0][0], B1[0][1]); in_split_slot<XM, 0, 3>(x0, sc0, B1[0][0], B1[0][1]);
+        RL_PMARK1(2);
+        k_pass_inx<0, XM>(w1, B1, F[0], F[1], [&](auto st, auto k, auto) {
+            constexpr int c = decltype(st)::value + 1;
+            if constexpr (c < kInChunks) in_split_slot<XM, c, decltype(k)::value>([&](int e) { return xraw(c, e); }, sc0, B1[c][0], B1[c][1]);
+        });
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) split_slice<6>(k, [&](int e) { return xraw(0, e); }, sc0, B1[0][0], B1[0][1]);
+        RL_PMARK1(2);
+        k_pass<kInChunks, 0>(w1, B1, F[0], F[1], [&](int slot) {
+            const int c = slot / 6 + 1;
+            if (c < kInChunks) split_slice<6>(slot % 6, [&](int e) { return xraw(c, e); }, sc0, B1[c][0], B1[c][1]);
+        });
+    }
     float mrow = 0.0f;
     const int64_t l2 = (PAIR && role) ? L.l2b : L.l2a, hd = (PAIR && role) ? L.hb : L.ha;
     WRingH<8, D> w2;
@@ -782,6 +861,13 @@ __device__ inline void policy_tile1s(const TileIO& io, int lane, int role = 0, c
             for (int pl = 0; pl < kPlanes; ++pl) B2[c][pl] = pair_lds->ex[(c * kPlanes + pl) * 64 + lane];
     } else {
         ep.c = consts;
+        if constexpr (XM >= 1)
+            k_pass_inx<1, XM>(w1, B1, F[2], F[3], [&](auto, auto, auto sl) {
+                constexpr int slot = decltype(sl)::value;
+                if constexpr (slot == 0) ep.fetch(0, 0);
+                if constexpr (slot >= 2 && slot < 34) ep.step(0, slot - 2, F[0], F[1], un0, mrow);
+            });
+        else
         k_pass<kInChunks, 1>(w1, B1, F[2], F[3], [&](int slot) {
             if (slot == 0) ep.fetch(0, 0);
             if (slot >= 2 && slot < 34) ep.step(0, slot - 2, F[0], F[1], un0, mrow);
@@ -1267,7 +1353,7 @@ __device__ inline void k_pass_lds16(Ring& w, const f32x4* __restrict__ ex, int l
     }
 }
 
-template <int KIND, bool COHERENT>
+template <int KIND, bool COHERENT, int XM = 0>   // XM: see policy_tile1s
 __device__ inline void policy_pair2(const TileIO& io, int lane, int role, const PairLds* pair_lds, Tile1Part* part)
 {
     static_assert(KIND == RL_DQN || KIND == RL_PPO, "the plain kinds (the dueling pair is policy_tile1s<PAIR>)");
@@ -1315,30 +1401,45 @@ __device__ inline void policy_pair2(const TileIO& io, int lane, int role, const 
     if (role == 0 && io.actions && (KIND == RL_PPO || io.eps > 0.0f))
         draw = rl_philox4x32(io.seed, io.key_epoch, io.key_world, io.key_tick, RL_SITE_ACT, io.key_index);
     if (h == 1) { X[kInChunks - 1][0] = f32x4{X[kInChunks - 1][0].w, 0.0f, 0.0f, 0.0f}; X[kInChunks - 1][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-    float m4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int c = 0; c < kInChunks; ++c)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            max3_abs(m4[(2 * c + q) & 3], X[c][q].x, X[c][q].y);
-            max3_abs(m4[(2 * c + q + 2) & 3], X[c][q].z, X[c][q].w);
-        }
-    float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-    m = fmaxf(m, __shfl_xor(m, 32));
+    // the row's scale and the chunks whose lo half is exactly zero: see in_chunk_class (the dueling pair: policy_tile1s)
     float sc0, un0;
-    row_scale(m, sc0, un0);
+    if constexpr (XM >= 1) row_scale(1.0f, sc0, un0);
+    else {
+        float m4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < kInChunks; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                max3_abs(m4[(2 * c + q) & 3], X[c][q].x, X[c][q].y);
+                max3_abs(m4[(2 * c + q + 2) & 3], X[c][q].z, X[c][q].w);
+            }
+        float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        row_scale(m, sc0, un0);
+    }
     f32x4 B1[kInChunks][kPlanes];
     auto xraw = [&](int c, int e) { return X[c][e >> 2][e & 3]; };
-#pragma unroll
-    for (int k = 0; k < 6; ++k) split_slice<6>(k, [&](int e) { return xraw(0, e); }, sc0, B1[0][0], B1[0][1]);
     f32x16 F[OWN1];
     EpiStream ep;
     float mrow = 0.0f;
-    RL_PMARK1(2);
-    k_pass<kInChunks, 0>(w1, B1, F[0], F[1], [&](int slot) {
-        const int c = slot / 6 + 1;
-        if (c < kInChunks) split_slice<6>(slot % 6, [&](int e) { return xraw(c, e); }, sc0, B1[c][0], B1[c][1]);
-    });
+    if constexpr (XM >= 1) {
+        auto x0 = [&](int e) { return xraw(0, e); };
+        in_split_slot<XM, 0, 0>(x0, sc0, B1[0][0], B1[0][1]); in_split_slot<XM, 0, 1>(x0, sc0, B1[0][0], B1[0][1]);
+        in_split_slot<XM, 0, 2>(x0, sc0, B1[0][0], B1[0][1]); in_split_slot<XM, 0, 3>(x0, sc0, B1[0][0], B1[0][1]);
+        RL_PMARK1(2);
+        k_pass_inx<0, XM>(w1, B1, F[0], F[1], [&](auto st, auto k, auto) {
+            constexpr int c = decltype(st)::value + 1;
+            if constexpr (c < kInChunks) in_split_slot<XM, c, decltype(k)::value>([&](int e) { return xraw(c, e); }, sc0, B1[c][0], B1[c][1]);
+        });
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) split_slice<6>(k, [&](int e) { return xraw(0, e); }, sc0, B1[0][0], B1[0][1]);
+        RL_PMARK1(2);
+        k_pass<kInChunks, 0>(w1, B1, F[0], F[1], [&](int slot) {
+            const int c = slot / 6 + 1;
+            if (c < kInChunks) split_slice<6>(slot % 6, [&](int e) { return xraw(c, e); }, sc0, B1[c][0], B1[c][1]);
+        });
+    }
     RL_PMARK1(3);
     ep.c = c1 + role * OWN1 * 64;
     // (the hidden layer's first weight chunks are requested before the exposed part of the epilogue and the two exchanges, not after them)
@@ -1346,6 +1447,13 @@ __device__ inline void policy_pair2(const TileIO& io, int lane, int role, const 
     WRing<2, 1, 1, D> w2d;         // DQN: hidden layer, output tile `role`
     WRing<1, 1, 1, 2> whd;         // DQN: the head's two K-chunks of that tile
     if (KIND == RL_PPO) {
+        if constexpr (XM >= 1)
+            k_pass_inx<1, XM>(w1, B1, F[OWN1 - 2], F[OWN1 - 1], [&](auto, auto, auto sl) {
+                constexpr int slot = decltype(sl)::value;
+                if constexpr (slot == 0) ep.fetch(0, 0);
+                if constexpr (slot >= 2 && slot < 34) ep.step(0, slot - 2, F[0], F[1], un0, mrow);
+            });
+        else
         k_pass<kInChunks, 1>(w1, B1, F[OWN1 - 2], F[OWN1 - 1], [&](int slot) {
             if (slot == 0) ep.fetch(0, 0);
             if (slot >= 2 && slot < 34) ep.step(0, slot - 2, F[0], F[1], un0, mrow);

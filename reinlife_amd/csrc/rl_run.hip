@@ -1,14 +1,26 @@
 // rl_run.hip -- the multi-tick kernel of the ReinLife hot path on MI355X (gfx950): k_run and its host launcher.
 #include "rl_world_dev.h"
+// What the input layer may assume about the Agent.state rows (XM of the tiles, rl_policy_dev.h in_chunk_class): measured per kernel family
+// (tools/xf_ab.sh).  The dueling-only kernel is SLOWER with it (21.8 -> 22.3 - 22.5 us per tick at configs[3]: its tiles are
+// bound by dependent latency, not by the matrix pipe, and fewer MFMAs leave the splits and the weight fetches nothing to hide behind), the
+// mixed-kind kernel faster (configs[4]: 26.7 -> 25.7 us): there a PPO tile shares its SIMD with a lighter one and every MFMA not issued is room.
+#ifndef RL_XM_DUELING_KERNEL
+#define RL_XM_DUELING_KERNEL 0
+#endif
+#ifndef RL_XM_ALL_KERNEL      /* 0: never; 2: tiles of worlds whose rows are known to be scaled by 2^10 with an integer health plane */
+#define RL_XM_ALL_KERNEL 2
+#endif
 
 // Measurement switch of the multi-tick launch (bench.py's per-half timings, tools/): 1 = skip the policy half, 2 = skip the tick half,
 // 4 / 8 / 16 = at most 2 / 1 / 3 policy tiles, 32 = no staggered start.  Results are then WRONG, so it exists in the TUNING builds only
 // (-DRL_TUNING: lib/libreinlife_hip_tune.so, and the stamped _prof build): the product library neither exports the switch nor compiles
 // the branches (RL_RUN_DBG is the constant 0 there).
 #ifdef RL_TUNING
+#if !(defined(RL_RUN_UNIT) && RL_RUN_UNIT == 1)   /* (the host side lives in unit 0) */
 static int g_run_debug = 0;
 extern "C" __attribute__((visibility("default"))) void rl_debug_set_run_mask(int mask) { g_run_debug = mask; }
 extern "C" __attribute__((visibility("default"))) int rl_debug_get_run_mask(void) { return g_run_debug; }
+#endif
 #define RL_RUN_DBG(ka) (*(const int __attribute__((address_space(4)))*)&(ka)->ra.debug)
 #else
 #define RL_RUN_DBG(ka) 0
@@ -81,6 +93,9 @@ struct PolSmem {
     int* wtask;         // [8]  per wave: tile | role << 8 | brains-list index << 12 | kind << 20, or -1
     int* texoff;        // [4]  per tile: byte offset of its exchange buffer inside the mirror
     int* bkind;         // [8]  the brains' kinds (filled once per launch)
+    int* oflags;        // [4]  [0] what is known about the CURRENT Agent.state rows (RL_XF_*, rl_policy_dev.h): the input layer skips the row-maximum
+                        //      pass and the exactly-zero partial products; [1] sticky for the launch: the loaded state held an agent with
+                        //      |health| >= 400 (never produced by the world's own rules: entities.py:145-159, environment.py:701-715)
 };
 // With mirror_budget > 0 the Agent.state rows are mirrored in LDS (as many rows as fit below the budget, at most cap); the two- and
 // four-wave tiles' exchange buffers alias the mirror.
@@ -122,6 +137,8 @@ __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o
     ps.wtask = (int*)(base + o); o = align16(o + sizeof(int) * 8);
     ps.texoff = (int*)(base + o); o = align16(o + sizeof(int) * 4);
     ps.bkind = (int*)(base + o); o = align16(o + sizeof(int) * kRunMaxBrains);
+    if (KIND == kKindAll) { ps.oflags = (int*)(base + o); o = align16(o + sizeof(int) * 4); }   // (the dueling-only kernel makes no use of it: see RL_XM_DUELING_KERNEL)
+    else ps.oflags = nullptr;
     ps.trk_scr = (double*)(base + o); o = align16(o + sizeof(double) * (size_t)cap);
     ps.trk.sum = (double*)(base + o); o = align16(o + sizeof(double) * kRunMaxBrains * RL_TRK_VARS);
     ps.trk.pop = (double*)(base + o); o = align16(o + sizeof(double) * 2);
@@ -296,6 +313,14 @@ __device__ inline void policy_lists_wave0(const KParams& p, PolSmem& ps, int n, 
 // the Agent.state mirror; the two roles of a tile may sit on any two wave slots (only LDS and the workgroup barriers connect them), so
 // the tiles are dealt heaviest first, each role onto the least loaded SIMD with a free slot (waves v and v + 4 share SIMD v): a PPO tile
 // (672 MFMAs) next to a dueling one (360) loads every SIMD with 516 instead of 672 / 360.  Otherwise: the same tiles in several rounds.
+// RL_XF_* of the Agent.state rows of a world whose state is in LDS (n rows, built by build_planes / write_observations from THIS state):
+// see in_lo_zero (rl_policy_dev.h).  bad_health: some agent of the launch's initial state had |health| >= 400.
+__device__ inline int run_obs_flags(const KParams& p, const Smem& s, int n, int bad_health)
+{
+    if (bad_health || n >= 2 * p.max_agents) return 0;
+    return RL_XF_SCALE | (s.type[0] == RL_AGENT ? 0 : RL_XF_INT_HEALTH);
+}
+
 __device__ inline void policy_schedule_wave0(const KParams& p, PolSmem& ps, RunParamsC* ka, int lane)
 {
     // Lane-parallel and in closed form (as serial single-lane code with a memory load per tile this cost 5.5k cycles on the wave that is
@@ -419,7 +444,7 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
         pl.ex = (f32x4*)((char*)ps.xmirror + (size_t)kPairExBytes * slot);
         if (have) {
             tile_io(slot, io, j);
-            policy_tile1s<KIND, RL_RUN_COHERENT, true>(io, lane, role, &pl, &part);
+            policy_tile1s<KIND, RL_RUN_COHERENT, true, RL_XM_DUELING_KERNEL>(io, lane, role, &pl, &part);
         } else { lds_barrier(); lds_barrier(); }   // (the two exchanges inside the tile)
 #ifdef RL_PHASE_PROFILE
         if (p.prof && (int)blockIdx.x == p.prof_world && lane == 0) p.prof[116 + wave] = (long long)clock64();   // (128 slots)
@@ -430,7 +455,7 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
     for (int ti = wave; ti < ntiles; ti += T / 64) {
         TileIO io;
         tile_io(ti, io, j);
-        if (T == 512) policy_tile1s<KIND, RL_RUN_COHERENT>(io, lane);
+        if (T == 512) policy_tile1s<KIND, RL_RUN_COHERENT, false, RL_XM_DUELING_KERNEL>(io, lane);
         else policy_tile1<KIND, RL_RUN_COHERENT, true>(io, lane);
     }
 #ifdef RL_PHASE_PROFILE
@@ -455,6 +480,13 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
     const int ntiles = __builtin_amdgcn_readfirstlane(ps.meta[0]);
     const bool mirrored = ps.xmirror != nullptr && __builtin_amdgcn_readfirstlane(ps.meta[4]) != 0;
     const bool fallback = __builtin_amdgcn_readfirstlane(ps.meta[5]) != 0;
+    // (read with the schedule, in ONE batch of LDS loads: not on the way into every tile)
+    constexpr int xneed = RL_XM_ALL_KERNEL == 2 ? (RL_XF_SCALE | RL_XF_INT_HEALTH) : RL_XF_SCALE;
+#ifdef RL_XM_ASSUME_ALWAYS   /* negative control of tests/test_hip_round5.py (results WRONG where the rows are not what is assumed) */
+    const bool rows_known = true;
+#else
+    const bool rows_known = RL_XM_ALL_KERNEL != 0 && (__builtin_amdgcn_readfirstlane(ps.oflags[0]) & xneed) == xneed;
+#endif
     auto tile_io = [&](int ti, TileIO& io, bool from_mirror, int task) {   // task >= 0: the wave's descriptor names brain and kind
         const int b = task >= 0 ? ((task >> 12) & 255) : __builtin_amdgcn_readfirstlane(ps.tbrain[ti]);
         const int e = (unsigned short)ps.trow[ti * 32 + j], k = e & 0x7fff;
@@ -486,9 +518,17 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
             kind = __builtin_amdgcn_readfirstlane(tile_io(ti, io, from_mirror, task));
             pl.val = ps.pairv + kPairFloatsAll * slot; pl.pmax = pl.val + kPairValFloats;
             pl.ex = (f32x4*)((char*)ps.xmirror + ex_off);
-            if (kind == RL_DQN) policy_pair2<RL_DQN, RL_RUN_COHERENT>(io, lane, role, &pl, &part);
-            else if (kind == RL_PPO) policy_pair2<RL_PPO, RL_RUN_COHERENT>(io, lane, role, &pl, &part);
-            else policy_tile1s<RL_PERD3QN, RL_RUN_COHERENT, true>(io, lane, role, &pl, &part);
+            // two copies of every tile: the rows of THIS world and tick are known to be scaled by 2^10 with exactly-zero lo halves in the
+            // plane chunks (oflags[0], run_obs_flags: ~9 in 10 ticks) -- or nothing is assumed.  Bit-identical either way.
+            if (rows_known) {
+                if (kind == RL_DQN) policy_pair2<RL_DQN, RL_RUN_COHERENT, RL_XM_ALL_KERNEL>(io, lane, role, &pl, &part);
+                else if (kind == RL_PPO) policy_pair2<RL_PPO, RL_RUN_COHERENT, RL_XM_ALL_KERNEL>(io, lane, role, &pl, &part);
+                else policy_tile1s<RL_PERD3QN, RL_RUN_COHERENT, true, RL_XM_ALL_KERNEL>(io, lane, role, &pl, &part);
+            } else {
+                if (kind == RL_DQN) policy_pair2<RL_DQN, RL_RUN_COHERENT>(io, lane, role, &pl, &part);
+                else if (kind == RL_PPO) policy_pair2<RL_PPO, RL_RUN_COHERENT>(io, lane, role, &pl, &part);
+                else policy_tile1s<RL_PERD3QN, RL_RUN_COHERENT, true>(io, lane, role, &pl, &part);
+            }
         } else { lds_barrier(); lds_barrier(); }   // (the two exchanges inside a tile)
         lds_barrier();
         if (have && role == 0) {
@@ -816,6 +856,9 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
             if constexpr (KIND == kKindAll) policy_schedule_wave0(p, ps, ka, tid);
             RL_MARK_T(97, 0);
         } else {
+            // (what the next tick's input layer may assume about these rows -- s.type[0] is what build_planes saw; on a lane of wave 1:
+            // wave 0 is the long pole of this interval)
+            if constexpr (KIND == kKindAll) { if (tid == 64) ps.oflags[0] = run_obs_flags(p, s, n2, ps.oflags[1]); }
             write_observations<(T > 64 ? T - 64 : 64)>(p, s, w, n2, obs_out, tid - 64, ps.xmirror, ps.xrows);
             RL_MARK_T(98, 64); RL_MARK_T(99, T - 64);
         }
@@ -910,7 +953,20 @@ __device__ __forceinline__ void run_load_call(RunParamsC* ka)   // (inlined: loa
             m[0] = 0.0f; m[1] = 0.0f; m[2] = 0.0f; *(float4*)(m + 3) = float4{0.0f, 0.0f, 0.0f, 0.0f};
         }
     RL_MARK(92);
-    if (tid == 0) { ps.meta[1] = n0; ps.meta[2] = first; ps.meta[3] = 0; ps.meta[4] = preload ? 1 : 0; }
+    if constexpr (KIND == kKindAll) {   // what is known about the rows this launch starts from (written by an earlier launch from THIS state): the loaded agents' health
+        // decides whether any row can exceed [1, 2) -- a world's own rules keep |health| <= 300, a state written by the caller may not
+        int bad = 0;
+        for (int a = tid; a < n0; a += T) bad |= (s.health[a] >= 400 || s.health[a] <= -400) ? 1 : 0;
+        bad = __any(bad);
+        if (tid == 0) ps.oflags[1] = 0;
+        lds_barrier();
+        if (bad && (tid & 63) == 0) ps.oflags[1] = 1;
+        lds_barrier();
+    }
+    if (tid == 0) {
+        ps.meta[1] = n0; ps.meta[2] = first; ps.meta[3] = 0; ps.meta[4] = preload ? 1 : 0;
+        if constexpr (KIND == kKindAll) ps.oflags[0] = run_obs_flags(p, s, n0, ps.oflags[1]);
+    }
     if (TRAIN && p.so.trk_tick) {   // the Tracker's running sums live in LDS for the length of the launch
         const int G = p.static_families ? p.n_brains : 1, t = tid;
         const size_t o = (size_t)blockIdx.x * G * RL_TRK_VARS;
@@ -1015,6 +1071,22 @@ __global__ __launch_bounds__(T) void k_run(const RunParams rp)
 }
 
 }  // namespace
+
+// Two translation units from this one file (build.py; the kernels of the two families compile side by side -- the mixed-kind family alone
+// takes as long as everything else in the library): RL_RUN_UNIT 1 holds the kKindAll instantiations and hands their addresses out through
+// rl_run_fn_all(); RL_RUN_UNIT 0 holds the dueling-kind instantiations and the host side.  Undefined (tuning one-offs): everything in one unit.
+#if defined(RL_RUN_UNIT) && RL_RUN_UNIT == 1
+const void* rl_run_fn_all(int fixed, int train)
+{
+#define RL_RUN_ALL(FX, TR) if (fixed == (FX ? 1 : 0) && train == TR) return (const void*)k_run<512, FX, kKindAll, TR>;
+    RL_RUN_ALL(true, 0) RL_RUN_ALL(true, 1) RL_RUN_ALL(true, 2) RL_RUN_ALL(false, 0) RL_RUN_ALL(false, 1) RL_RUN_ALL(false, 2)
+#undef RL_RUN_ALL
+    return nullptr;
+}
+#else
+#if defined(RL_RUN_UNIT)
+const void* rl_run_fn_all(int fixed, int train);
+#endif
 
 // rl_run: which kernel serves these brains -- RL_PERD3QN (all of a dueling kind), kKindAll (any mix), or -1
 static int run_kind_of(const rl_brain* brains, int n_brains)
@@ -1135,7 +1207,11 @@ int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n
 #ifdef RL_RUN_256
     RL_RUN_PICK3(256, true, RL_PERD3QN) RL_RUN_PICK3(256, false, RL_PERD3QN)
 #endif
+#if defined(RL_RUN_UNIT)
+    if (T == 512 && kind == kKindAll) fn = rl_run_fn_all(fixed ? 1 : 0, train);   // (the other translation unit)
+#else
     RL_RUN_PICK3(512, true, kKindAll) RL_RUN_PICK3(512, false, kKindAll)
+#endif
 #undef RL_RUN_PICK3
 #endif
 #undef RL_RUN_PICK
@@ -1162,4 +1238,4 @@ int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n
     if (e != hipSuccess) { rl_set_error("run kernel launch failed: %s", hipGetErrorString(e)); return RL_E_LAUNCH; }
     return RL_OK;
 }
-
+#endif   // RL_RUN_UNIT != 1

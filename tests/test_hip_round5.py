@@ -75,3 +75,54 @@ def test_single_world_figures_of_the_default_line():
         assert r["rng"] == "reference" and r["n_worlds"] == 1 and r["episodes"] == 301 and r["value"] > 0 and r["mean_agents"] > 0
     assert "configs[0]" in sw["trainer_configs0"]["call"] and "DQN(max_epi=300)" in sw["trainer_default"]["call"]
     assert sw["reference_cpu_survey_time"]["C3 100 agents, DQN forward + step"] == 7100
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the input layer's use of what an observation row IS (rl_policy_dev.h in_chunk_class) -- where it must NOT be used
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["health-1000", "crowded-beyond-2n", "plain"])
+def test_known_row_structure_is_only_used_where_it_holds(case):
+    """The mixed-kind multi-tick kernel skips the input layer's row-maximum pass and the exactly-zero W_hi . x_lo products when a world's rows
+    are KNOWN to lie in [1, 2) with an integer health plane (run_obs_flags).  Worlds where that does not hold -- an agent whose health a
+    caller set beyond +-400 (the row's health feature then exceeds 2), more than 2 x max_agents agents (n / max_agents >= 2), an agent on
+    cell (0,0) (float health plane: happens by itself in a few worlds per tick) -- must take the general code: outputs (Q / probabilities),
+    actions and worlds BIT-identical to the stand-alone kernels, which assume nothing, tick by tick."""
+    import numpy as np
+    import torch
+    from reinlife_amd import _lib
+    from reinlife_amd.worlds import DeviceWorlds, pack_brain_weights
+    from test_hip_round2 import _cmp_rows, _same_device_state, _weights
+    names, eps = ["PPO", "PERD3QN", "DQN"], [0.0, 0.05, 0.1]
+    crowded = case == "crowded-beyond-2n"
+    cfg = dict(width=12, height=10, max_agents=4, n_brains=3) if crowded else dict(width=30, height=30, max_agents=100, n_brains=3)
+    n_new, thr = (11, 3) if crowded else (100, 70)
+    pair = []
+    for _ in range(2):
+        dw = DeviceWorlds(n_worlds=24, seed=17, static_families=False, **cfg)
+        dw.set_brains([(_lib.KIND_BY_METHOD[n], e, pack_brain_weights(_lib.KIND_BY_METHOD[n], _weights(n, 40 + k))) for k, (n, e) in enumerate(zip(names, eps))])
+        dw.reset_synthetic(n_new)
+        if case == "health-1000":   # a state only a caller can write: the row scale of these worlds' rows is not 2^10
+            dw.s["a_health"][::3, 0] = 1000
+            dw.s["a_health"][1::3, 1] = -900
+            dw.s["a_flags"][1::3, 1] = 0
+            _lib.check(dw.lib.rl_bind_state(dw.handle, __import__("ctypes").byref(dw._state)), "rl_bind_state")
+            dw.observe()
+        pair.append(dw)
+    fused, loop = pair
+    assert fused.run_supported()
+    float_rows = big_rows = 0
+    for t in range(25):
+        obs = fused.obs_state().cpu().numpy()
+        n = fused.s["n_agents"].cpu().numpy()
+        live = np.arange(fused.cap)[None, :] < n[:, None]
+        big_rows += int((np.abs(obs).max(axis=2)[live] >= 2.0).sum())
+        float_rows += int(((obs[:, :, 49:98] != np.trunc(obs[:, :, 49:98])).any(axis=2) & live).sum())
+        fused.run(1, thr, n_new, want_q=True)
+        loop.act(want_q=True); loop.tick_refill(thr, n_new)
+        fused.check_error_flag(); loop.check_error_flag()
+        acted = fused.n_acted.cpu().numpy()
+        _cmp_rows(fused.out_q.cpu().numpy(), loop.out_q.cpu().numpy(), acted, "tick %d outputs" % t)
+        _cmp_rows(fused.actions.cpu().numpy(), loop.actions.cpu().numpy(), acted, "tick %d actions" % t)
+        _same_device_state(fused, loop, "tick %d" % t)
+    assert float_rows > 0                                  # some worlds had an agent on cell (0,0): the float health plane was exercised
+    assert (big_rows > 0) == (case != "plain"), big_rows   # rows whose largest magnitude is >= 2 exist exactly in the two adversarial cases

@@ -25,13 +25,9 @@ ap.add_argument("--ticks", type=int, default=200)
 a = ap.parse_args()
 
 from reinlife_amd import build as _build  # noqa: E402
-if a.no_build:
-    hdrs = [os.path.join(_build.CSRC, h) for h in _build.HEADERS]
-    flags = _build.FLAGS + ["-DRL_TUNING", "-DRL_RUN_1024", "-DRL_RUN_256"]
-    digests = [_build._digest([os.path.join(_build.CSRC, s)] + hdrs, " ".join(flags)) for s in _build.SOURCES]
-    if not _build._stamp_ok(_build.LIB_PATH, _build._digest([], " ".join(digests))):
-        print(json.dumps({"error": "the tuning library is not built for these sources: RL_TUNE=1 python reinlife_amd/build.py"}))
-        raise SystemExit(0)
+if a.no_build and not _build.library_is_current():
+    print(json.dumps({"error": "the tuning library is not built for these sources: RL_TUNE=1 python reinlife_amd/build.py"}))
+    raise SystemExit(0)
 
 import torch  # noqa: E402
 import bench  # noqa: E402
