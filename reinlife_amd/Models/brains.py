@@ -62,12 +62,17 @@ class _HipBrain(BasicBrain):
         address and in-place version counter, so load_state_dict(), optimizer steps, target/eval syncs or a replaced module
         repack automatically at the next use."""
         net = self._net()
-        # (the module's tensors are listed once per module object: walking parameters() / buffers() through nn.Module's generators on
-        # every call cost 50 us per brain -- more than a short launch's whole host side; in-place updates bump _version, a replaced
-        # module has another id, and a parameter swapped for a new tensor object calls for invalidate())
-        if getattr(self, "_tensors_of", None) != id(net):
-            self._tensors, self._tensors_of = list(net.parameters()) + list(net.buffers()), id(net)
-        key = (str(device), id(net)) + tuple((t.data_ptr(), t._version) for t in self._tensors)
+        # The key must notice every way the weights can change -- in-place updates (optimizer steps, load_state_dict: _version), a Parameter
+        # object swapped for a new one (net.fc1.weight = nn.Parameter(...), weight_norm / parametrize, .to() under
+        # overwrite_module_params_on_conversion: another data_ptr), a replaced sub-module or network (ids) -- without walking
+        # nn.Module.parameters() / buffers() through their generators on every call (50 us per brain: more than a short launch's whole host
+        # side).  So the SLOTS the tensors live in ((dict, name) per parameter and buffer) are listed once per set of module objects, and
+        # every call reads the tensors that are in those slots NOW.
+        mods = (id(net),) + tuple(map(id, net._modules.values()))   # (the reference's networks are flat: Linear children only)
+        if getattr(self, "_slots_of", None) != mods:
+            self._slots = [(m._parameters, k) for m in net.modules() for k in m._parameters] + [(m._buffers, k) for m in net.modules() for k in m._buffers]
+            self._slots_of = mods
+        key = (str(device),) + mods + tuple((t.data_ptr(), t._version) for t in (d[k] for d, k in self._slots) if t is not None)
         if getattr(self, "_packed_key", None) != key:
             from ..worlds import pack_brain_weights
             self._packed = pack_brain_weights(self.kind, self.state_dict_flat(), device)
@@ -75,7 +80,7 @@ class _HipBrain(BasicBrain):
         return self._packed
 
     def invalidate(self):
-        self._packed_key = self._tensors_of = None
+        self._packed_key = self._slots_of = None
 
     def forward_batch(self, states, device="cuda:0"):
         """[n,153] observations -> [n,8] Q values / probabilities on the GPU."""

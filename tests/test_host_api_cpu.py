@@ -77,3 +77,28 @@ def test_saver_writes_the_reference_layout_and_loadable_state_dicts(tmp_path, mo
             assert k in params and (params[k] == v or k in ("load_model",)), (b.method, k, params.get(k), v)
     assert os.path.exists(os.path.join(exp2, "PERD3QN", "brain_1.pt")) and os.path.exists(os.path.join(exp2, "DQN", "parameters_1.json"))
     assert json.load(open(os.path.join(exp, "results.json")))["Avg Number of Populations"] == [2.0]
+
+
+def test_packed_weights_cache_notices_every_way_the_weights_can_change(monkeypatch):
+    """Models.*.packed_weights() repacks exactly when the weights changed: in-place updates, load_state_dict, a Parameter object swapped
+    for a new one, a replaced sub-module, a replaced network -- and not otherwise (the key used to cache the tensor LIST)."""
+    import torch
+    from reinlife_amd import Models, worlds
+    calls = []
+    monkeypatch.setattr(worlds, "pack_brain_weights", lambda kind, flat, device="cuda:0": calls.append(float(flat.sum())) or object())
+    b = Models.PERD3QN()
+    p0 = b.packed_weights("cuda:0")
+    assert b.packed_weights("cuda:0") is p0 and len(calls) == 1                      # unchanged: the cached pack
+    with torch.no_grad():
+        b.eval_net.fc.weight.add_(1.0)                                               # in place (an optimizer step)
+    assert b.packed_weights("cuda:0") is not p0 and len(calls) == 2
+    b.eval_net.load_state_dict(b.target_net.state_dict())                            # load_state_dict copies in place
+    b.packed_weights("cuda:0"); assert len(calls) == 3
+    b.eval_net.adv_fc1.weight = torch.nn.Parameter(torch.zeros_like(b.eval_net.adv_fc1.weight))   # a NEW Parameter object in the slot
+    b.packed_weights("cuda:0"); assert len(calls) == 4 and calls[-1] != calls[-2]
+    b.eval_net.value_fc2 = torch.nn.Linear(128, 1)                                   # a replaced sub-module
+    b.packed_weights("cuda:0"); assert len(calls) == 5
+    b.eval_net = type(b.eval_net)(153, 8)                                            # a replaced network
+    b.packed_weights("cuda:0"); assert len(calls) == 6
+    b.packed_weights("cuda:0"); assert len(calls) == 6
+    b.packed_weights("cuda:1"); assert len(calls) == 7                               # another device: its own pack

@@ -1,7 +1,8 @@
 """Workload run under rocprofv3 --pmc: a calibration copy of known size, then a few bench steps."""
 import argparse
 import os
-os.environ.setdefault("RL_TUNE", "1")   # the tuning library (libreinlife_hip_tune.so) carries rl_debug_set_run_mask; the product does not
+if os.environ.get("RL_PMC_RUN_MASK", "0") != "0":
+    os.environ.setdefault("RL_TUNE", "1")   # counters of one half alone: the tuning library carries rl_debug_set_run_mask (the product does not)
 import sys
 
 import torch
@@ -9,7 +10,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
-args = argparse.Namespace(worlds=int(os.environ.get("RL_WORLDS", "256")), workload="c4", seed=1)
+args = argparse.Namespace(worlds=int(os.environ.get("RL_WORLDS", "256")), workload=os.environ.get("RL_PMC_WORKLOAD", "c4"), seed=1)
 x = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device="cuda:0").normal_()   # 512 MiB > L3
 y = torch.empty_like(x)
 for _ in range(3):

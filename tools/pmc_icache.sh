@@ -3,7 +3,7 @@
 set -e
 export RL_WORLDS=${1:-256}
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_icache
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_icache_${RL_PMC_WORKLOAD:-c4}
 rm -rf $OUT && mkdir -p $OUT
 rocprofv3 -L 2>/dev/null | grep -o "SQC_[A-Z_0-9]*\|SQ_IFETCH[A-Z_0-9]*\|SQ_INST_LEVEL[A-Z_0-9]*\|SQ_WAIT_IFETCH[A-Z_0-9]*" | sort -u > $OUT/available.txt || true
 head -60 $OUT/available.txt
