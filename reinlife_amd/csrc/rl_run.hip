@@ -7,6 +7,9 @@
 #ifndef RL_XM_DUELING_KERNEL
 #define RL_XM_DUELING_KERNEL 0
 #endif
+#ifndef RL_XM_ALL_DUELING_TILE   /* the dueling tile INSIDE the mixed-kind kernel (A/B: RL_XM_ALL_KERNEL, or 0 = one copy of it) */
+#define RL_XM_ALL_DUELING_TILE RL_XM_ALL_KERNEL
+#endif
 #ifndef RL_XM_ALL_KERNEL      /* 0: never; 2: tiles of worlds whose rows are known to be scaled by 2^10 with an integer health plane */
 #define RL_XM_ALL_KERNEL 2
 #endif
@@ -520,10 +523,12 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
             pl.ex = (f32x4*)((char*)ps.xmirror + ex_off);
             // two copies of every tile: the rows of THIS world and tick are known to be scaled by 2^10 with exactly-zero lo halves in the
             // plane chunks (oflags[0], run_obs_flags: ~9 in 10 ticks) -- or nothing is assumed.  Bit-identical either way.
-            if (rows_known) {
+            const bool plain = kind == RL_DQN || kind == RL_PPO;
+            if (!plain && RL_XM_ALL_DUELING_TILE == 0) policy_tile1s<RL_PERD3QN, RL_RUN_COHERENT, true>(io, lane, role, &pl, &part);   // (ONE copy of this tile)
+            else if (rows_known) {
                 if (kind == RL_DQN) policy_pair2<RL_DQN, RL_RUN_COHERENT, RL_XM_ALL_KERNEL>(io, lane, role, &pl, &part);
                 else if (kind == RL_PPO) policy_pair2<RL_PPO, RL_RUN_COHERENT, RL_XM_ALL_KERNEL>(io, lane, role, &pl, &part);
-                else policy_tile1s<RL_PERD3QN, RL_RUN_COHERENT, true, RL_XM_ALL_KERNEL>(io, lane, role, &pl, &part);
+                else policy_tile1s<RL_PERD3QN, RL_RUN_COHERENT, true, RL_XM_ALL_DUELING_TILE>(io, lane, role, &pl, &part);
             } else {
                 if (kind == RL_DQN) policy_pair2<RL_DQN, RL_RUN_COHERENT>(io, lane, role, &pl, &part);
                 else if (kind == RL_PPO) policy_pair2<RL_PPO, RL_RUN_COHERENT>(io, lane, role, &pl, &part);

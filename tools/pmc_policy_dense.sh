@@ -1,7 +1,7 @@
 #!/bin/bash
 # Vector-memory / L2 counters of a dense policy launch (tuning aid; run on the GPU box through gpurun):  bash tools/pmc_policy_dense.sh [variant]
 set -e
-export RL_POLICY_VARIANT=${1:-nsplit}
+export RL_POLICY_VARIANT=${1:-pair}
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_dense_$RL_POLICY_VARIANT
 rm -rf $OUT && mkdir -p $OUT
