@@ -551,18 +551,23 @@ def main():
     events_in_region = fused and not args.no_kernel_timing and args.steps >= 200
     advance(args.steps, timed_events if events_in_region else None)
     torch.cuda.synchronize()
+    # This rank's K steps: from the common start (barrier + synchronise above) to ITS device being idle.  The job's time is the MAXIMUM of
+    # these over the ranks (taken by the counter collective below) -- the moment the slowest rank finished.  The closing barrier + synchronise
+    # of the bracket follow; a collective's own latency (tens of microseconds over xGMI, next to a 0.5 ms window of 20 steps) is not work
+    # of the K steps, so it is reported beside the figure (per_rank.elapsed_incl_closing_barrier_ms), not inside it.  One rank: identical.
+    elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed_bracket = time.perf_counter() - t0
     (grp or dw).check_error_flag()
 
     # the only collective of the job: ONE RCCL all-gather of every rank's [agent-steps, refills, elapsed] row over xGMI
     # (reinlife_amd/distributed.py); executed whenever a process group exists, also with one rank
     counted = grp.counters() if grp else (float(dw.acted_total.item()), float(dw.refill_count.item()))
-    stats = torch.tensor(list(counted) + [float(dw.world_base)], dtype=torch.float64, device=device)   # (world_base: for the per-rank table only)
+    stats = torch.tensor(list(counted) + [float(dw.world_base), elapsed_bracket], dtype=torch.float64, device=device)   # (world_base, bracket: for the per-rank table only)
     stats, elapsed, rank_table = reduce_counters(stats, elapsed, dist)
-    total_agent_steps, refills, _ = stats.tolist()
+    total_agent_steps, refills = stats.tolist()[:2]
     rank_rates = (rank_table[:, 0] / rank_table[:, -1]).tolist()   # each rank's own agent-steps/s over its own clock: stragglers show here
 
     # ---- per-kernel durations with HIP events on the launch stream (untimed extra steps) ------------------------------
@@ -742,6 +747,8 @@ def main():
             "dist_backend": {None: None, "nccl": "nccl (RCCL)"}.get(backend, backend),
             "per_rank": {"value_min": round(min(rank_rates), 1), "value_max": round(max(rank_rates), 1),
                          "elapsed_ms": [round(float(x) * 1e3, 3) for x in rank_table[:, -1].tolist()],
+                         "elapsed_incl_closing_barrier_ms": [round(float(x) * 1e3, 3) for x in rank_table[:, 3].tolist()],
+                         "timed": "per rank: common start (barrier + synchronise) -> its own synchronise after the K steps; value = all ranks' agent-steps / the MAXIMUM of these",
                          "agent_steps": [int(x) for x in rank_table[:, 0].tolist()], "world_base": [int(x) for x in rank_table[:, 2].tolist()],
                          "device": device if not args.share_gpu else "cuda:0 shared by every rank (dry run)",
                          "final_barrier_wait_s": barrier_waits},

@@ -43,6 +43,8 @@ def test_two_rank_dry_run_of_the_multi_gpu_bench_path():
     assert two["rccl_collectives_executed"] == 1 and one["rccl_collectives_executed"] == 0      # the metric's reduction: ONE collective
     assert abs(two["value"] - two["config"]["agent_steps"] / (two["ms_per_step"] * 1e-3 * 30)) < 1e-3 * two["value"]
     assert max(pr["elapsed_ms"]) * 1e-3 <= two["ms_per_step"] * 1e-3 * 30 + 1e-6 and pr["value_min"] <= pr["value_max"]
+    # the job's time = the slowest rank's own K steps; the closing barrier's latency (milliseconds under gloo) is reported beside it
+    assert abs(max(pr["elapsed_ms"]) - two["ms_per_step"] * 30) < 1e-2 and all(b >= e for b, e in zip(pr["elapsed_incl_closing_barrier_ms"], pr["elapsed_ms"]))
     # nobody is left waiting behind a leg only rank 0 runs
     assert len(pr["final_barrier_wait_s"]) == 2 and max(pr["final_barrier_wait_s"]) < 5.0
     # the dominant kernel's roofline stays in a multi-rank line (rank 0's kernel)
