@@ -81,10 +81,15 @@ def brain_weights(kind_name, seed):
 
 WORKLOADS = {
     "c4": dict(brains=["PERD3QN", "PERD3QN"], static_families=True,
-               name="256 worlds/GPU x 30x30 x 100 agents, 2xPERD3QN greedy inference, static families (BASELINE configs[3])"),
+               name="%d worlds/GPU x 30x30 x 100 agents, 2xPERD3QN greedy inference, static families (BASELINE configs[3]%s)"),
     "c5": dict(brains=["PPO", "PERD3QN"], static_families=False,
-               name="256 worlds/GPU x 30x30 x 100 agents, PPO + PERD3QN mixed brains, static_families=False (BASELINE configs[4])"),
+               name="%d worlds/GPU x 30x30 x 100 agents, PPO + PERD3QN mixed brains, static_families=False (BASELINE configs[4]%s)"),
 }
+
+
+def workload_name(key, worlds):
+    """config.workload: the BASELINE configuration at the replica count that actually ran (256 per GPU is the configuration's own)."""
+    return WORKLOADS[key]["name"] % (worlds, "" if worlds == 256 else " at %d instead of 256 worlds per GPU" % worlds)
 
 
 def make_worlds(args, rank, device, n_worlds=None, world_base=None):
@@ -382,7 +387,7 @@ def c5_leg(args, rank, device, dist=None):
     flop = float(np.mean([POLICY_FLOP_PER_AGENT[k] for k in wl["brains"]]))
     by = TICK_BYTES_PER_AGENT_STEP + POLICY_BYTES_PER_AGENT
     n_ranks = len(table)
-    return {"workload": wl["name"], "value": round(steps_all / wall_max, 1), "unit": "agent-steps/s", "ranks": n_ranks,
+    return {"workload": workload_name("c5", args.worlds), "value": round(steps_all / wall_max, 1), "unit": "agent-steps/s", "ranks": n_ranks,
             "worlds_total": args.worlds * n_ranks, "agent_steps": int(round(steps_all)), "ticks": n,
             "us_per_tick": round(wall_max / n * 1e6, 2), "kernel_us_per_tick": round(float(table[:, 1].max()) / n * 1e6, 2),
             "agent_steps_per_tick": round(steps_all / n, 1),
@@ -438,6 +443,10 @@ def respawn_under_torchrun(args):
     if os.environ.get("RL_BENCH_PRINT_SPAWN"):   # (tests/test_bench_cpu.py: the launch line, without launching)
         print(json.dumps({"cmd": cmd, "HSA_ENABLE_IPC_MODE_LEGACY": env["HSA_ENABLE_IPC_MODE_LEGACY"]}))
         raise SystemExit(0)
+    # the library is brought up to date HERE, once, before N ranks exist: they then find it current (a few file digests each, no lock, no
+    # compiler).  Under the driver's own torchrun line there is no parent: build() is serialised by an flock and moves its files into
+    # place atomically (reinlife_amd/build.py), so N ranks on a stale tree compile once and never map a half-written library.
+    _lib.lib()
     sys.stdout.flush()
     raise SystemExit(subprocess.call(cmd, env=env))
 
@@ -480,6 +489,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend: nccl = RCCL over xGMI (the product); gloo = dry run of the N > 1 path (collectives hop through the host)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank on cuda:0 (needs --dist-backend gloo)")
+    ap.add_argument("--dist-timeout", type=float, default=180.0, help="process-group timeout in seconds (rendezvous and every collective)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -493,10 +503,13 @@ def main():
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world_size))
         torch.cuda.set_device(dev_index)
+        # a rank that dies in set-up must not leave the others in a collective for the backend's default 10 / 30 minutes
+        from datetime import timedelta
+        pg_timeout = timedelta(seconds=args.dist_timeout)
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=pg_timeout)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: the process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus))
     n_ranks = dist.get_world_size() if dist is not None else 1
@@ -546,29 +559,35 @@ def main():
             pass
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    t0_shared = time.monotonic_ns()   # CLOCK_MONOTONIC: one clock for every process of the node -- the ranks' starts and ends are comparable
     # (HIP events around the launches of the timed region itself when it is long; a short region -- the driver's 20 steps are ONE launch
     # of ~0.5 ms -- is not burdened with the two event records (~1 % of it): its launch is replayed right afterwards, see below)
     events_in_region = fused and not args.no_kernel_timing and args.steps >= 200
     advance(args.steps, timed_events if events_in_region else None)
     torch.cuda.synchronize()
-    # This rank's K steps: from the common start (barrier + synchronise above) to ITS device being idle.  The job's time is the MAXIMUM of
-    # these over the ranks (taken by the counter collective below) -- the moment the slowest rank finished.  The closing barrier + synchronise
-    # of the bracket follow; a collective's own latency (tens of microseconds over xGMI, next to a 0.5 ms window of 20 steps) is not work
-    # of the K steps, so it is reported beside the figure (per_rank.elapsed_incl_closing_barrier_ms), not inside it.  One rank: identical.
+    # This rank's K steps end when ITS device is idle.  The JOB's time is taken on the node's shared clock: from the EARLIEST rank's start
+    # (its exit from the opening barrier + synchronise) to the LATEST rank's end -- start skew between the ranks is inside the figure, the
+    # closing barrier's own latency (a collective, not work of the K steps) is not; the bracketed figure (closing barrier + synchronise
+    # included: the contract's literal bracket) is reported beside it as value_incl_closing_barrier.  One rank: all three are the same interval.
     elapsed = time.perf_counter() - t0
+    t1_shared = time.monotonic_ns()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed_bracket = time.perf_counter() - t0
     (grp or dw).check_error_flag()
 
-    # the only collective of the job: ONE RCCL all-gather of every rank's [agent-steps, refills, elapsed] row over xGMI
-    # (reinlife_amd/distributed.py); executed whenever a process group exists, also with one rank
+    # the only collective of the job: ONE RCCL all-gather of every rank's [agent-steps, refills, world_base, bracket, start, end, own elapsed]
+    # row over xGMI (reinlife_amd/distributed.py); executed whenever a process group exists, also with one rank.  (Nanoseconds of
+    # CLOCK_MONOTONIC = time since boot: < 2^53 for 104 days of uptime, exact in float64.)
     counted = grp.counters() if grp else (float(dw.acted_total.item()), float(dw.refill_count.item()))
-    stats = torch.tensor(list(counted) + [float(dw.world_base), elapsed_bracket], dtype=torch.float64, device=device)   # (world_base, bracket: for the per-rank table only)
-    stats, elapsed, rank_table = reduce_counters(stats, elapsed, dist)
+    stats = torch.tensor(list(counted) + [float(dw.world_base), elapsed_bracket, float(t0_shared), float(t1_shared)], dtype=torch.float64, device=device)
+    stats, elapsed_own_max, rank_table = reduce_counters(stats, elapsed, dist)
     total_agent_steps, refills = stats.tolist()[:2]
     rank_rates = (rank_table[:, 0] / rank_table[:, -1]).tolist()   # each rank's own agent-steps/s over its own clock: stragglers show here
+    starts_ns, ends_ns = rank_table[:, 4], rank_table[:, 5]
+    elapsed = float(ends_ns.max() - starts_ns.min()) * 1e-9 if n_ranks > 1 else elapsed_own_max   # latest end - earliest start
+    elapsed_bracket_max = float(rank_table[:, 3].max())
 
     # ---- per-kernel durations with HIP events on the launch stream (untimed extra steps) ------------------------------
     roofline, extra = None, {}
@@ -721,18 +740,27 @@ def main():
     if rank == 0 and args.gpus == 1 and args.groups == 1 and not args.no_single_world:
         single = single_world(args, device)
 
-    cpu = None
-    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args)
-
-    # every rank is done with its legs: how long each one waits here for the slowest (rank 0 carries the rank-0-only legs) is part of
-    # the line -- a rank stuck behind a leg the others skipped would show as seconds
+    # every rank is done with its timed legs: how long each one waits here for the slowest (rank 0 carries the rank-0-only kernel probes)
+    # is part of the line -- a rank stuck behind a leg the others skipped would show as seconds
     barrier_waits = [0.0]
     if dist is not None:
         tb = time.perf_counter()
         dist.barrier()
         w = torch.tensor([time.perf_counter() - tb], dtype=torch.float64, device=device)
         barrier_waits = [round(float(x), 4) for x in rl_dist.gather_rows(w, dist).reshape(-1).tolist()]
+
+    # the CPU port on the box's host cores, in the same run, at EVERY N (north_star: "next to the reference numpy/CPU path timed on the
+    # same box's host cores ... in the same run"): rank 0, AFTER every timed leg of every rank (the barrier above), the other ranks parked
+    # in the barrier below -- its ~15 s of all-core work never overlap a GPU measurement.
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+    cpu_wait = [0.0]
+    if dist is not None:
+        tb = time.perf_counter()
+        dist.barrier()
+        w = torch.tensor([time.perf_counter() - tb], dtype=torch.float64, device=device)
+        cpu_wait = [round(float(x), 3) for x in rl_dist.gather_rows(w, dist).reshape(-1).tolist()]
 
     if rank == 0:
         wl = WORKLOADS[args.workload]
@@ -745,13 +773,22 @@ def main():
             "rccl_collectives_executed": main_collectives,
             "ranks": n_ranks,
             "dist_backend": {None: None, "nccl": "nccl (RCCL)"}.get(backend, backend),
+            "value_incl_closing_barrier": round(total_agent_steps / elapsed_bracket_max, 1),
+            "value_slowest_rank_own_clock": round(total_agent_steps / elapsed_own_max, 1),
+            "timed": "N > 1: all ranks' agent-steps / (latest rank's end - earliest rank's start) on the node's CLOCK_MONOTONIC, a rank's start = its exit from "
+                     "the opening barrier + synchronise, its end = its own synchronise after the K steps; value_incl_closing_barrier = over the slowest "
+                     "rank's bracket incl. the closing barrier + synchronise; value_slowest_rank_own_clock = over the longest of the ranks' own "
+                     "start -> end intervals (start skew invisible).  N = 1: one interval, three equal figures up to the closing synchronise",
             "per_rank": {"value_min": round(min(rank_rates), 1), "value_max": round(max(rank_rates), 1),
                          "elapsed_ms": [round(float(x) * 1e3, 3) for x in rank_table[:, -1].tolist()],
                          "elapsed_incl_closing_barrier_ms": [round(float(x) * 1e3, 3) for x in rank_table[:, 3].tolist()],
-                         "timed": "per rank: common start (barrier + synchronise) -> its own synchronise after the K steps; value = all ranks' agent-steps / the MAXIMUM of these",
+                         "start_skew_us": [round(float(x - starts_ns[0]) * 1e-3, 1) for x in starts_ns.tolist()],
+                         "end_skew_us": [round(float(x - ends_ns[0]) * 1e-3, 1) for x in ends_ns.tolist()],
+                         "timed": "per rank: its exit from the opening barrier + synchronise -> its own synchronise after the K steps; start_skew_us / end_skew_us = "
+                                  "that rank's start / end against rank 0's on the node's shared clock",
                          "agent_steps": [int(x) for x in rank_table[:, 0].tolist()], "world_base": [int(x) for x in rank_table[:, 2].tolist()],
                          "device": device if not args.share_gpu else "cuda:0 shared by every rank (dry run)",
-                         "final_barrier_wait_s": barrier_waits},
+                         "final_barrier_wait_s": barrier_waits, "cpu_baseline_wait_s": cpu_wait},
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
@@ -760,7 +797,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32-grade policy via block-scaled 2 x f16 split on v_mfma_f32_32x32x16_f16 (f32 accumulate) / int32+u8 world state / f64 rewards",
             "data": "synthetic",
-            "config": {"workload": wl["name"], "worlds_per_gpu": args.worlds, "worlds_total": args.worlds * max(1, world_size),
+            "config": {"workload": workload_name(args.workload, args.worlds), "worlds_per_gpu": args.worlds, "worlds_total": args.worlds * max(1, world_size),
                        "stream_groups": args.groups, "loop": "one multi-tick launch (rl_run)" if fused else "two launches per tick (rl_policy_act + rl_tick_refill)", "grid": "30x30", "max_agents": 100, "brains": wl["brains"], "static_families": wl["static_families"],
                        "refill_below": 70, "includes_update_env": True, "burn_in_ticks": args.burnin,
                        "mean_agents_per_world": round(total_agent_steps / (args.steps * args.worlds * max(1, world_size)), 2),

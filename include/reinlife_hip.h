@@ -207,8 +207,11 @@ int rl_tick_refill(rl_world* h, const int8_t* actions, const rl_step_out* sout, 
  *               obs[(first_obs + n_ticks) & 1] and the rows the policy read for the last tick in the other buffer
  *   update_src  [R][cap] or NULL: rl_update_out.src of the last tick
  *   threshold   < 0: no re-generation; else worlds below `threshold` agents are re-generated with n_agents (rl_refill)
- * Supported (rl_run_supported() != 0): n_brains <= 8 and slot_cap <= the workgroup size (512 threads; 256 when n_worlds > 768);
- * brains of any kinds with 512-thread workgroups, with 256 / 1024 threads only all of the dueling kinds (RL_D3QN / RL_PERD3QN).
+ * Supported (rl_run_supported() != 0) in THIS library (libreinlife_hip.so): n_brains <= 8, slot_cap <= 512 (the workgroup: 512 threads,
+ * one world per workgroup), brains of any kinds, and n_worlds <= 768 -- or any n_worlds with the "run_always" option set (several
+ * workgroups per CU then take turns; the two-launch loop is faster there, which is why it is not the default).
+ * Not in this library: the 256- and 1024-thread instantiations ("world_block" = 256 / 1024, dueling kinds only) exist in the tuning
+ * build alone (libreinlife_hip_tune.so, RL_TUNE=1 python reinlife_amd/build.py); here they answer 0 / RL_E_UNSUPPORTED.
  * Otherwise RL_E_UNSUPPORTED: loop over rl_policy_act + rl_tick_refill. */
 /* rl_run_ex: rl_run with the options a TRAINING loop needs (Helpers/trainer.py:85-99 with training=True):
  *   eps_schedule  device [n_ticks][n_brains] or NULL: the brains' exploration rate in every tick of the launch -- the reference's brains

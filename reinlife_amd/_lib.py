@@ -117,8 +117,10 @@ def lib():
         path = os.environ.get("REINLIFE_HIP_LIB")
         if not path:
             path = _build.LIB_PATH
-            try:
-                _build.build(force=bool(os.environ.get("REINLIFE_REBUILD")))   # (a few file digests when everything is current)
+            try:   # current by its stamps: a few file digests, no lock, no compiler needed; otherwise build() (serialised by an flock,
+                #    files moved into place atomically: N ranks finding it stale together compile once and never map a half-written file)
+                if os.environ.get("REINLIFE_REBUILD") or not _build.library_is_current():
+                    _build.build(force=bool(os.environ.get("REINLIFE_REBUILD")))
             except Exception as e:  # noqa: BLE001
                 raise ReinLifeHipError("libreinlife_hip.so is missing or older than its sources and could not be built with hipcc: %s" % e)
         handle = C.CDLL(path)

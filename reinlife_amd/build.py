@@ -77,11 +77,38 @@ def library_is_current():
     return _stamp_ok(LIB_PATH, _digest([], " ".join(digests)))
 
 
+class _BuildLock:
+    """One builder at a time per library directory (an flock on lib/.build.lock): N ranks that find the library stale at the same moment
+    (torchrun, `bench.py --gpus N` on a tree whose sources were just edited) take turns -- the first one compiles, the others find the
+    stamps current when they get the lock and do nothing.  The lock is advisory and dies with its process."""
+
+    def __enter__(self):
+        import fcntl
+        os.makedirs(LIB_DIR, exist_ok=True)
+        self.fh = open(os.path.join(LIB_DIR, ".build.lock"), "a+")
+        fcntl.flock(self.fh, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.fh, fcntl.LOCK_UN)
+        self.fh.close()
+        return False
+
+
 def build(force=False, verbose=False):
+    """Compile what is stale and link LIB_PATH.  Safe to call from several processes at once: the whole of it runs under _BuildLock, and every
+    object and the library itself are written under a temporary name and moved into place with os.replace() -- a process that dlopens
+    LIB_PATH while another one rebuilds it maps either the old file or the new one, never a half-written one."""
+    with _BuildLock():
+        return _build_locked(force, verbose)
+
+
+def _build_locked(force, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(LIB_DIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     flags = variant_flags()
+    tmp_tag = ".tmp%d" % os.getpid()
     objs, digests, jobs = [], [], []
     for src in SOURCES:   # the translation units compile side by side (rl_world.hip alone takes over half a minute)
         sp = os.path.join(CSRC, src)
@@ -90,29 +117,38 @@ def build(force=False, verbose=False):
             want = _digest([sp] + hdrs, " ".join(flags + extra))   # (every unit includes every header)
             objs.append(obj); digests.append(want)
             if force or not _stamp_ok(obj, want):
-                cmd = [hipcc] + flags + extra + ["-c", sp, "-o", obj]
+                cmd = [hipcc] + flags + extra + ["-c", sp, "-o", obj + tmp_tag]
                 if verbose:
                     print(" ".join(cmd))
-                if os.path.exists(obj + ".srchash"):
-                    os.remove(obj + ".srchash")
                 jobs.append((cmd, subprocess.Popen(cmd), obj, want))
     failed = None
     for cmd, job, obj, want in jobs:   # wait for EVERY compiler before reporting the first failure (no orphaned hipcc behind an exception)
         if job.wait() != 0:
             failed = failed or subprocess.CalledProcessError(job.returncode, cmd)
+            if os.path.exists(obj + tmp_tag):
+                os.remove(obj + tmp_tag)
         else:
+            if os.path.exists(obj + ".srchash"):
+                os.remove(obj + ".srchash")
+            os.replace(obj + tmp_tag, obj)
             _write_stamp(obj, want)
     if failed is not None:
         raise failed
     lib_want = _digest([], " ".join(digests))
     if force or jobs or not _stamp_ok(LIB_PATH, lib_want):
         vs = os.path.join(CSRC, "exports.map")   # global: rl_*; everything else (libstdc++ template instances, toolchain markers) local
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + vs, "-o", LIB_PATH] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + vs, "-o", LIB_PATH + tmp_tag] + objs
         if verbose:
             print(" ".join(cmd))
+        try:
+            subprocess.check_call(cmd)
+        except BaseException:
+            if os.path.exists(LIB_PATH + tmp_tag):
+                os.remove(LIB_PATH + tmp_tag)
+            raise
         if os.path.exists(LIB_PATH + ".srchash"):
             os.remove(LIB_PATH + ".srchash")
-        subprocess.check_call(cmd)
+        os.replace(LIB_PATH + tmp_tag, LIB_PATH)
         _write_stamp(LIB_PATH, lib_want)
     return LIB_PATH
 

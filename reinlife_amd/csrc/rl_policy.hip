@@ -6,10 +6,9 @@
 //   PERD3QN  DuelingDDQN.forward     PERD3QN.py:198-202  (same network)
 //   PPO      PPO.pi                  PPO.py:101-106      153 -> 256 -> 256 -> 8 -> softmax
 //   action selection                 DQN.py:132-139, D3QN.py:167-173, PERD3QN.py:204-210, PPO.py:164-169
-// The reference runs one batch-1 forward per agent; here a 4-wave workgroup owns 32 agents (observation rows):
-// every wave computes a quarter of each layer's output features for those 32 rows ("N-split": 4x shorter dependency
-// chain per tile and 4x more waves than one-wave-per-tile, which is what matters at 256 worlds = ~700 tiles on
-// 1024 SIMDs), activations cross waves through LDS once per layer:
+// The reference runs one batch-1 forward per agent; here 32 agents of one brain form a tile computed by TWO waves on one SIMD (the tiles of
+// the multi-tick kernel's policy half, rl_policy_dev.h): k_policy_pair = four tiles of one brain per 512-thread workgroup, k_policy_dense
+// from 1,536 dueling tiles on; k_policy_wave (policy_variant "wave") = one wave per tile.  One arithmetic in all of them:
 //
 //   * f32-grade results from the f16 matrix pipe ("2 x f16, block-scaled"): every operand row is scaled by a power of two,
 //     split into two f16 parts x = hi + lo, and a product is hi.hi + hi.lo + lo.hi -- three v_mfma_f32_32x32x16_f16 per 16 k

@@ -6,10 +6,12 @@
 //   PERD3QN  DuelingDDQN.forward     PERD3QN.py:198-202  (same network)
 //   PPO      PPO.pi                  PPO.py:101-106      153 -> 256 -> 256 -> 8 -> softmax
 //   action selection                 DQN.py:132-139, D3QN.py:167-173, PERD3QN.py:204-210, PPO.py:164-169
-// The reference runs one batch-1 forward per agent; here a 4-wave workgroup owns 32 agents (observation rows):
-// every wave computes a quarter of each layer's output features for those 32 rows ("N-split": 4x shorter dependency
-// chain per tile and 4x more waves than one-wave-per-tile, which is what matters at 256 worlds = ~700 tiles on
-// 1024 SIMDs), activations cross waves through LDS once per layer:
+// The reference runs one batch-1 forward per agent; here 32 agents (observation rows) of one brain form a TILE, and a tile is computed by
+// TWO waves that share a SIMD (policy_tile1s<PAIR> for the dueling kinds, policy_pair2 for DQN / PPO: each role owns half of every layer's
+// output features, the halves meet through LDS twice per tile) -- inside the multi-tick kernel (k_run's policy half: up to four tiles of a
+// world on its workgroup's eight waves) and in the stand-alone launches (k_policy_pair: four tiles of one brain per 512-thread workgroup;
+// k_policy_dense from 1,536 dueling tiles on).  One arithmetic everywhere.  (The 4-wave "N-split" tile of rounds 1-2,
+// every wave a quarter of each layer, was deleted in round 5.)
 //
 //   * f32-grade results from the f16 matrix pipe ("2 x f16, block-scaled"): every f32 operand row is scaled by a power
 //     of two so that its largest element lands in [2^10, 2^11) -- per observation / activation ROW (the B operand's

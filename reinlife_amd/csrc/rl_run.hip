@@ -1,11 +1,18 @@
 // rl_run.hip -- the multi-tick kernel of the ReinLife hot path on MI355X (gfx950): k_run and its host launcher.
+#include <mutex>
 #include "rl_world_dev.h"
 // What the input layer may assume about the Agent.state rows (XM of the tiles, rl_policy_dev.h in_chunk_class): measured per kernel family
 // (tools/xf_ab.sh).  The dueling-only kernel is SLOWER with it (21.8 -> 22.3 - 22.5 us per tick at configs[3]: its tiles are
 // bound by dependent latency, not by the matrix pipe, and fewer MFMAs leave the splits and the weight fetches nothing to hide behind), the
 // mixed-kind kernel faster (configs[4]: 26.7 -> 25.7 us): there a PPO tile shares its SIMD with a lighter one and every MFMA not issued is room.
+// RL_XM_DUELING_KERNEL != 0 is an A/B switch only (tools/xf_ab.sh): run_policy1 hands it to the tile WITHOUT the per-world oflags gate
+// of run_policy_all, i.e. it assumes row scale 2^10 and zero lo halves unconditionally -- true for states the world's own rules produce,
+// WRONG for a caller-loaded state with |health| >= 400.  Such a build must say that it knows.
 #ifndef RL_XM_DUELING_KERNEL
 #define RL_XM_DUELING_KERNEL 0
+#endif
+#if RL_XM_DUELING_KERNEL != 0 && !defined(RL_XM_SELF_GENERATED_STATES_ONLY)
+#error "RL_XM_DUELING_KERNEL != 0 is valid for self-generated states only: add -DRL_XM_SELF_GENERATED_STATES_ONLY to an A/B build that knows"
 #endif
 #ifndef RL_XM_ALL_DUELING_TILE   /* the dueling tile INSIDE the mixed-kind kernel (A/B: RL_XM_ALL_KERNEL, or 0 = one copy of it) */
 #define RL_XM_ALL_DUELING_TILE RL_XM_ALL_KERNEL
@@ -34,7 +41,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 // k_run: n_ticks iterations of the inference loop (Helpers/trainer.py:85-99 minus learn) in ONE launch.
 //
-//   for every tick:  Agent.get_action for the world's agents (policy_tile, rl_policy_dev.h)  ->  Environment.step  ->
+//   for every tick:  Agent.get_action for the world's agents (policy_tile1s<PAIR> / policy_pair2, rl_policy_dev.h)  ->  Environment.step  ->
 //                    update_env  ->  optional re-generation below the refill threshold
 //
 // A world never leaves its workgroup: the state is loaded once, every tick runs out of LDS (the same phase functions as
@@ -43,8 +50,9 @@ namespace {
 // (state_prime / state rows, reward, done, both permutations, actions), so a tick moves the same algorithmic bytes as
 // rl_policy_act + rl_tick_refill; what disappears is two launches, the world's load / store, the row lists, and the trip of
 // the observation rows through the fabric to another CU (the policy reads its own world's rows back from L2, sc1).
-// The policy tiles run on the waves of the world's workgroup -- one, two or four waves per 32-row tile (run_policy1) -- and every wave
-// executes the same number of workgroup barriers.
+// The policy tiles run on the waves of the world's workgroup -- two waves per 32-row tile in the product's 512-thread kernels (run_policy1 /
+// run_policy_all; one or four in the tuning-only 256- / 1024-thread instantiations) -- and every wave executes the same number of
+// workgroup barriers.
 // ---------------------------------------------------------------------------------------------------------------
 #include "rl_policy_dev.h"
 
@@ -82,8 +90,10 @@ struct PolSmem {
     int* tstart;        // [64] first tile of brain b
     short* trow;        // [kMaxTiles][32] list index of tile row j (0x8000: padding -- reads list entry 0, not valid)
     int* tbrain;        // [kMaxTiles] brain of tile t
-    int* meta;          // [8]  [0] number of tiles; loop state of k_run: [1] list length, [2] Agent.state parity, [3] ticks done,
-                        //      [4] the LDS mirror holds the current Agent.state rows
+    int* meta;          // [16] [0] number of tiles; loop state of k_run: [1] list length, [2] Agent.state parity, [3] ticks done,
+                        //      [4] the LDS mirror holds the current Agent.state rows, [5] / [6] the schedule of kKindAll (below),
+                        //      [8] / [9] the world's tick and epoch for the NEXT policy half's Philox keys (RL_SEAM_OPEN: the tiles start
+                        //      while recycle_world may still be writing s.scal[])
     float* pairv;       // [4 tiles][32 row values | 2 x 64 partial row maxima] of the two-waves-per-tile policy (T = 512), or null
     float* cconst;      // [n_brains][3][256] epilogue constants of the brains' three 128-wide layers for policy_tile1s (T = 512), or null
     float* xmirror;     // [xrows][kXStride] Agent.state rows of this world for the one-wave policy tile (T <= 512), or null
@@ -132,7 +142,7 @@ __host__ __device__ inline size_t carve_policy(PolSmem& ps, char* base, size_t o
     ps.tstart = (int*)(base + o); o = align16(o + sizeof(int) * 64);
     ps.trow = (short*)(base + o); o = align16(o + sizeof(short) * kMaxTiles * 32);
     ps.tbrain = (int*)(base + o); o = align16(o + sizeof(int) * kMaxTiles);
-    ps.meta = (int*)(base + o); o = align16(o + sizeof(int) * 8);
+    ps.meta = (int*)(base + o); o = align16(o + sizeof(int) * 16);
     ps.cconst = nullptr;
     if (n_cbrains > 0) { ps.cconst = (float*)(base + o); o = align16(o + sizeof(float) * run_const_floats<KIND>() * (size_t)n_cbrains); }
     ps.pairv = nullptr;
@@ -179,9 +189,18 @@ __device__ inline RecycleRegs recycle_read(Smem& s, int n)
     r.f = s.fitness[a];
     return r;
 }
+// RL_SEAM_OPEN (round 6): between two ticks of ONE launch the closing barrier is left out (`open`): nothing the policy half touches is
+// written in here any more -- its Philox keys come from meta[8] / [9] (written before the first barrier), its action bytes land in
+// s.action[] slots whose carried-over value nobody reads before they are overwritten (so the carry-over itself is left to the launch's
+// last tick, where the barrier stays because store_world follows) -- and every wave passes the policy half's own barriers before
+// Environment.step reads what is written here.  Kept closed when rows have to be drained to L2 first (tiles reading them from memory).
+#ifndef RL_SEAM_OPEN
+#define RL_SEAM_OPEN 1
+#endif
 template <int T, bool SPEC>
 __device__ __forceinline__ void recycle_world(const KParams& p, Smem& s, int n, int tick, int epoch, int next_uid, int max_gene, bool drain_stores, const RecycleRegs& rr,
-                                              const int* also_drain = nullptr)   // optional LDS flag, valid after the first barrier in here
+                                              const int* also_drain = nullptr,   // optional LDS flag, valid after the first barrier in here
+                                              bool open = false)                 // uniform: a policy half of the same launch follows
 {
     const int tid = rl_tidx();
     const bool mine = tid < n;
@@ -193,7 +212,8 @@ __device__ __forceinline__ void recycle_world(const KParams& p, Smem& s, int n, 
     lds_barrier();   // every field is in registers; the planes were last read before the barrier that precedes this call
     if (mine) {
         s.pos[tid] = r_pos; s.health[tid] = r_h; s.age[tid] = r_age; s.max_age[tid] = r_ma; s.gene[tid] = r_g; s.brain[tid] = r_b;
-        s.uid[tid] = r_u; s.flags[tid] = r_fl; s.action[tid] = r_act; s.fitness[tid] = r_f;
+        s.uid[tid] = r_u; s.flags[tid] = r_fl; s.fitness[tid] = r_f;
+        if (!open) s.action[tid] = r_act;   // (open: the tiles of the next policy half write s.action[k] for every k < n, possibly before this line runs)
         s.aux[tid] = 0; s.src[tid] = (short)tid; s.order[tid] = (short)tid; s.newidx[tid] = (short)tid;
         // the occupancy grid names the agents by slot: every live agent renames its own cell.  No other cell holds a slot: a cell an
         // agent leaves, a corpse's cell and the target of an erased mover are set to -1 where that happens (phase_step, reproduce_wave0),
@@ -207,8 +227,9 @@ __device__ __forceinline__ void recycle_world(const KParams& p, Smem& s, int n, 
     if (SPEC) for (int i = tid; i < 2 * p.cap; i += T) ((unsigned*)s.reward)[i] = 0u;
     if (tid < S_COUNT)
         s.scal[tid] = tid == S_NSLOTS ? n : tid == S_TICK ? tick : tid == S_EPOCH ? epoch : tid == S_NEXT_UID ? next_uid : tid == S_MAX_GENE ? max_gene : 0;
-    if (drain_stores || (also_drain && *also_drain)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tick's observation rows are in L2 before any wave reads them back
-    lds_barrier();
+    const bool drain = drain_stores || (also_drain && __builtin_amdgcn_readfirstlane(*also_drain) != 0);   // (uniform)
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tick's observation rows are in L2 before any wave reads them back
+    if (!open || drain) lds_barrier();
 }
 
 // The kernel's only parameter.  The two halves of a tick are real (noinline) function calls, each with a register allocation
@@ -397,7 +418,7 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
         io.out = TRAIN == 2 ? *(float* const __attribute__((address_space(4)))*)&ka->ra.policy_out : nullptr;
         io.actions = *(int8_t* const __attribute__((address_space(4)))*)&ka->ra.actions;
         io.seed = p.seed;
-        io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
+        io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)(RL_SEAM_OPEN ? ps.meta[8] : s.scal[S_TICK]); io.key_epoch = (uint32_t)(RL_SEAM_OPEN ? ps.meta[9] : s.scal[S_EPOCH]);
         io.key_index = (uint32_t)k;
         io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
         io.x_lds_off = (mirrored && k < ps.xrows) ? (int)((char*)(ps.xmirror + k * kXStride) - smem_base) : -1;
@@ -501,7 +522,7 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
         io.out = TRAIN == 2 ? *(float* const __attribute__((address_space(4)))*)&ka->ra.policy_out : nullptr;
         io.actions = *(int8_t* const __attribute__((address_space(4)))*)&ka->ra.actions;
         io.seed = p.seed;
-        io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
+        io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)(RL_SEAM_OPEN ? ps.meta[8] : s.scal[S_TICK]); io.key_epoch = (uint32_t)(RL_SEAM_OPEN ? ps.meta[9] : s.scal[S_EPOCH]);
         io.key_index = (uint32_t)k;
         io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
         io.x_lds_off = (from_mirror && mirrored && k < ps.xrows) ? (int)((char*)(ps.xmirror + k * kXStride) - smem_base) : -1;
@@ -869,11 +890,13 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
         }
     }
     RL_MARK(68);
-    if (tid == 0) { ps.meta[1] = n2; ps.meta[2] = cur ^ 1; ps.meta[3] = ticks_done + 1; ps.meta[4] = ps.xmirror != nullptr; }
+    if (tid == 0) { ps.meta[1] = n2; ps.meta[2] = cur ^ 1; ps.meta[3] = ticks_done + 1; ps.meta[4] = ps.xmirror != nullptr; ps.meta[8] = tick_next; ps.meta[9] = epoch_next; }
+    const bool seam_open = RL_SEAM_OPEN && T == 512 && ticks_done + 1 < *(const int __attribute__((address_space(4)))*)&ka->ra.n_ticks;   // (uniform; the launch's last tick: store_world follows)
     // (rows the policy will read back from memory must have reached L2 first; with every row mirrored in LDS the stores just drain)
     // (capture copies the rows the policy read back from memory a tick later: they must have arrived)
     recycle_world<T, kSpec>(p, s, n2, tick_next, epoch_next, next_uid, max_gene, ps.xmirror == nullptr || n2 > ps.xrows || (TRAIN == 2 && cap), rr,
-                            (KIND == kKindAll || T == 1024) ? &ps.meta[5] : nullptr);   // (tiles that take several rounds read their rows from memory)
+                            (KIND == kKindAll || T == 1024) ? &ps.meta[5] : nullptr,   // (tiles that take several rounds read their rows from memory)
+                            seam_open);
     RL_MARK(69);
 }
 
@@ -970,6 +993,7 @@ __device__ __forceinline__ void run_load_call(RunParamsC* ka)   // (inlined: loa
     }
     if (tid == 0) {
         ps.meta[1] = n0; ps.meta[2] = first; ps.meta[3] = 0; ps.meta[4] = preload ? 1 : 0;
+        ps.meta[8] = ((cint*)ka->p.st.tick)[blockIdx.x]; ps.meta[9] = ((cint*)ka->p.st.epoch)[blockIdx.x];   // (what load_world puts into s.scal[S_TICK] / [S_EPOCH])
         if constexpr (KIND == kKindAll) ps.oflags[0] = run_obs_flags(p, s, n0, ps.oflags[1]);
     }
     if (TRAIN && p.so.trk_tick) {   // the Tracker's running sums live in LDS for the length of the launch
@@ -1128,7 +1152,15 @@ static int run_block(const rl_world* h)
 {
     const int forced = h->opt.world_block;
     if (forced == 256 || forced == 512 || forced == 1024) return forced;
-    return h->cfg.n_worlds <= 768 ? 512 : 256;
+    if (h->cfg.n_worlds <= 768) return 512;
+#ifdef RL_RUN_256
+    return 256;
+#else
+    // the product library holds no k_run<256> (slower than the two-launch loop wherever it would be chosen): beyond 768 worlds the answer is
+    // "not supported" -- callers loop over rl_policy_act + rl_tick_refill -- unless the run_always option asks for the single launch, which
+    // then runs the 512-thread kernel with several workgroups per CU taking turns (8.9e8 against 9.7e8 agent-steps/s at 1,024 worlds)
+    return h->opt.run_always ? 512 : 256;
+#endif
 }
 int rl_world_run_supported(const rl_world* h, const rl_brain* brains, int n_brains)
 {
@@ -1223,8 +1255,11 @@ int rl_world_launch_run(rl_world* h, const rl_brain* brains, int n_brains, int n
     if (!fn) { rl_set_error("rl_run: no kernel instantiation for T=%d fixed=%d kind=%d train=%d in this build", T, (int)fixed, kind, train); return RL_E_UNSUPPORTED; }
     if (bytes > 64 * 1024) {   // opt in to the large dynamic-LDS window: once per (kernel, device, size) -- the attribute belongs to the device's copy of the kernel
         // (a process may alternate several instantiations -- bench.py's TRAIN 0 line and trainer()'s TRAIN 1: each keeps its grant)
+        // (process-wide table behind a mutex: handles are independent of each other, include/reinlife_hip.h, and may launch from several threads)
         struct Grant { const void* fn; size_t bytes; };
         static Grant granted[64][8];
+        static std::mutex granted_mu;
+        const std::lock_guard<std::mutex> hold(granted_mu);
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
         Grant* g = nullptr;

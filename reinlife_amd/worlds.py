@@ -31,7 +31,13 @@ _NP = {torch.uint8: np.uint8, torch.int8: np.int8, torch.int16: np.int16, torch.
        torch.float64: np.float64}
 
 
-_raw_stream = torch._C._cuda_getCurrentRawStream
+def _public_raw_stream(device_index):
+    return torch.cuda.current_stream(device_index).cuda_stream
+
+
+# the current stream's handle for the C ABI, once per launch: torch's private accessor where this build has it (no Stream object per call,
+# ~1 us), the public torch.cuda.current_stream(...).cuda_stream otherwise (a CPU-only wheel, a renamed symbol) -- same handle either way
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or _public_raw_stream
 
 
 class _Snapshot:
@@ -52,6 +58,72 @@ class _Snapshot:
 
     def keys(self):
         return self._layout.keys()
+
+
+class TapeRing:
+    """The draws a host makes for a tick (Tape: food_k, food_u, repro_u, birth_k, produce_u, produce_choice), staged for the device.  The six
+    arrays of a tape are carved out of ONE pinned host buffer and ONE device buffer -- one host-to-device copy per tape (a host that draws
+    every tick uploads two tapes per tick) -- and there is a ring of SLOTS such pairs: every make() returns a FRESH Tape struct over the next
+    slot's device buffer, so a caller may prepare the step's and the update's tape before launching either (until round 6 every tape aliased
+    one device buffer and the second make() silently replaced the first one's draws).  A tape stays valid until the SLOTS-th make() after
+    it; its slot's buffers are then rewritten in stream order -- behind every launch queued so far -- and the pinned buffer only once its
+    last upload has executed.  With a CPU device (tests/test_host_api_cpu.py) the "upload" is a plain copy and nothing is pinned."""
+    SLOTS = 4
+
+    def __init__(self, n_worlds, cap, device, cur_stream=None):
+        self.R, self.cap, self.device = n_worlds, cap, torch.device(device)
+        self._cur_stream = cur_stream
+        R = n_worlds
+        spec = [("food_k", np.int32, (R, _lib.FOOD_TRIES)), ("food_u", np.float64, (R, _lib.FOOD_TRIES)), ("repro_u", np.float64, (R, cap)),
+                ("birth_k", np.int32, (R, cap + 1)), ("produce_u", np.float64, (R,)), ("produce_choice", np.int32, (R,))]
+        lay, off = {}, 0
+        for name, dt, shape in spec:
+            nb = int(np.prod(shape)) * np.dtype(dt).itemsize
+            lay[name] = (off, nb, dt, shape)
+            off += (nb + 255) // 256 * 256
+        self.layout, self.nbytes = lay, off
+        on_gpu = self.device.type == "cuda"
+        self.slots = []
+        for _ in range(self.SLOTS):
+            host = torch.zeros(off, dtype=torch.uint8)
+            if on_gpu:
+                host = host.pin_memory()
+            buf = host.numpy()
+            dev = torch.zeros(off, dtype=torch.uint8, device=self.device)
+            self.slots.append({"host": host, "dev": dev, "event": None,
+                               "views": {n: buf[o:o + nb].view(dt).reshape(shape) for n, (o, nb, dt, shape) in lay.items()}})
+        self.made = 0
+
+    def make(self, tapes):
+        R, cap = self.R, self.cap
+        slot = self.slots[self.made % self.SLOTS]
+        self.made += 1
+        if slot["event"] is not None:
+            slot["event"].synchronize()
+        host = slot["views"]
+        for w, t in enumerate(tapes):
+            host["food_k"][w] = t["food_k"]
+            host["food_u"][w] = t["food_u"]
+            m = min(cap, len(t["repro_u"]))
+            host["repro_u"][w, :m] = t["repro_u"][:m]
+            host["repro_u"][w, m:] = 0
+            m = min(cap + 1, len(t["birth_k"]))
+            host["birth_k"][w, :m] = t["birth_k"][:m]
+            host["birth_k"][w, m:] = 0
+            host["produce_u"][w] = t["produce_u"]
+            host["produce_choice"][w] = t["produce_choice"]
+        if len(tapes) < R:   # (worlds beyond the list: zeros)
+            for name in _lib.TAPE_FIELDS:
+                host[name][len(tapes):] = 0
+        slot["dev"].copy_(slot["host"], non_blocking=True)
+        if self.device.type == "cuda":
+            if slot["event"] is None:
+                slot["event"] = torch.cuda.Event()
+            slot["event"].record(self._cur_stream() if self._cur_stream else torch.cuda.current_stream(self.device))
+        base = slot["dev"].data_ptr()
+        tape = _lib.Tape(*[C.c_void_p(base + self.layout[n][0]) for n in _lib.TAPE_FIELDS])
+        tape._keep = slot["dev"]   # (the struct keeps its buffer alive)
+        return tape
 
 
 def _ptr(t):
@@ -253,53 +325,11 @@ class DeviceWorlds:
         return d
 
     def make_tape(self, tapes):
-        """tapes: one dict per world (food_k, food_u, repro_u, birth_k, produce_u, produce_choice) -> device Tape.  The six arrays are
-        carved out of one pinned host buffer and one device buffer: ONE host-to-device copy per tape (a host that draws every tick
-        uploads two tapes per tick).  The device buffer is rewritten in stream order (behind the launch that read the previous tape);
-        the pinned buffers form a ring of four, each reused only once its last upload has executed."""
-        R, cap = self.R, self.cap
+        """tapes: one dict per world (food_k, food_u, repro_u, birth_k, produce_u, produce_choice) -> device Tape (TapeRing.make): a FRESH
+        struct over its own device buffer per call, valid until the fourth make_tape() after it."""
         if getattr(self, "_tape_ring", None) is None:
-            spec = [("food_k", np.int32, (R, _lib.FOOD_TRIES)), ("food_u", np.float64, (R, _lib.FOOD_TRIES)), ("repro_u", np.float64, (R, cap)),
-                    ("birth_k", np.int32, (R, cap + 1)), ("produce_u", np.float64, (R,)), ("produce_choice", np.int32, (R,))]
-            lay, off = {}, 0
-            for name, dt, shape in spec:
-                nb = int(np.prod(shape)) * np.dtype(dt).itemsize
-                lay[name] = (off, nb, dt, shape)
-                off += (nb + 255) // 256 * 256
-            self._tape_layout, self._tape_bytes = lay, off
-            self._tape_dev = torch.zeros(off, dtype=torch.uint8, device=self.device)
-            self._tape_ring = []
-            for _ in range(4):
-                pin = torch.zeros(off, dtype=torch.uint8).pin_memory()
-                buf = pin.numpy()
-                self._tape_ring.append([pin, None, {n: buf[o:o + nb].view(dt).reshape(shape) for n, (o, nb, dt, shape) in lay.items()}])
-            self._tape_next = 0
-            base = self._tape_dev.data_ptr()
-            self._tape_struct = _lib.Tape(*[C.c_void_p(base + lay[n][0]) for n in _lib.TAPE_FIELDS])
-        slot = self._tape_ring[self._tape_next % 4]
-        self._tape_next += 1
-        if slot[1] is not None:
-            slot[1].synchronize()
-        host = slot[2]
-        for w, t in enumerate(tapes):
-            host["food_k"][w] = t["food_k"]
-            host["food_u"][w] = t["food_u"]
-            m = min(cap, len(t["repro_u"]))
-            host["repro_u"][w, :m] = t["repro_u"][:m]
-            host["repro_u"][w, m:] = 0
-            m = min(cap + 1, len(t["birth_k"]))
-            host["birth_k"][w, :m] = t["birth_k"][:m]
-            host["birth_k"][w, m:] = 0
-            host["produce_u"][w] = t["produce_u"]
-            host["produce_choice"][w] = t["produce_choice"]
-        for name in ("food_k", "food_u", "repro_u", "birth_k", "produce_u", "produce_choice"):   # (worlds beyond the list: zeros, as before)
-            if len(tapes) < R:
-                host[name][len(tapes):] = 0
-        self._tape_dev.copy_(slot[0], non_blocking=True)
-        if slot[1] is None:
-            slot[1] = torch.cuda.Event()
-        slot[1].record(self._cur_stream())
-        return self._tape_struct
+            self._tape_ring = TapeRing(self.R, self.cap, self.device, self._cur_stream)
+        return self._tape_ring.make(tapes)
 
     # -- the path -----------------------------------------------------------------------------------------------
     @property

@@ -225,3 +225,45 @@ def test_options_are_process_level_snapshotted_by_handles_and_never_read_from_th
     src = os.path.join(ROOT, "reinlife_amd", "csrc")
     users = [f for f in sorted(os.listdir(src)) if "getenv(" in open(os.path.join(src, f)).read()]
     assert users == ["rl_capi.hip"], users   # the one place that reads the environment: options_from_env
+
+
+def test_the_header_says_what_the_product_library_runs_and_the_library_agrees():
+    """include/reinlife_hip.h's "Supported" paragraph of rl_run against rl_run_supported() of the PRODUCT library (the
+    header named 256- / 1024-thread instantiations the product refuses): 512-thread workgroups up to 768 worlds, any world count with
+    run_always, the forced 256- / 1024-thread instantiations answered 0 with an error that names the tuning build -- and the library's
+    symbol table holds k_run<512, ...> and nothing else of that family (reference loop: Helpers/trainer.py:85-99)."""
+    import subprocess
+    from reinlife_amd import build
+    hdr = open(os.path.join(ROOT, "include", "reinlife_hip.h")).read()
+    para = hdr[hdr.index(" * Supported (rl_run_supported() != 0)"):]
+    para = para[:para.index("*/")]
+    assert "slot_cap <= 512" in para and "n_worlds <= 768" in para and '"run_always"' in para
+    assert "tuning" in para and "libreinlife_hip_tune.so" in para and "256- and 1024-thread" in para
+    lib = _lib.lib()
+    nm = subprocess.run(["nm", "-C", build.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    blocks = set(re.findall(r"k_run<(\d+),", nm))
+    assert blocks == {"512"}, blocks
+    brains = (_lib.Brain * 2)(_lib.Brain(_lib.PERD3QN, 0.0, None), _lib.Brain(_lib.PERD3QN, 0.0, None))
+    mixed = (_lib.Brain * 2)(_lib.Brain(_lib.PPO, 0.0, None), _lib.Brain(_lib.PERD3QN, 0.0, None))
+
+    def supported(n_worlds, which=brains, **opts):
+        for k, v in opts.items():
+            _lib.set_option(k, v)
+        try:
+            cfg = _lib.Config(30, 30, 100, 2, 256, n_worlds, 1, 0, 1, 0, 7)
+            h = C.c_void_p()
+            assert lib.rl_create(C.byref(cfg), C.byref(h)) == 0
+            r = lib.rl_run_supported(h, which, 2)
+            err = lib.rl_last_error().decode()
+            lib.rl_destroy(h)
+            return r, err
+        finally:
+            for k in opts:
+                _lib.set_option(k, None)
+    assert supported(256)[0] == 1 and supported(768)[0] == 1 and supported(256, mixed)[0] == 1
+    r, err = supported(1024)
+    assert r == 0 and "tuning-build" in err and "256-thread" in err
+    assert supported(1024, run_always=1)[0] == 1 and supported(4096, mixed, run_always=1)[0] == 1     # ... the 512-thread kernel, several workgroups per CU in turn
+    for block in (256, 1024):
+        r, err = supported(256, world_block=block)
+        assert r == 0 and "tuning-build" in err and ("%d-thread" % block) in err

@@ -16,9 +16,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ["--steps", "30", "--warmup", "5", "--burnin", "40", "--no-cpu-baseline"]
 
 
-def _bench(*args, timeout=900):
+def _bench(*args, timeout=900, drop=()):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RL_WORLD_BLOCK", "RL_WORLD_GENERIC", "RL_FORCE_DIST")}
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *COMMON, *args], env=env, capture_output=True, text=True, timeout=timeout)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *[a for a in COMMON if a not in drop], *args], env=env, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "expected ONE JSON line, got %d" % len(lines)
@@ -43,8 +43,15 @@ def test_two_rank_dry_run_of_the_multi_gpu_bench_path():
     assert two["rccl_collectives_executed"] == 1 and one["rccl_collectives_executed"] == 0      # the metric's reduction: ONE collective
     assert abs(two["value"] - two["config"]["agent_steps"] / (two["ms_per_step"] * 1e-3 * 30)) < 1e-3 * two["value"]
     assert max(pr["elapsed_ms"]) * 1e-3 <= two["ms_per_step"] * 1e-3 * 30 + 1e-6 and pr["value_min"] <= pr["value_max"]
-    # the job's time = the slowest rank's own K steps; the closing barrier's latency (milliseconds under gloo) is reported beside it
-    assert abs(max(pr["elapsed_ms"]) - two["ms_per_step"] * 30) < 1e-2 and all(b >= e for b, e in zip(pr["elapsed_incl_closing_barrier_ms"], pr["elapsed_ms"]))
+    # the job's time = latest rank's end - earliest rank's start on the node's shared clock (round 6): never shorter than any rank's own K
+    # steps, longer by the start skew; the bracket incl. the closing barrier (milliseconds under gloo) and the own-clock figure are beside it
+    assert all(b >= e for b, e in zip(pr["elapsed_incl_closing_barrier_ms"], pr["elapsed_ms"]))
+    assert pr["start_skew_us"][0] == 0.0 and pr["end_skew_us"][0] == 0.0 and len(pr["start_skew_us"]) == 2
+    job_ms = two["ms_per_step"] * 30
+    spread = max(e + s * 1e-3 for e, s in zip(pr["elapsed_ms"], pr["start_skew_us"])) - min(s * 1e-3 for s in pr["start_skew_us"])
+    assert abs(job_ms - spread) < 2e-2, (job_ms, spread)          # ... reproducible from the per-rank table
+    assert two["value_slowest_rank_own_clock"] >= two["value"] * (1 - 1e-9) and two["value_incl_closing_barrier"] <= two["value_slowest_rank_own_clock"]
+    assert abs(one["value_slowest_rank_own_clock"] - one["value"]) < 1e-6 * one["value"]      # one rank: one interval
     # nobody is left waiting behind a leg only rank 0 runs
     assert len(pr["final_barrier_wait_s"]) == 2 and max(pr["final_barrier_wait_s"]) < 5.0
     # the dominant kernel's roofline stays in a multi-rank line (rank 0's kernel)
@@ -64,6 +71,32 @@ def test_two_rank_dry_run_of_the_multi_gpu_bench_path():
     assert len(c2["per_rank"]["us_per_tick"]) == 2 and c2["us_per_tick"] == max(c2["per_rank"]["us_per_tick"])
     assert c2["value_min_rank"] <= c2["value_max_rank"] and c2["roofline"]["rank"] == 0 and 0 < c2["roofline"]["mfma_frac"] < 1
     assert abs(c2["value"] - c2["agent_steps"] / (c2["us_per_tick"] * 1e-6 * 1000)) < 2e-3 * c2["value"]
+
+
+def test_eight_rank_dry_run_with_the_cpu_baseline_in_a_multi_rank_line():
+    """What the driver's ONE 8-GPU run executes, rehearsed as eight gloo ranks on the one GPU of the box: rendezvous of
+    eight, eight concurrent imports of the (current) library, 8-row tables, world_base = rank x worlds, configs[4] on every rank, the
+    Tracker pooled over eight ranks, `cpu_baseline` on rank 0 AFTER every timed leg with the other ranks parked (north_star: the CPU path
+    beside the 1/2/4/8 figures, in the same run), nobody waiting long at the legs' barrier."""
+    line = _bench("--gpus", "8", "--dist-backend", "gloo", "--share-gpu", "--worlds", "32", "--no-single-world",
+                  drop=("--no-cpu-baseline",), timeout=1500)
+    assert line["n_gpus"] == 8 and line["ranks"] == 8 and line["dist_backend"] == "gloo" and line["rccl_ranks"] == 0
+    pr = line["per_rank"]
+    assert pr["world_base"] == [32 * r for r in range(8)] and line["config"]["worlds_total"] == 256
+    assert "32 worlds/GPU" in line["config"]["workload"] and "instead of 256" in line["config"]["workload"]
+    for key in ("agent_steps", "elapsed_ms", "elapsed_incl_closing_barrier_ms", "start_skew_us", "end_skew_us", "final_barrier_wait_s", "cpu_baseline_wait_s"):
+        assert len(pr[key]) == 8, key
+    assert sum(pr["agent_steps"]) == line["config"]["agent_steps"] > 30 * 256 * 60 and min(pr["agent_steps"]) > 30 * 32 * 60
+    assert line["rccl_collectives_executed"] == 1
+    # the legs' barrier: rank 0 carries the kernel probes (~1 s); nobody is parked for long.  The CPU baseline's barrier is the one that waits.
+    assert max(pr["final_barrier_wait_s"]) < 30.0
+    cpu = line["cpu_baseline"]
+    assert cpu is not None and cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["unit"] == "agent-steps/s"
+    assert max(pr["cpu_baseline_wait_s"][1:]) > 1.0 and pr["cpu_baseline_wait_s"][0] < max(pr["cpu_baseline_wait_s"][1:])
+    c5, api = line["c5"], line["api_trainer"]
+    assert c5["ranks"] == 8 and c5["per_rank"]["world_base"] == [32 * r for r in range(8)] and c5["worlds_total"] == 256
+    assert api["ranks"] == 8 and api["tracker_intervals_closed"] == 4 and api["tracker_rccl_collectives"] == 8
+    assert line["value"] <= line["value_slowest_rank_own_clock"] * (1 + 1e-9)
 
 
 def test_single_world_figures_of_the_default_line():

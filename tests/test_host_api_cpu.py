@@ -102,3 +102,38 @@ def test_packed_weights_cache_notices_every_way_the_weights_can_change(monkeypat
     b.packed_weights("cuda:0"); assert len(calls) == 6
     b.packed_weights("cuda:0"); assert len(calls) == 6
     b.packed_weights("cuda:1"); assert len(calls) == 7                               # another device: its own pack
+
+
+def test_two_tapes_prepared_before_either_is_used_hold_two_different_draws():
+    """DeviceWorlds.make_tape (worlds.TapeRing): every call returns a fresh struct over its own device buffer -- a caller that prepares the
+    step's and the update's tape before launching either keeps both (one aliased buffer silently replayed the second
+    tape on both).  Here on CPU tensors, the tapes read back through the struct's own pointers, as a kernel would."""
+    import ctypes as C
+    import numpy as np
+    from reinlife_amd import _lib
+    from reinlife_amd.worlds import TapeRing
+    R, cap = 3, 64
+    ring = TapeRing(R, cap, "cpu")
+    rng = np.random.RandomState(5)
+
+    def draws():
+        return [dict(food_k=rng.randint(0, 900, _lib.FOOD_TRIES), food_u=rng.rand(_lib.FOOD_TRIES), repro_u=rng.rand(cap), birth_k=rng.randint(0, 900, cap + 1),
+                     produce_u=rng.rand(), produce_choice=rng.randint(0, 10)) for _ in range(R)]
+
+    def read(tape, name, dt, shape):
+        n = int(np.prod(shape))
+        return np.ctypeslib.as_array(C.cast(getattr(tape, name), C.POINTER(np.ctypeslib.as_ctypes_type(dt))), (n,)).reshape(shape).copy()
+
+    made = [(draws(),) for _ in range(TapeRing.SLOTS)]
+    tapes = [ring.make(d[0]) for d in made]                       # every tape of the ring prepared before any is read
+    assert len({t.food_k for t in tapes}) == TapeRing.SLOTS and len({id(t) for t in tapes}) == TapeRing.SLOTS
+    for (d,), t in zip(made, tapes):
+        assert np.array_equal(read(t, "food_k", np.int32, (R, _lib.FOOD_TRIES)), np.stack([w["food_k"] for w in d]))
+        assert np.array_equal(read(t, "repro_u", np.float64, (R, cap)), np.stack([w["repro_u"] for w in d]))
+        assert np.array_equal(read(t, "birth_k", np.int32, (R, cap + 1)), np.stack([w["birth_k"] for w in d]))
+        assert np.array_equal(read(t, "produce_u", np.float64, (R,)), np.array([w["produce_u"] for w in d]))
+        assert np.array_equal(read(t, "produce_choice", np.int32, (R,)), np.array([w["produce_choice"] for w in d]))
+    # the ring wraps: the fifth tape lives where the first one did (documented lifetime), with its own draws; a short list leaves zeros behind
+    fifth = ring.make(draws()[:1])
+    assert fifth.food_k == tapes[0].food_k
+    assert not read(fifth, "food_u", np.float64, (R, _lib.FOOD_TRIES))[1:].any()
