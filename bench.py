@@ -400,9 +400,33 @@ def c5_leg(args, rank, device, dist=None):
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(steps * by / t_k / 1e9 / HBM_PEAK_GBS, 5), "bytes_per_agent_step": by,
                          "flop_per_agent": flop, "mfma_tflops": round(steps * flop / t_k / 1e12, 2),
                          "mfma_frac": round(steps * flop / t_k / 1e12 / MFMA_F32_EQUIV_PEAK_TFLOPS, 5),
-                         "how": "rank 0's launch: HIP events on the launch stream around ONE launch of %d ticks, queued behind %d untimed ticks" % (n, n)},
+                         "how": "rank 0's launch: HIP events on the launch stream around ONE launch of %d ticks, queued behind %d untimed ticks" % (n, n),
+                         **latency_bound("c5", args.worlds, t_k / n)},
             "timed": "wall clock around the launch + synchronize on every rank, released together by a barrier; value = all ranks' agent-steps / "
                      "the slowest rank's wall time; inputs resident in HBM"}
+
+
+def latency_bound(workload, worlds, tick_s):
+    """roofline.latency_bound_us / frac_of_latency_bound (tools/latency_bound.py): the part of a k_run tick that is matrix-pipe
+    issue of the slowest SIMD + the tick's barriers + the sections one wave executes alone -- what remains if every data-parallel section cost
+    nothing -- as a fraction of the tick (taken in a stamped build, profiles/latency_model.json, valid for the kernel sources it is stamped
+    with) times the tick measured HERE.  At one world per CU this, not the HBM or MFMA peak, is the floor the structure can approach."""
+    path = os.path.join(ROOT, "profiles", "latency_model.json")
+    out = {"latency_bound_us": None, "frac_of_latency_bound": None}
+    try:
+        m = json.load(open(path))
+        from reinlife_amd import build as _build
+        w = m["workloads"].get(workload)
+        if w and w.get("frac_of_latency_bound") and worlds <= 256 and m.get("kernel_src_sha16") == _build.source_hash():
+            out = {"latency_bound_us": round(w["frac_of_latency_bound"] * tick_s * 1e6, 2), "frac_of_latency_bound": w["frac_of_latency_bound"],
+                   "latency_model": {"file": "profiles/latency_model.json", "mfma_slowest_simd_counts": w["mfma_slowest_simd"]["counts"],
+                                     "barriers_counts": w["barriers"]["counts"], "one_wave_sections_counts": w["one_wave_sections_counts"],
+                                     "bound_counts": w["bound_counts"], "stamped_tick_counts": w["stamped_tick_counts"],
+                                     "how": "bound counts / the stamped build's tick counts x avg_tick_us; one world per CU: matrix-pipe issue of the slowest "
+                                            "SIMD + workgroup barriers + one-wave sections (DESIGN.md 6.2)"}}
+    except Exception:  # noqa: BLE001
+        pass
+    return out
 
 
 def tuning_halves(args):
@@ -641,6 +665,7 @@ def main():
                                                 "current_kernel_src_sha16": now}
             except Exception:  # noqa: BLE001
                 pass
+        fused_roof.update(latency_bound(args.workload, args.worlds, t_all))
         # the launch's two halves alone: measured by the TUNING library in a process of its own (tools/run_halves.py: the switch that
         # skips half of every tick -- results WRONG by design -- is not in the product library this process has loaded)
         halves = tuning_halves(args)

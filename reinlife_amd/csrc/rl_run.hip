@@ -92,8 +92,7 @@ struct PolSmem {
     int* tbrain;        // [kMaxTiles] brain of tile t
     int* meta;          // [16] [0] number of tiles; loop state of k_run: [1] list length, [2] Agent.state parity, [3] ticks done,
                         //      [4] the LDS mirror holds the current Agent.state rows, [5] / [6] the schedule of kKindAll (below),
-                        //      [8] / [9] the world's tick and epoch for the NEXT policy half's Philox keys (RL_SEAM_OPEN: the tiles start
-                        //      while recycle_world may still be writing s.scal[])
+                        //      [8..15] spare
     float* pairv;       // [4 tiles][32 row values | 2 x 64 partial row maxima] of the two-waves-per-tile policy (T = 512), or null
     float* cconst;      // [n_brains][3][256] epilogue constants of the brains' three 128-wide layers for policy_tile1s (T = 512), or null
     float* xmirror;     // [xrows][kXStride] Agent.state rows of this world for the one-wave policy tile (T <= 512), or null
@@ -190,7 +189,8 @@ __device__ inline RecycleRegs recycle_read(Smem& s, int n)
     return r;
 }
 // RL_SEAM_OPEN (round 6): between two ticks of ONE launch the closing barrier is left out (`open`): nothing the policy half touches is
-// written in here any more -- its Philox keys come from meta[8] / [9] (written before the first barrier), its action bytes land in
+// written in here any more -- its Philox keys (s.scal[S_TICK] / [S_EPOCH]) are stored before the first barrier by the caller and only
+// re-written with the same values here, its action bytes land in
 // s.action[] slots whose carried-over value nobody reads before they are overwritten (so the carry-over itself is left to the launch's
 // last tick, where the barrier stays because store_world follows) -- and every wave passes the policy half's own barriers before
 // Environment.step reads what is written here.  Kept closed when rows have to be drained to L2 first (tiles reading them from memory).
@@ -345,7 +345,7 @@ __device__ inline int run_obs_flags(const KParams& p, const Smem& s, int n, int 
     return RL_XF_SCALE | (s.type[0] == RL_AGENT ? 0 : RL_XF_INT_HEALTH);
 }
 
-__device__ inline void policy_schedule_wave0(const KParams& p, PolSmem& ps, RunParamsC* ka, int lane)
+__device__ inline void policy_schedule_wave0(const KParams& p, PolSmem& ps, RunParamsC* ka, int lane, bool first_call = false)
 {
     // Lane-parallel and in closed form (as serial single-lane code with a memory load per tile this cost 5.5k cycles on the wave that is
     // the longest of its interval): lane t < 4 owns tile t.  With at most four tiles the balanced deal has a fixed shape -- the heaviest
@@ -378,9 +378,12 @@ __device__ inline void policy_schedule_wave0(const KParams& p, PolSmem& ps, RunP
     }
     if (lane < 4) ps.texoff[lane] = off;
     if (lane < 8) ps.wtask[lane] = (pair_ok && tile >= 0) ? (tile | ((lane & 1) << 8) | (tb << 12) | (tk << 20)) : -1;
+    // (meta[6], the tiles per round when the tiles take several rounds, does not change during a launch: written once, by run_load_call
+    // -- written here it was a loop invariant of the tick loop, spilled, and reloaded every tick behind an s_waitcnt vmcnt(0) on the wave
+    // that is the long pole of its interval)
     if (lane == 0) {
         ps.meta[5] = pair_ok ? 0 : 1;
-        ps.meta[6] = fit < 1 ? 1 : (fit > 4 ? 4 : fit);   // tiles per round when the tiles take several rounds
+        if (first_call) ps.meta[6] = fit < 1 ? 1 : (fit > 4 ? 4 : fit);
     }
 }
 
@@ -418,7 +421,7 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
         io.out = TRAIN == 2 ? *(float* const __attribute__((address_space(4)))*)&ka->ra.policy_out : nullptr;
         io.actions = *(int8_t* const __attribute__((address_space(4)))*)&ka->ra.actions;
         io.seed = p.seed;
-        io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)(RL_SEAM_OPEN ? ps.meta[8] : s.scal[S_TICK]); io.key_epoch = (uint32_t)(RL_SEAM_OPEN ? ps.meta[9] : s.scal[S_EPOCH]);
+        io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
         io.key_index = (uint32_t)k;
         io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
         io.x_lds_off = (mirrored && k < ps.xrows) ? (int)((char*)(ps.xmirror + k * kXStride) - smem_base) : -1;
@@ -491,6 +494,32 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
 #endif
 }
 
+// RL_XM_COLD_CALL (round 6): the GENERAL copies of the tiles (nothing assumed about the rows: one tick in ten) as ONE
+// out-of-line function with a register allocation of its own, so that the kernel body's allocation is that of the hot copies alone -- what
+// the forced build `f3` had (5 spilled VGPRs against 12-14 with both copies inlined).
+#ifndef RL_XM_COLD_CALL
+#define RL_XM_COLD_CALL 0
+#endif
+// RL_XM_LIKELY: the branch between the two copies of a tile carries its frequency (nine ticks in ten take the copy that knows its rows), so
+// that the register allocator's spill weights and the block layout favour that copy (A/B: DESIGN.md 5.12)
+#ifndef RL_XM_LIKELY
+#define RL_XM_LIKELY 1
+#endif
+#if RL_XM_LIKELY
+#define RL_XM_EXPECT(x) __builtin_expect_with_probability(!!(x), 1, 0.9)
+#else
+#define RL_XM_EXPECT(x) (x)
+#endif
+__device__ __attribute__((noinline, cold)) Tile1Part run_tile_general(TileIO io, PairLds pl, int role, int kind)
+{
+    Tile1Part part;
+    const int lane = rl_lane_fresh();
+    if (kind == RL_DQN) policy_pair2<RL_DQN, RL_RUN_COHERENT>(io, lane, role, &pl, &part);
+    else if (kind == RL_PPO) policy_pair2<RL_PPO, RL_RUN_COHERENT>(io, lane, role, &pl, &part);
+    else policy_tile1s<RL_PERD3QN, RL_RUN_COHERENT, true>(io, lane, role, &pl, &part);
+    return part;
+}
+
 // The policy half of the kKindAll kernels (512-thread workgroups): per tile, the code of its brain's kind.
 template <int T, int TRAIN>
 __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSmem& ps, RunParamsC* ka, int w, int n, const float* obs_rows, char* smem_base, int wave)
@@ -522,7 +551,7 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
         io.out = TRAIN == 2 ? *(float* const __attribute__((address_space(4)))*)&ka->ra.policy_out : nullptr;
         io.actions = *(int8_t* const __attribute__((address_space(4)))*)&ka->ra.actions;
         io.seed = p.seed;
-        io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)(RL_SEAM_OPEN ? ps.meta[8] : s.scal[S_TICK]); io.key_epoch = (uint32_t)(RL_SEAM_OPEN ? ps.meta[9] : s.scal[S_EPOCH]);
+        io.key_world = (uint32_t)(p.world_base + w); io.key_tick = (uint32_t)s.scal[S_TICK]; io.key_epoch = (uint32_t)s.scal[S_EPOCH];
         io.key_index = (uint32_t)k;
         io.lds_actions_off = (int)((char*)s.action - smem_base); io.lds_slot = k;
         io.x_lds_off = (from_mirror && mirrored && k < ps.xrows) ? (int)((char*)(ps.xmirror + k * kXStride) - smem_base) : -1;
@@ -546,11 +575,12 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
             // plane chunks (oflags[0], run_obs_flags: ~9 in 10 ticks) -- or nothing is assumed.  Bit-identical either way.
             const bool plain = kind == RL_DQN || kind == RL_PPO;
             if (!plain && RL_XM_ALL_DUELING_TILE == 0) policy_tile1s<RL_PERD3QN, RL_RUN_COHERENT, true>(io, lane, role, &pl, &part);   // (ONE copy of this tile)
-            else if (rows_known) {
+            else if (RL_XM_EXPECT(rows_known)) {
                 if (kind == RL_DQN) policy_pair2<RL_DQN, RL_RUN_COHERENT, RL_XM_ALL_KERNEL>(io, lane, role, &pl, &part);
                 else if (kind == RL_PPO) policy_pair2<RL_PPO, RL_RUN_COHERENT, RL_XM_ALL_KERNEL>(io, lane, role, &pl, &part);
                 else policy_tile1s<RL_PERD3QN, RL_RUN_COHERENT, true, RL_XM_ALL_DUELING_TILE>(io, lane, role, &pl, &part);
-            } else {
+            } else if (RL_XM_COLD_CALL) part = run_tile_general(io, pl, role, kind);
+            else {
                 if (kind == RL_DQN) policy_pair2<RL_DQN, RL_RUN_COHERENT>(io, lane, role, &pl, &part);
                 else if (kind == RL_PPO) policy_pair2<RL_PPO, RL_RUN_COHERENT>(io, lane, role, &pl, &part);
                 else policy_tile1s<RL_PERD3QN, RL_RUN_COHERENT, true>(io, lane, role, &pl, &part);
@@ -890,7 +920,13 @@ __device__ __forceinline__ void run_tick_body(RunParamsC* ka)
         }
     }
     RL_MARK(68);
-    if (tid == 0) { ps.meta[1] = n2; ps.meta[2] = cur ^ 1; ps.meta[3] = ticks_done + 1; ps.meta[4] = ps.xmirror != nullptr; ps.meta[8] = tick_next; ps.meta[9] = epoch_next; }
+    if (tid == 0) { ps.meta[1] = n2; ps.meta[2] = cur ^ 1; ps.meta[3] = ticks_done + 1; }
+    // (the mirror holds the rows from the launch's first tick on: written in that tick only -- written every tick, the loop-invariant 0 / 1 was
+    // hoisted out of the tick loop as a VGPR, spilled, and reloaded here behind an s_waitcnt vmcnt(0) on wave 0: round 6, found in the ISA)
+    if (ticks_done == 0 && tid == 0) ps.meta[4] = ps.xmirror != nullptr;
+    // (RL_SEAM_OPEN: the next policy half's Philox keys are in place BEFORE recycle_world's first barrier -- nobody reads the two words in this
+    // interval --, and recycle_world writes the same values again)
+    if (RL_SEAM_OPEN && tid == 64) { s.scal[S_TICK] = tick_next; s.scal[S_EPOCH] = epoch_next; }
     const bool seam_open = RL_SEAM_OPEN && T == 512 && ticks_done + 1 < *(const int __attribute__((address_space(4)))*)&ka->ra.n_ticks;   // (uniform; the launch's last tick: store_world follows)
     // (rows the policy will read back from memory must have reached L2 first; with every row mirrored in LDS the stores just drain)
     // (capture copies the rows the policy read back from memory a tick later: they must have arrived)
@@ -993,7 +1029,6 @@ __device__ __forceinline__ void run_load_call(RunParamsC* ka)   // (inlined: loa
     }
     if (tid == 0) {
         ps.meta[1] = n0; ps.meta[2] = first; ps.meta[3] = 0; ps.meta[4] = preload ? 1 : 0;
-        ps.meta[8] = ((cint*)ka->p.st.tick)[blockIdx.x]; ps.meta[9] = ((cint*)ka->p.st.epoch)[blockIdx.x];   // (what load_world puts into s.scal[S_TICK] / [S_EPOCH])
         if constexpr (KIND == kKindAll) ps.oflags[0] = run_obs_flags(p, s, n0, ps.oflags[1]);
     }
     if (TRAIN && p.so.trk_tick) {   // the Tracker's running sums live in LDS for the length of the launch
@@ -1006,7 +1041,7 @@ __device__ __forceinline__ void run_load_call(RunParamsC* ka)   // (inlined: loa
         if constexpr (KIND == kKindAll) { if (tid < kRunMaxBrains) ps.bkind[tid] = tid < p.n_brains ? ((const int __attribute__((address_space(4)))*)ka->ra.kind)[tid] : RL_D3QN; }
         policy_lists_wave0(p, ps, n0, tid, [&](int k) { return s.brain[k]; });   // (slot == list index after load_world)
         if (T == 1024 && tid == 0) ps.meta[5] = ps.meta[0] > 4;
-        if constexpr (KIND == kKindAll) policy_schedule_wave0(p, ps, ka, tid);
+        if constexpr (KIND == kKindAll) policy_schedule_wave0(p, ps, ka, tid, true);
     }
     RL_MARK(93);
     if (ctotal > 0) {   // the brains' epilogue constants (three 128-wide layers x 256 floats + the heads') for policy_tile1s

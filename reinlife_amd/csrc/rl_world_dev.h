@@ -34,7 +34,16 @@
 // The thread index as the multi-tick kernel sees it: opaque, so that nothing derived from it is loop-invariant.  k_run runs
 // policy and tick back to back inside a tick loop; with the plain builtin every per-thread constant of the tick phases (window
 // offsets, row bases, ...) was hoisted out of that loop and kept alive -- i.e. spilled -- across the 126-VGPR tile code.
+// RL_TIDX_VIA_WAVE (the multi-tick kernel's translation units, round 6): the thread index as wave index (uniform: ONE readfirstlane at the
+// kernel's top, kept in an SGPR -- an SGPR that does not fit is parked in a VGPR lane, not in memory) x 64 + the lane index from v_mbcnt.  The
+// work-item id VGPR then dies in the kernel's preamble instead of living through the 256-VGPR tile code: in the TRAIN kernels it was spilled,
+// and every rl_tidx() of the tick half was a scratch reload + s_waitcnt vmcnt(0) (six of them in the Tracker pass alone).
+#ifdef RL_TIDX_VIA_WAVE
+__device__ inline int rl_lane_fresh();
+__device__ inline int rl_tidx() { return rl_lane_fresh() + (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) << 6); }
+#else
 __device__ inline int rl_tidx() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+#endif
 // The lane index WITHOUT the thread index: at the head of the policy half the thread index has been spilled (the tile code takes all 256
 // VGPRs), and its reload is a memory round trip that also waits for the wave's observation-row stores.  Opaque for the same reason as above.
 __device__ inline int rl_lane_fresh()
@@ -767,6 +776,14 @@ __device__ __forceinline__ void write_observations(const KParams& p, Smem& s, in
                 }
         }
     }
+    // (Loop invariants of the multi-tick kernel's TICK loop must not outlive a tick: the compiler hoists (double)max_agents and the zero
+    // vector of the mirror's padding to the kernel's preamble, the 256-VGPR tile code makes it spill them, and every reload here is a
+    // scratch load + s_waitcnt vmcnt(0) -- which also waits for every observation-row store this wave has just issued.  Found in the ISA
+    // of the mixed-kind kernel in round 6; both values are rebuilt from opaque operands where they are used: one v_cvt / v_mov each.)
+    int max_agents_here = p.max_agents;
+    asm volatile("" : "+s"(max_agents_here));
+    float zero_here = 0.0f;
+    asm volatile("" : "+v"(zero_here));
     for (int k = t; k < n; k += NT) {
         const int a = s.order[k];
         const int same = (int)(s.hcnt[s.hslot[a]] >> 16);
@@ -774,7 +791,7 @@ __device__ __forceinline__ void write_observations(const KParams& p, Smem& s, in
         const float v0 = (float)((double)s.health[a] * rl_one_200th());  // == (float)(health / 200.0), see build_planes
         const float v1 = (s.flags[a] & RL_F_REPRODUCED) ? 1.f : 0.f;
         const float v2 = (float)((double)same / (double)n);
-        const float v3 = (float)((double)n / (double)p.max_agents);
+        const float v3 = (float)((double)n / (double)max_agents_here);
         const float v4 = (s.flags[a] & RL_F_KILLED) ? 1.f : 0.f;
         const float v5 = (s.flags[a] & RL_F_ATE_SUPER) ? 1.f : -1.f;
         o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4; o[5] = v5;
@@ -783,7 +800,7 @@ __device__ __forceinline__ void write_observations(const KParams& p, Smem& s, in
             m[0] = v0; m[1] = v1; m[2] = v2; m[3] = v3; m[4] = v4; m[5] = v5;
             // floats 153 .. 159 of a mirror row are the zero padding of the input layer's last K-chunk (the four-wave tile reads the chunk
             // as it lies; the tiles' exchange buffers alias the mirror, so the padding is rewritten with the row)
-            m[6] = 0.0f; m[7] = 0.0f; m[8] = 0.0f; *(float4*)(m + 9) = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            m[6] = zero_here; m[7] = zero_here; m[8] = zero_here; *(float4*)(m + 9) = float4{zero_here, zero_here, zero_here, zero_here};
         }
     }
 }
@@ -1448,7 +1465,9 @@ __device__ __forceinline__ void track_world_wave0(const KParams& p, Smem& s, int
     const bool by_atomics = 16 * G <= 8 * p.cap && n1 <= 4096;
     if (by_atomics) {
         unsigned* const acc4 = (unsigned*)scr;
-        if (lane < G) { acc4[4 * lane] = 0u; acc4[4 * lane + 1] = 0u; acc4[4 * lane + 2] = 0u; acc4[4 * lane + 3] = 0u; }
+        unsigned zero_here = 0u;   // (opaque: as a constant the 16-byte zero vector was hoisted out of the multi-tick kernel's tick loop, spilled, and reloaded
+        asm volatile("" : "+v"(zero_here));   //  here behind an s_waitcnt vmcnt(0) -- see write_observations)
+        if (lane < G) { acc4[4 * lane] = zero_here; acc4[4 * lane + 1] = zero_here; acc4[4 * lane + 2] = zero_here; acc4[4 * lane + 3] = zero_here; }
         for (int base = 0; base < n1; base += 64) {
             const int k = base + lane;
             if (k < n1) {
