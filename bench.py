@@ -593,8 +593,8 @@ def main():
     # (its exit from the opening barrier + synchronise) to the LATEST rank's end -- start skew between the ranks is inside the figure, the
     # closing barrier's own latency (a collective, not work of the K steps) is not; the bracketed figure (closing barrier + synchronise
     # included: the contract's literal bracket) is reported beside it as value_incl_closing_barrier.  One rank: all three are the same interval.
-    elapsed = time.perf_counter() - t0
     t1_shared = time.monotonic_ns()
+    elapsed = (t1_shared - t0_shared) * 1e-9   # (this rank's own K steps, on the same clock as the job's figure: own <= job by construction)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()

@@ -477,7 +477,10 @@ __device__ __forceinline__ void run_policy1(const KParams& p, Smem& s, PolSmem& 
         if (p.prof && (int)blockIdx.x == p.prof_world && lane == 0) p.prof[116 + wave] = (long long)clock64();   // (128 slots)
 #endif
         lds_barrier();
-        if (have && role == 0) tile1_finish<KIND>(io, lane, part.head, pl.val[j], part.draw, *(const f32x4*)((const float*)(smem_base + io.c_lds_off) + 768 + 8 + 4 * (lane >> 5)));
+        if (have && role == 0) {   // (a fresh lane index: `lane` / `j` from above the tile lived through it -- spilled in the TRAIN instantiations, a reload behind vmcnt(0) right here)
+            const int fl = rl_lane_fresh();
+            tile1_finish<KIND>(io, fl, part.head, pl.val[fl & 31], part.draw, *(const f32x4*)((const float*)(smem_base + io.c_lds_off) + 768 + 8 + 4 * (fl >> 5)));
+        }
     } else
     for (int ti = wave; ti < ntiles; ti += T / 64) {
         TileIO io;
@@ -588,9 +591,10 @@ __device__ __forceinline__ void run_policy_all(const KParams& p, Smem& s, PolSme
         } else { lds_barrier(); lds_barrier(); }   // (the two exchanges inside a tile)
         lds_barrier();
         if (have && role == 0) {
-            if (kind == RL_DQN) pair_finish<RL_DQN>(io, lane, part, &pl);
-            else if (kind == RL_PPO) pair_finish<RL_PPO>(io, lane, part, &pl);
-            else tile1_finish<RL_PERD3QN>(io, lane, part.head, pl.val[j], part.draw, *(const f32x4*)((const float*)(smem_base + io.c_lds_off) + 768 + 8 + 4 * (lane >> 5)));
+            const int fl = rl_lane_fresh();   // (not the lane index from above the tile: see run_policy1)
+            if (kind == RL_DQN) pair_finish<RL_DQN>(io, fl, part, &pl);
+            else if (kind == RL_PPO) pair_finish<RL_PPO>(io, fl, part, &pl);
+            else tile1_finish<RL_PERD3QN>(io, fl, part.head, pl.val[fl & 31], part.draw, *(const f32x4*)((const float*)(smem_base + io.c_lds_off) + 768 + 8 + 4 * (fl >> 5)));
         }
     };
     // meta[5] == 0: every tile in ONE round, the waves dealt over the SIMDs by cost (policy_schedule_wave0), rows from the mirror.

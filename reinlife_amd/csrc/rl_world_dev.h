@@ -34,16 +34,7 @@
 // The thread index as the multi-tick kernel sees it: opaque, so that nothing derived from it is loop-invariant.  k_run runs
 // policy and tick back to back inside a tick loop; with the plain builtin every per-thread constant of the tick phases (window
 // offsets, row bases, ...) was hoisted out of that loop and kept alive -- i.e. spilled -- across the 126-VGPR tile code.
-// RL_TIDX_VIA_WAVE (the multi-tick kernel's translation units, round 6): the thread index as wave index (uniform: ONE readfirstlane at the
-// kernel's top, kept in an SGPR -- an SGPR that does not fit is parked in a VGPR lane, not in memory) x 64 + the lane index from v_mbcnt.  The
-// work-item id VGPR then dies in the kernel's preamble instead of living through the 256-VGPR tile code: in the TRAIN kernels it was spilled,
-// and every rl_tidx() of the tick half was a scratch reload + s_waitcnt vmcnt(0) (six of them in the Tracker pass alone).
-#ifdef RL_TIDX_VIA_WAVE
-__device__ inline int rl_lane_fresh();
-__device__ inline int rl_tidx() { return rl_lane_fresh() + (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) << 6); }
-#else
 __device__ inline int rl_tidx() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; }
-#endif
 // The lane index WITHOUT the thread index: at the head of the policy half the thread index has been spilled (the tile code takes all 256
 // VGPRs), and its reload is a memory round trip that also waits for the wave's observation-row stores.  Opaque for the same reason as above.
 __device__ inline int rl_lane_fresh()
@@ -213,7 +204,9 @@ __host__ __device__ inline size_t carve(Smem& s, char* base, int Cp, int cap, in
 // ---------------------------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------------------------
-__device__ inline int lane_id() { return rl_tidx() & 63; }
+// (from v_mbcnt, not from the work-item id: in the TRAIN instantiations of the multi-tick kernel the work-item id VGPR is spilled across the
+// tile code, and every lane_id() of the one-wave sections -- six in the Tracker pass alone -- was a scratch reload + s_waitcnt vmcnt(0))
+__device__ inline int lane_id() { return rl_lane_fresh(); }
 // float64 constants that must NOT be hoisted out of k_run's tick loop: loop-invariant 64-bit values are kept alive across the policy half's
 // 250-VGPR tile code, i.e. spilled, and every use becomes a scratch reload -- a memory round trip, on wave 0's serial sections at that
 // (the ISA of round 3 reloaded -1e300 twice per tick in _update_best_agents and 0.005 in the planes).  Built from opaque halves at the use site.

@@ -267,3 +267,29 @@ def test_the_header_says_what_the_product_library_runs_and_the_library_agrees():
     for block in (256, 1024):
         r, err = supported(256, world_block=block)
         assert r == 0 and "tuning-build" in err and ("%d-thread" % block) in err
+
+
+def test_builds_are_serialised_by_a_lock_and_files_are_moved_into_place():
+    """reinlife_amd/build.py: N ranks that find the library stale together must not compile into the same files while
+    others dlopen them.  build() runs under an flock on lib/.build.lock (checked here with two processes: the second waits for the first)
+    and writes every object and the library under a temporary name before os.replace() (checked in the source: no compiler or linker
+    command line names a final path as its output)."""
+    import subprocess
+    import sys
+    import time
+    from reinlife_amd import build
+    holder = subprocess.Popen([sys.executable, "-c",
+                               "import sys, time; sys.path.insert(0, %r)\nfrom reinlife_amd import build\nwith build._BuildLock():\n    print('held', flush=True); time.sleep(1.5)\n" % ROOT],
+                              stdout=subprocess.PIPE, text=True)
+    assert holder.stdout.readline().strip() == "held"
+    t0 = time.perf_counter()
+    with build._BuildLock():
+        waited = time.perf_counter() - t0
+    holder.wait()
+    assert waited > 0.8, "the lock did not wait for its holder (%.2f s)" % waited
+    t0 = time.perf_counter()
+    with build._BuildLock():
+        assert time.perf_counter() - t0 < 0.5            # free again
+    src = open(os.path.join(ROOT, "reinlife_amd", "build.py")).read()
+    assert '"-o", obj + tmp_tag]' in src and '"-o", LIB_PATH + tmp_tag]' in src and src.count("os.replace(obj + tmp_tag, obj)") == 1 and src.count("os.replace(LIB_PATH + tmp_tag, LIB_PATH)") == 1
+    assert build.library_is_current()                    # (and the shipped stamps are those of the shipped sources)
