@@ -73,3 +73,5 @@ done; cat $O/full_fence_soak.txt
   echo "== configs[4], TRAIN 0"; RL_AB_WORKLOAD=c5 timeout 600 python tools/run_ab.py $L/libreinlife_hip_r05.so $L/libreinlife_hip.so 4
   echo "== configs[3], TRAIN 1 (Tracker + epsilon schedule: what trainer() launches)"; RL_AB_TRAIN=1 timeout 600 python tools/run_ab.py $L/libreinlife_hip_r05.so $L/libreinlife_hip.so 3
   echo "== configs[4], TRAIN 1"; RL_AB_TRAIN=1 RL_AB_WORKLOAD=c5 timeout 600 python tools/run_ab.py $L/libreinlife_hip_r05.so $L/libreinlife_hip.so 3; } > $O/ab_vs_r05.txt 2>&1; cat $O/ab_vs_r05.txt
+# ---- 8. only the summaries travel back (gpurun merges at most 64 MiB): the rocpd databases stay on the box
+rm -rf gpurun_out/pmc gpurun_out/pmc_* $O/prof; du -sh gpurun_out | tail -1
