@@ -293,3 +293,25 @@ def test_builds_are_serialised_by_a_lock_and_files_are_moved_into_place():
     src = open(os.path.join(ROOT, "reinlife_amd", "build.py")).read()
     assert '"-o", obj + tmp_tag]' in src and '"-o", LIB_PATH + tmp_tag]' in src and src.count("os.replace(obj + tmp_tag, obj)") == 1 and src.count("os.replace(LIB_PATH + tmp_tag, LIB_PATH)") == 1
     assert build.library_is_current()                    # (and the shipped stamps are those of the shipped sources)
+
+
+def test_measurements_bench_reports_from_files_are_those_of_the_shipped_kernel_sources():
+    """bench.py takes three figures from tracked files -- PMC HBM traffic of the multi-tick launch (profiles/run_traffic.json), of the two
+    stand-alone kernels (profiles/tick_traffic.json) and the latency-bound model (profiles/latency_model.json) -- and drops each when the
+    kernel sources no longer hash to its stamp.  The shipped tree must carry stamps of the shipped sources (tick_traffic.json
+    had been three rounds stale, its fields null in every driver line): after a kernel change, re-take them (tools/final_round6.sh)."""
+    import json
+    from reinlife_amd import build
+    now = build.source_hash()
+    for name, keys in (("run_traffic.json", ("hbm_bytes_per_tick",)), ("tick_traffic.json", ("hbm_bytes_per_launch", "policy_hbm_bytes_per_launch")),
+                       ("latency_model.json", ("workloads",))):
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert d["kernel_src_sha16"] == now, "%s was measured on kernel sources %s, the tree holds %s" % (name, d["kernel_src_sha16"], now)
+        for k in keys:
+            assert d.get(k), (name, k)
+    m = json.load(open(os.path.join(ROOT, "profiles", "latency_model.json")))["workloads"]
+    for wl in ("c4", "c5"):
+        w = m[wl]
+        assert 0.2 < w["frac_of_latency_bound"] < 0.8
+        parts = w["mfma_slowest_simd"]["counts"] + w["barriers"]["counts"] + sum(w["one_wave_sections_counts"].values())
+        assert abs(parts - w["bound_counts"]) < 1.0 and abs(w["bound_counts"] / w["stamped_tick_counts"] - w["frac_of_latency_bound"]) < 1e-3
