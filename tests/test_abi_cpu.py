@@ -315,3 +315,20 @@ def test_measurements_bench_reports_from_files_are_those_of_the_shipped_kernel_s
         assert 0.2 < w["frac_of_latency_bound"] < 0.8
         parts = w["mfma_slowest_simd"]["counts"] + w["barriers"]["counts"] + sum(w["one_wave_sections_counts"].values())
         assert abs(parts - w["bound_counts"]) < 1.0 and abs(w["bound_counts"] / w["stamped_tick_counts"] - w["frac_of_latency_bound"]) < 1e-3
+
+
+def test_the_latency_bound_of_the_bench_line_reproduces_from_the_tracked_profiles(tmp_path):
+    """roofline.latency_bound_us (DESIGN.md 6.2): profiles/latency_model.json is what tools/latency_bound.py makes of the tracked unit costs
+    (profiles/r06_ubench.txt) and stamps (profiles/r06_stamps.txt) -- run it again and compare (VERDICT r05 next #5: 'reproducible from profiles/')."""
+    import json
+    import subprocess
+    import sys
+    out = tmp_path / "model.json"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "latency_bound.py"), os.path.join(ROOT, "profiles", "r06_ubench.txt"),
+                    os.path.join(ROOT, "profiles", "r06_stamps.txt"), str(out)], check=True, capture_output=True, cwd=ROOT)
+    new, kept = json.load(open(out)), json.load(open(os.path.join(ROOT, "profiles", "latency_model.json")))
+    assert new["workloads"] == kept["workloads"] and new["unit_costs_counts"] == kept["unit_costs_counts"]
+    u = kept["unit_costs_counts"]
+    assert 31.5 < u["mfma_pipe_counts"] < 32.5 and 40 < u["barrier_counts"] < 70 and 7 < u["valu_dependent_counts"] < 10
+    c4 = kept["workloads"]["c4"]
+    assert c4["mfma_slowest_simd"]["mfmas"] == 360 and abs(c4["mfma_slowest_simd"]["counts"] - 360 * u["mfma_pipe_counts"]) < 1
