@@ -407,8 +407,9 @@ def c5_leg(args, rank, device, dist=None):
 
 
 def latency_bound(workload, worlds, tick_s):
-    """roofline.latency_bound_us / frac_of_latency_bound (tools/latency_bound.py): the part of a k_run tick that is matrix-pipe
-    issue of the slowest SIMD + the tick's barriers + the sections one wave executes alone -- what remains if every data-parallel section cost
+    """roofline.latency_bound_us / frac_of_latency_bound (tools/latency_bound.py): the part of a k_run tick that is the policy
+    half's floor (matrix-pipe issue of the slowest SIMD, or the world's weight stream through the CU's load path, whichever is longer) + the
+    tick's barriers + the sections one wave executes alone -- what remains if every data-parallel section cost
     nothing -- as a fraction of the tick (taken in a stamped build, profiles/latency_model.json, valid for the kernel sources it is stamped
     with) times the tick measured HERE.  At one world per CU this, not the HBM or MFMA peak, is the floor the structure can approach."""
     path = os.path.join(ROOT, "profiles", "latency_model.json")
@@ -420,10 +421,12 @@ def latency_bound(workload, worlds, tick_s):
         if w and w.get("frac_of_latency_bound") and worlds <= 256 and m.get("kernel_src_sha16") == _build.source_hash():
             out = {"latency_bound_us": round(w["frac_of_latency_bound"] * tick_s * 1e6, 2), "frac_of_latency_bound": w["frac_of_latency_bound"],
                    "latency_model": {"file": "profiles/latency_model.json", "mfma_slowest_simd_counts": w["mfma_slowest_simd"]["counts"],
+                                     "weight_stream_counts": w["weight_stream"]["counts"], "weight_stream_kb_per_world_tick": w["weight_stream"]["kb_per_world_tick"],
+                                     "cu_load_bytes_per_clock": w["weight_stream"]["cu_load_bytes_per_clock"], "policy_floor_counts": w["policy_floor_counts"],
                                      "barriers_counts": w["barriers"]["counts"], "one_wave_sections_counts": w["one_wave_sections_counts"],
                                      "bound_counts": w["bound_counts"], "stamped_tick_counts": w["stamped_tick_counts"],
-                                     "how": "bound counts / the stamped build's tick counts x avg_tick_us; one world per CU: matrix-pipe issue of the slowest "
-                                            "SIMD + workgroup barriers + one-wave sections (DESIGN.md 6.2)"}}
+                                     "how": "bound counts / the stamped build's tick counts x avg_tick_us; one world per CU: max(matrix-pipe issue of the slowest "
+                                            "SIMD, the world's weight stream through the CU's 64 B/clk load path) + workgroup barriers + one-wave sections (DESIGN.md 6.2)"}}
     except Exception:  # noqa: BLE001
         pass
     return out

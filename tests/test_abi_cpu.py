@@ -313,7 +313,9 @@ def test_measurements_bench_reports_from_files_are_those_of_the_shipped_kernel_s
     for wl in ("c4", "c5"):
         w = m[wl]
         assert 0.2 < w["frac_of_latency_bound"] < 0.8
-        parts = w["mfma_slowest_simd"]["counts"] + w["barriers"]["counts"] + sum(w["one_wave_sections_counts"].values())
+        assert w["policy_floor_counts"] == max(w["mfma_slowest_simd"]["counts"], w["weight_stream"]["counts"])
+        assert abs(w["weight_stream"]["counts"] - w["weight_stream"]["kb_per_world_tick"] * 1024 / w["weight_stream"]["cu_load_bytes_per_clock"]) < 1.0
+        parts = w["policy_floor_counts"] + w["barriers"]["counts"] + sum(w["one_wave_sections_counts"].values())
         assert abs(parts - w["bound_counts"]) < 1.0 and abs(w["bound_counts"] / w["stamped_tick_counts"] - w["frac_of_latency_bound"]) < 1e-3
 
 

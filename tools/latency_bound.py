@@ -1,7 +1,11 @@
 """roofline.latency_bound_us: what ONE tick of the multi-tick kernel costs a world that has its CU to itself when
 every data-parallel section costs nothing -- the part of the tick that more waves, more ILP or fewer bytes cannot remove in this structure:
 
-  (i)   the matrix pipe of the slowest SIMD:   MFMAs of the tiles dealt to it x mfma_pipe_counts            (profiles/r06_ubench.txt)
+  (i)   the policy half's floor, the larger of
+        the matrix pipe of the slowest SIMD:   MFMAs of the tiles dealt to it x mfma_pipe_counts            (profiles/r06_ubench.txt)
+        the world's weight stream:             packed fragment bytes of its tiles / the CU's vector-load path (64 B per shader clock whether
+                                               the lines come from L1, L2 or beyond: profiles/r06_ubench_cu_load_bw.txt) -- every 32-row tile reads
+                                               its brain's fragments once per tick (dueling 240 KB, PPO 448 KB, DQN 120 KB)
   (ii)  the tick's workgroup barriers:         barriers per tick x barrier_counts                            (profiles/r06_ubench.txt)
   (iii) the sections ONE wave executes alone:  _reproduce (wave 0), _add_food's placement (wave 0), the next tick's row lists (+ the tile
         schedule of the mixed-kind kernel) -- their shader-clock stamps in the stamped build                 (profiles/r06_stamps.txt)
@@ -28,6 +32,20 @@ SLOWEST_SIMD_MFMA = {"c4": TILE_MFMA["dueling"], "c5": (TILE_MFMA["PPO"] + TILE_
 # the movement fixed point -- every further round adds two): policy half 4 (two exchanges inside a tile, behind the tiles, behind the
 # finish), phase_step 7, run_tick_body 4, recycle_world 1 (RL_SEAM_OPEN)
 BARRIERS = {"c4": 16, "c5": 16}
+# packed weight fragments a 32-row tile streams per tick, KB (rl_policy_dev.h layout_of / frag_floats: [chunks][output tiles][2 planes] x 1 KB):
+#   dueling 10*4*2 + 2 * (8*4*2) + 2 * (8*1*2) = 240;  PPO 10*8*2 + 16*8*2 + 16*1*2 = 448;  DQN 10*4*2 + 8*2*2 + 4*1*2 = 120
+TILE_WEIGHT_KB = {"dueling": 240, "PPO": 448, "DQN": 120}
+WORLD_WEIGHT_KB = {"c4": 4 * TILE_WEIGHT_KB["dueling"], "c5": 2 * TILE_WEIGHT_KB["PPO"] + 2 * TILE_WEIGHT_KB["dueling"]}   # four tiles per world
+
+
+def parse_load_bw(path):
+    """bytes per shader clock per CU: the best L2-resident line of tools/ubench/cu_load_bw.hip"""
+    best = 0.0
+    for ln in open(path):
+        m = re.search(r"buffer\s+480 KB.*?([0-9.]+) B per shader clock per CU", ln)
+        if m:
+            best = max(best, float(m.group(1)))
+    return best
 
 
 def parse_ubench(path):
@@ -71,6 +89,8 @@ def parse_stamps(path):
 
 def main():
     ub, st = parse_ubench(sys.argv[1]), parse_stamps(sys.argv[2])
+    bw_path = os.path.join(os.path.dirname(os.path.abspath(sys.argv[1])), "r06_ubench_cu_load_bw.txt")
+    load_bw = parse_load_bw(bw_path) if os.path.exists(bw_path) else 0.0
     from reinlife_amd import build
     model = {"kernel_src_sha16": build.source_hash(), "inputs": {"ubench": os.path.relpath(sys.argv[1], ROOT), "stamps": os.path.relpath(sys.argv[2], ROOT)},
              "unit_costs_counts": {k: ub[k] for k in ("mfma_pipe_counts", "barrier_counts", "valu_dependent_counts", "lds_round_trip_counts", "l2_round_trip_counts") if k in ub},
@@ -82,9 +102,12 @@ def main():
         serial = {"reproduce_wave0": s.get("reproduce", 0.0), "add_food_placement_wave0": s.get("food_placement", 0.0),
                   "row_lists_wave0": s.get("lists", 0.0) + (s.get("schedule", 0.0) if wl == "c5" else 0.0)}
         mfma = SLOWEST_SIMD_MFMA[wl] * ub["mfma_pipe_counts"]
+        stream = WORLD_WEIGHT_KB[wl] * 1024.0 / load_bw if load_bw else 0.0
         bars = BARRIERS[wl] * ub["barrier_counts"]
-        bound = mfma + bars + sum(serial.values())
-        w = {"mfma_slowest_simd": {"mfmas": SLOWEST_SIMD_MFMA[wl], "counts": round(mfma, 1)}, "barriers": {"n": BARRIERS[wl], "counts": round(bars, 1)},
+        bound = max(mfma, stream) + bars + sum(serial.values())
+        w = {"mfma_slowest_simd": {"mfmas": SLOWEST_SIMD_MFMA[wl], "counts": round(mfma, 1)},
+             "weight_stream": {"kb_per_world_tick": WORLD_WEIGHT_KB[wl], "cu_load_bytes_per_clock": load_bw, "counts": round(stream, 1)},
+             "policy_floor_counts": round(max(mfma, stream), 1), "barriers": {"n": BARRIERS[wl], "counts": round(bars, 1)},
              "one_wave_sections_counts": {k: round(v, 1) for k, v in serial.items()}, "bound_counts": round(bound, 1),
              "stamped_tick_half_counts": s["tick_total"], "stamped_policy_half_counts": pol_total}
         if pol_total:
