@@ -111,3 +111,19 @@ def test_the_tuning_library_runs_the_forced_workgroup_sizes_the_product_refuses(
     assert "not in the product library" not in out.stdout, tail
     m = re.search(r"(\d+) skipped", tail)
     assert m is None or int(m.group(1)) <= 2, tail
+
+
+def test_mfma_16x16x32_chains_give_the_bits_of_32x32x16_chains(tmp_path):
+    """The hardware fact DESIGN.md 5.12 / section 9 rest on: a chain of v_mfma_f32_16x16x32_f16 over the same k slots gives
+    the same f32 bits as the chain of v_mfma_f32_32x32x16_f16 every policy tile runs -- tools/ubench/mfma_shapes.hip, 400 trials x 1,024 dot
+    products over 96 k from a non-zero accumulator -- at 18 instead of 32 matrix-pipe counts per instruction."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    exe = str(tmp_path / "mfma_shapes")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-o", exe, os.path.join(ROOT, "tools", "ubench", "mfma_shapes.hip")], check=True, capture_output=True, timeout=300)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120, check=True).stdout
+    m = re.search(r"results_differing_in_bits (\d+) of (\d+)", out)
+    assert m and int(m.group(1)) == 0 and int(m.group(2)) == 409600, out
+    p = re.search(r"pipe_counts_per_mfma 32x32x16 ([0-9.]+)\s+16x16x32 ([0-9.]+)", out)
+    assert p and 30.0 < float(p.group(1)) < 34.0 and 16.0 < float(p.group(2)) < 20.0, out
